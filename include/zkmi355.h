@@ -1,0 +1,148 @@
+/*
+ * zkmi355.h — C ABI of libzkmi355.so: the MI355X (gfx950) backend for the halo2 KZG prover
+ * hot path of CliqueOfficial/zk-dcap-verifier.
+ *
+ * The reference has no FFI of its own; it reaches this arithmetic only through
+ *     create_proof   circuits/src/sgx_dcap_verifier.rs:814-822, crates/p256-ecdsa/src/base.rs:193-212
+ *     keygen_vk/pk   circuits/src/sgx_dcap_verifier.rs:803,807,       crates/p256-ecdsa/src/base.rs:145
+ *     gen_srs        circuits/src/sgx_dcap_verifier.rs:799,           crates/p256-ecdsa/src/base.rs:134
+ * which bottom out in halo2_proofs 0.2.0 (zkwebauthn @ c254c75, Cargo.lock:1314-1327)
+ * arithmetic::{best_multiexp, best_fft}, poly::EvaluationDomain::* and
+ * plonk::evaluation::Evaluator::evaluate_h.  Each entry point below names the function of that
+ * crate it replaces; INTEGRATION.md shows the Rust `extern "C"` shim a maintainer patches in with
+ * Cargo [patch] (the mechanism the reference already uses, Cargo.toml:5-7).
+ *
+ * Conventions
+ *   - Field elements are 32 bytes: 4 x u64 little-endian limbs in Montgomery form (R = 2^256),
+ *     i.e. the in-memory representation of halo2curves::bn256::{Fr,Fq} — no conversion at the FFI.
+ *   - G1Affine = {x, y} (64 B), identity = (0, 0).  G1 = {x, y, z} Jacobian (96 B).
+ *   - All functions return 0 (ZK_OK) or a negative error code; nothing throws or aborts.
+ *     zk_last_error() returns a human-readable description of the last failure on that context.
+ *   - A context is bound to one GPU and is thread-safe (calls are serialised internally and
+ *     block until the result is valid).  One process per GPU is the intended deployment; several
+ *     contexts (one per device) may coexist in one process.
+ *   - "host" pointers are ordinary process memory owned by the caller; the library never keeps a
+ *     host pointer after the call returns.  "_dev" variants take device pointers (hipMalloc'ed
+ *     or torch CUDA tensors) resident on the context's GPU.
+ *   - There is NO CPU fallback: without a usable gfx950 device zk_ctx_create fails.
+ */
+#ifndef ZKMI355_H
+#define ZKMI355_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_OK 0
+#define ZK_ERR_ARG (-1)     /* bad argument (null pointer, size out of range, unknown handle) */
+#define ZK_ERR_HIP (-2)     /* a HIP runtime call failed                                     */
+#define ZK_ERR_NODEV (-3)   /* no usable GPU                                                  */
+#define ZK_ERR_PROGRAM (-4) /* malformed / unsupported quotient program                       */
+#define ZK_ERR_LIMIT (-5)   /* size limit of this build exceeded                              */
+
+typedef struct zk_ctx zk_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int zk_ctx_create(int device_id, zk_ctx** out);
+void zk_ctx_destroy(zk_ctx* ctx);
+const char* zk_last_error(zk_ctx* ctx);
+/* runtime tunables, e.g. "msm_c", "ntt_tile_log" (see DESIGN.md); unknown key -> ZK_ERR_ARG */
+int zk_tune_set(zk_ctx* ctx, const char* key, int value);
+int zk_tune_get(zk_ctx* ctx, const char* key, int* value);
+/* per-kernel HIP-event timing of the most recent call (enable with zk_timing_enable(ctx, 1));
+ * zk_timing_get returns milliseconds for a kernel label such as "msm_accumulate", or < 0. */
+int zk_timing_enable(zk_ctx* ctx, int on);
+float zk_timing_get(zk_ctx* ctx, const char* label);
+
+/* ---- device memory helpers (so callers need no HIP of their own) -------------------------- */
+int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** dptr);
+int zk_dev_free(zk_ctx* ctx, void* dptr);
+int zk_dev_upload(zk_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int zk_dev_download(zk_ctx* ctx, void* host, const void* dptr, size_t bytes);
+int zk_dev_sync(zk_ctx* ctx);
+
+/* ---- MSM: replaces arithmetic::best_multiexp / ParamsKZG::{commit, commit_lagrange} -------- *
+ * halo2_proofs src/arithmetic.rs best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1 and
+ * src/poly/kzg/commitment.rs commit{,_lagrange} (bases = params.g / params.g_lagrange, fixed per
+ * SRS).  A base table is registered once (copied to HBM and expanded to its window multiples
+ * 2^(c*j) * P_i so that every window shares one bucket set); each MSM then only ships scalars.  */
+int zk_bases_register(zk_ctx* ctx, const void* g1_affine_host, size_t n, uint64_t* handle);
+int zk_bases_register_dev(zk_ctx* ctx, const void* g1_affine_dev, size_t n, uint64_t* handle);
+int zk_bases_release(zk_ctx* ctx, uint64_t handle);
+/* out_jacobian: 96 B, always normalised: (x, y, mont(1)) or (0, 0, 0) for the identity — a valid
+ * halo2curves G1 value.  n may be smaller than the registered table (prefix is used). */
+int zk_msm(zk_ctx* ctx, uint64_t bases, const void* scalars_host, size_t n, void* out_jacobian);
+int zk_msm_dev(zk_ctx* ctx, uint64_t bases, const void* scalars_dev, size_t n, void* out_jacobian);
+/* unnormalised partial result as 128 B XYZZ (X, Y, ZZ, ZZZ) for multi-GPU sharding: partial
+ * results of the ranks are exchanged (RCCL all-gather) and combined with zk_g1_sum_xyzz. */
+int zk_msm_partial_dev(zk_ctx* ctx, uint64_t bases, const void* scalars_dev, size_t n, void* out_xyzz_host);
+int zk_g1_sum_xyzz(const void* xyzz_host, size_t count, void* out_jacobian);
+
+/* fixed-base batch: out[i] = [s_i] * G1::generator(), affine.  Replaces the n fixed-base
+ * multiplications of ParamsKZG::setup (halo2_proofs src/poly/kzg/commitment.rs), reached from
+ * gen_srs (sgx_dcap_verifier.rs:799); also used to build synthetic SRS-shaped tables. */
+int zk_g1_fixed_base_mul_dev(zk_ctx* ctx, const void* scalars_dev, size_t n, void* out_affine_dev);
+
+/* ---- NTT: replaces arithmetic::best_fft (G = Fr) and the EvaluationDomain wrappers --------- *
+ * halo2_proofs src/arithmetic.rs best_fft(a, omega, log_n): in place, natural order in and out,
+ * out[j] = sum_i a[i] * omega^(i*j).  omega: 32 B Montgomery.                                   */
+int zk_ntt(zk_ctx* ctx, void* a_host, uint32_t log_n, const void* omega);
+int zk_ntt_dev(zk_ctx* ctx, void* a_dev, uint32_t log_n, const void* omega);
+/* halo2_proofs src/poly/domain.rs — fused forms (j = cs.degree(), as EvaluationDomain::new(j,k)) */
+int zk_lagrange_to_coeff_dev(zk_ctx* ctx, void* a_dev, uint32_t k);                 /* ifft * n^-1  */
+int zk_coeff_to_lagrange_dev(zk_ctx* ctx, void* a_dev, uint32_t k);
+/* coeff (2^k) -> extended coset evaluations (2^extended_k): zeta^(i mod 3) scaling, zero pad, NTT */
+int zk_coeff_to_extended_dev(zk_ctx* ctx, const void* coeff_dev, uint32_t k, uint32_t extended_k, void* out_dev);
+/* inverse of the above, in place on 2^extended_k values; entries [0, out_len) are the result    */
+int zk_extended_to_coeff_dev(zk_ctx* ctx, void* a_ext_dev, uint32_t k, uint32_t extended_k);
+/* a[i] *= t_evaluations[i mod 2^(extended_k-k)] (1/(X^n - 1) on the coset)                      */
+int zk_divide_by_vanishing_poly_dev(zk_ctx* ctx, void* a_ext_dev, uint32_t k, uint32_t extended_k);
+int zk_lagrange_to_coeff(zk_ctx* ctx, void* a_host, uint32_t k);
+int zk_coeff_to_extended(zk_ctx* ctx, const void* coeff_host, uint32_t k, uint32_t extended_k, void* out_host);
+int zk_extended_to_coeff(zk_ctx* ctx, void* a_ext_host, uint32_t k, uint32_t extended_k);
+
+/* ---- element-wise Fr vector ops used around the NTTs (device) ------------------------------ */
+int zk_fr_mul_dev(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n);
+int zk_fr_add_dev(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n);
+int zk_fr_sub_dev(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n);
+int zk_fr_scale_dev(zk_ctx* ctx, const void* a, const void* scalar_host, void* out, size_t n);
+/* Fq flavour of mul (used by the parity tests of the curve field) */
+int zk_fq_mul_dev(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n);
+
+/* ---- quotient: replaces plonk::evaluation::Evaluator::evaluate_h ---------------------------- *
+ * halo2_proofs src/plonk/evaluation.rs.  The compiled GraphEvaluator of a proving key is uploaded
+ * once as a "ZKQ1" blob (layout in DESIGN.md / INTEGRATION.md), then run per proof on
+ * device-resident extended cosets.  Column pointer arrays are HOST arrays of DEVICE pointers.     */
+typedef struct zk_quotient_args {
+    const void* const* fixed;        /* n_fixed cosets                                        */
+    const void* const* advice;       /* n_advice cosets                                       */
+    const void* const* instance;     /* n_instance cosets                                     */
+    const void* l0;
+    const void* l_last;
+    const void* l_active_row;
+    const void* const* perm_cosets;  /* sigma cosets, one per permutation column              */
+    const void* const* perm_products;/* z cosets, one per set                                 */
+    uint32_t n_sets;
+    const void* const* lookup_product;
+    const void* const* lookup_input;
+    const void* const* lookup_table;
+    const void* challenges;          /* HOST: n_challenges x 32 B                             */
+    const void* beta;                /* HOST 32 B each                                        */
+    const void* gamma;
+    const void* theta;
+    const void* y;
+    void* out;                       /* DEVICE: 2^extended_k x 32 B, overwritten              */
+} zk_quotient_args;
+int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
+int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog);
+int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args);
+
+/* library / build identification */
+const char* zk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKMI355_H */

@@ -1,0 +1,24 @@
+// TEST-ONLY: runs the product's __host__ __device__ field / curve routines on the CPU so the
+// limb logic can be checked against the oracle without a GPU (tests/test_host_logic.py).
+// It is not a CPU fallback: the product library never links this file.
+#include "../../zk-dcap-verifier_amd/csrc/ec.cuh"
+using namespace zk;
+extern "C" {
+void hh_fr_mul(const u256* a, const u256* b, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fr::mul(a[i], b[i]); }
+void hh_fr_add(const u256* a, const u256* b, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fr::add(a[i], b[i]); }
+void hh_fr_sub(const u256* a, const u256* b, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fr::sub(a[i], b[i]); }
+void hh_fr_neg(const u256* a, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fr::neg(a[i]); }
+void hh_fr_inv(const u256* a, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fr::inv(a[i]); }
+void hh_fr_from_mont(const u256* a, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fr::from_mont(a[i]); }
+void hh_fq_mul(const u256* a, const u256* b, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fq::mul(a[i], b[i]); }
+void hh_fq_add(const u256* a, const u256* b, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fq::add(a[i], b[i]); }
+void hh_fq_sub(const u256* a, const u256* b, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fq::sub(a[i], b[i]); }
+// acc (XYZZ) += sign * p for a list of affine points; acc starts at identity
+void hh_xyzz_sum(const Affine* pts, const uint8_t* neg, size_t n, XYZZ* out) {
+    XYZZ acc = xyzz_identity();
+    for (size_t i = 0; i < n; i++) xyzz_madd_signed(acc, pts[i], neg[i] != 0);
+    *out = acc;
+}
+void hh_xyzz_add(const XYZZ* a, const XYZZ* b, XYZZ* out) { XYZZ t = *a; xyzz_add(t, *b); *out = t; }
+void hh_xyzz_dbl(const XYZZ* a, XYZZ* out) { *out = xyzz_dbl(*a); }
+}

@@ -1,0 +1,269 @@
+"""ctypes binding of libzkmi355.so (include/zkmi355.h).  Thin: pointers and sizes only.
+
+The product path FAILS LOUDLY when the HIP library is missing or no GPU is usable — there is no
+CPU implementation behind this module.  (Tests that exercise kernel index logic on a machine
+without a GPU pass an explicit ``lib_path`` to the emulator build under tests/csrc/; nothing in
+this package knows about or defaults to it.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libzkmi355.so")
+
+ZK_OK = 0
+_ERR_NAMES = {-1: "ZK_ERR_ARG", -2: "ZK_ERR_HIP", -3: "ZK_ERR_NODEV", -4: "ZK_ERR_PROGRAM", -5: "ZK_ERR_LIMIT"}
+
+
+class ZkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{_ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class QuotientArgs(C.Structure):
+    _fields_ = [("fixed", C.c_void_p), ("advice", C.c_void_p), ("instance", C.c_void_p),
+                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
+                ("perm_cosets", C.c_void_p), ("perm_products", C.c_void_p), ("n_sets", C.c_uint32),
+                ("lookup_product", C.c_void_p), ("lookup_input", C.c_void_p), ("lookup_table", C.c_void_p),
+                ("challenges", C.c_void_p), ("beta", C.c_void_p), ("gamma", C.c_void_p), ("theta", C.c_void_p),
+                ("y", C.c_void_p), ("out", C.c_void_p)]
+
+
+def _load(path: str):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.zk_last_error.restype = C.c_char_p
+    lib.zk_version.restype = C.c_char_p
+    lib.zk_timing_get.restype = C.c_float
+    return lib
+
+
+def _dptr(x) -> int:
+    """Device pointer of a DeviceBuffer / torch tensor / int."""
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "ptr"):
+        return int(x.ptr)
+    if hasattr(x, "data_ptr"):
+        return int(x.data_ptr())
+    raise TypeError(f"not a device buffer: {type(x)}")
+
+
+class DeviceBuffer:
+    """hipMalloc'ed buffer owned through the C ABI (so callers need neither torch nor HIP)."""
+
+    def __init__(self, backend: "Backend", nbytes: int):
+        self.backend, self.nbytes = backend, int(nbytes)
+        p = C.c_void_p()
+        backend._ck(backend.lib.zk_dev_alloc(backend.ctx, C.c_size_t(self.nbytes), C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray, offset: int = 0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        b = self.backend
+        b._ck(b.lib.zk_dev_upload(b.ctx, C.c_void_p(self.ptr + offset), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
+        return self
+
+    def download(self, shape, dtype=np.uint64, offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        b = self.backend
+        b._ck(b.lib.zk_dev_download(b.ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + offset), C.c_size_t(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.backend.lib.zk_dev_free(self.backend.ctx, C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Backend:
+    """One zk_ctx = one GPU.  Mirrors nothing in halo2 (halo2 has no device object); the
+    halo2-named functions in arithmetic/domain/kzg/evaluation take a Backend (or use the default)."""
+
+    def __init__(self, device: int = 0, lib_path: str | None = None):
+        self.lib = _load(lib_path or LIB_PATH)
+        self.ctx = C.c_void_p()
+        rc = self.lib.zk_ctx_create(C.c_int(device), C.byref(self.ctx))
+        if rc != ZK_OK:
+            raise ZkError(rc, f"zk_ctx_create(device={device}) failed — no usable gfx950 GPU? (no CPU fallback)")
+        self.device = device
+        self._bases_cache = {}
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _ck(self, rc: int):
+        if rc != ZK_OK:
+            raise ZkError(rc, (self.lib.zk_last_error(self.ctx) or b"").decode())
+
+    def version(self) -> str:
+        return self.lib.zk_version().decode()
+
+    def close(self):
+        if self.ctx:
+            self.lib.zk_ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def tune(self, **kw):
+        for k, v in kw.items():
+            self._ck(self.lib.zk_tune_set(self.ctx, k.encode(), C.c_int(int(v))))
+
+    def tune_get(self, key: str) -> int:
+        v = C.c_int()
+        self._ck(self.lib.zk_tune_get(self.ctx, key.encode(), C.byref(v)))
+        return v.value
+
+    def timing(self, on: bool = True):
+        self._ck(self.lib.zk_timing_enable(self.ctx, C.c_int(1 if on else 0)))
+
+    def timing_get(self, label: str):
+        """(total ms, launches) accumulated since timing(True)."""
+        ms = self.lib.zk_timing_get(self.ctx, label.encode())
+        n = self.lib.zk_timing_get(self.ctx, (label + "#n").encode())
+        return (ms, int(n)) if ms >= 0 else (None, 0)
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr: np.ndarray) -> DeviceBuffer:
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 32)).upload(arr)
+
+    def sync(self):
+        self._ck(self.lib.zk_dev_sync(self.ctx))
+
+    # -- MSM ------------------------------------------------------------------------------------
+    def bases_register(self, bases) -> int:
+        h = C.c_uint64()
+        if isinstance(bases, np.ndarray):
+            b = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+            self._ck(self.lib.zk_bases_register(self.ctx, b.ctypes.data_as(C.c_void_p), C.c_size_t(b.shape[0]), C.byref(h)))
+        else:
+            ptr, n = bases
+            self._ck(self.lib.zk_bases_register_dev(self.ctx, C.c_void_p(_dptr(ptr)), C.c_size_t(n), C.byref(h)))
+        return h.value
+
+    def bases_release(self, handle: int):
+        self._ck(self.lib.zk_bases_release(self.ctx, C.c_uint64(handle)))
+
+    def msm(self, handle: int, scalars, n: int | None = None) -> np.ndarray:
+        out = np.zeros(12, dtype=np.uint64)
+        if isinstance(scalars, np.ndarray):
+            s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+            n = s.shape[0] if n is None else n
+            self._ck(self.lib.zk_msm(self.ctx, C.c_uint64(handle), s.ctypes.data_as(C.c_void_p), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
+        else:
+            assert n is not None
+            self._ck(self.lib.zk_msm_dev(self.ctx, C.c_uint64(handle), C.c_void_p(_dptr(scalars)), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def msm_partial(self, handle: int, scalars_dev, n: int) -> np.ndarray:
+        out = np.zeros(16, dtype=np.uint64)
+        self._ck(self.lib.zk_msm_partial_dev(self.ctx, C.c_uint64(handle), C.c_void_p(_dptr(scalars_dev)), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def g1_sum_xyzz(self, parts: np.ndarray) -> np.ndarray:
+        parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(-1, 16)
+        out = np.zeros(12, dtype=np.uint64)
+        rc = self.lib.zk_g1_sum_xyzz(parts.ctypes.data_as(C.c_void_p), C.c_size_t(parts.shape[0]), out.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise ZkError(rc, "zk_g1_sum_xyzz")
+        return out
+
+    def g1_fixed_base_mul(self, scalars_dev, n: int, out_dev):
+        self._ck(self.lib.zk_g1_fixed_base_mul_dev(self.ctx, C.c_void_p(_dptr(scalars_dev)), C.c_size_t(n), C.c_void_p(_dptr(out_dev))))
+
+    # -- NTT / domain ---------------------------------------------------------------------------
+    @staticmethod
+    def _fe(x) -> np.ndarray:
+        return np.ascontiguousarray(np.asarray(x, dtype=np.uint64).reshape(4))
+
+    def ntt(self, a: np.ndarray, log_n: int, omega) -> None:
+        """in place on a host array (n, 4)"""
+        assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"] and a.size == 4 << log_n
+        w = self._fe(omega)
+        self._ck(self.lib.zk_ntt(self.ctx, a.ctypes.data_as(C.c_void_p), C.c_uint32(log_n), w.ctypes.data_as(C.c_void_p)))
+
+    def ntt_dev(self, a_dev, log_n: int, omega) -> None:
+        w = self._fe(omega)
+        self._ck(self.lib.zk_ntt_dev(self.ctx, C.c_void_p(_dptr(a_dev)), C.c_uint32(log_n), w.ctypes.data_as(C.c_void_p)))
+
+    def lagrange_to_coeff_dev(self, a_dev, k): self._ck(self.lib.zk_lagrange_to_coeff_dev(self.ctx, C.c_void_p(_dptr(a_dev)), C.c_uint32(k)))
+    def coeff_to_lagrange_dev(self, a_dev, k): self._ck(self.lib.zk_coeff_to_lagrange_dev(self.ctx, C.c_void_p(_dptr(a_dev)), C.c_uint32(k)))
+
+    def coeff_to_extended_dev(self, coeff_dev, k, ek, out_dev):
+        self._ck(self.lib.zk_coeff_to_extended_dev(self.ctx, C.c_void_p(_dptr(coeff_dev)), C.c_uint32(k), C.c_uint32(ek), C.c_void_p(_dptr(out_dev))))
+
+    def extended_to_coeff_dev(self, a_dev, k, ek):
+        self._ck(self.lib.zk_extended_to_coeff_dev(self.ctx, C.c_void_p(_dptr(a_dev)), C.c_uint32(k), C.c_uint32(ek)))
+
+    def divide_by_vanishing_poly_dev(self, a_dev, k, ek):
+        self._ck(self.lib.zk_divide_by_vanishing_poly_dev(self.ctx, C.c_void_p(_dptr(a_dev)), C.c_uint32(k), C.c_uint32(ek)))
+
+    # -- vectors --------------------------------------------------------------------------------
+    def _vec(self, fn, a, b, out, n):
+        self._ck(getattr(self.lib, fn)(self.ctx, C.c_void_p(_dptr(a)), C.c_void_p(_dptr(b)), C.c_void_p(_dptr(out)), C.c_size_t(n)))
+
+    def fr_mul_dev(self, a, b, out, n): self._vec("zk_fr_mul_dev", a, b, out, n)
+    def fr_add_dev(self, a, b, out, n): self._vec("zk_fr_add_dev", a, b, out, n)
+    def fr_sub_dev(self, a, b, out, n): self._vec("zk_fr_sub_dev", a, b, out, n)
+    def fq_mul_dev(self, a, b, out, n): self._vec("zk_fq_mul_dev", a, b, out, n)
+
+    def fr_scale_dev(self, a, scalar, out, n):
+        s = self._fe(scalar)
+        self._ck(self.lib.zk_fr_scale_dev(self.ctx, C.c_void_p(_dptr(a)), s.ctypes.data_as(C.c_void_p), C.c_void_p(_dptr(out)), C.c_size_t(n)))
+
+    # -- quotient -------------------------------------------------------------------------------
+    def quotient_program_load(self, blob: bytes) -> int:
+        h = C.c_uint64()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        self._ck(self.lib.zk_quotient_program_load(self.ctx, buf, C.c_size_t(len(blob)), C.byref(h)))
+        return h.value
+
+    def quotient_program_release(self, prog: int):
+        self._ck(self.lib.zk_quotient_program_release(self.ctx, C.c_uint64(prog)))
+
+    def quotient_run_dev(self, prog: int, *, fixed, advice, instance, l0, l_last, l_active_row, perm_cosets, perm_products,
+                         lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out):
+        keep = []
+
+        def parr(cols):
+            arr = (C.c_void_p * max(1, len(cols)))(*[_dptr(c) for c in cols])
+            keep.append(arr)
+            return C.cast(arr, C.c_void_p)
+
+        ch = np.ascontiguousarray(np.asarray(challenges, dtype=np.uint64).reshape(-1, 4)) if len(challenges) else np.zeros((1, 4), np.uint64)
+        sc = [self._fe(v) for v in (beta, gamma, theta, y)]
+        a = QuotientArgs(parr(fixed), parr(advice), parr(instance), _dptr(l0), _dptr(l_last), _dptr(l_active_row),
+                         parr(perm_cosets), parr(perm_products), len(perm_products),
+                         parr(lookup_product), parr(lookup_input), parr(lookup_table),
+                         ch.ctypes.data, sc[0].ctypes.data, sc[1].ctypes.data, sc[2].ctypes.data, sc[3].ctypes.data, _dptr(out))
+        self._ck(self.lib.zk_quotient_run_dev(self.ctx, C.c_uint64(prog), C.byref(a)))
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_backend() -> Backend:
+    """Process-wide backend on the GPU named by LOCAL_RANK (one process per GPU), else device 0."""
+    global _default
+    with _default_lock:
+        if _default is None:
+            _default = Backend(int(os.environ.get("LOCAL_RANK", "0")))
+        return _default

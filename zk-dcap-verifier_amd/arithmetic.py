@@ -1,0 +1,62 @@
+"""halo2_proofs::arithmetic, MI355X edition.
+
+Mirrors (halo2_proofs 0.2.0 @ zkwebauthn c254c75, Cargo.lock:1314-1327) src/arithmetic.rs:
+    pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve
+    pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32)
+reached from the reference through create_proof (circuits/src/sgx_dcap_verifier.rs:814-822).
+Data are numpy uint64 arrays holding the Rust in-memory representation: Fr (n, 4), G1Affine (n, 8),
+G1 (12,) — Montgomery limbs, little endian.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import Backend, default_backend
+
+
+class BasesHandle:
+    """A base table resident on the GPU (params.g / params.g_lagrange of one SRS)."""
+
+    def __init__(self, backend: Backend, bases):
+        self.backend = backend
+        if isinstance(bases, np.ndarray):
+            self.n = bases.reshape(-1, 8).shape[0]
+        else:
+            self.n = bases[1]
+        self.handle = backend.bases_register(bases)
+
+    def release(self):
+        if self.handle:
+            self.backend.bases_release(self.handle)
+            self.handle = 0
+
+
+def best_multiexp(coeffs, bases, backend: Backend | None = None) -> np.ndarray:
+    """sum_i coeffs[i] * bases[i]  ->  G1 {x, y, z} (12 limbs), normalised (z = 1) or identity (0,0,0).
+
+    `bases` is a BasesHandle (the production path: the table is uploaded once per SRS) or a raw
+    (n, 8) array, which is registered for this call only.  Like the Rust function it asserts
+    coeffs.len() == bases.len() for raw arrays; with a handle, len(coeffs) <= handle.n (a prefix of
+    the table is used, as commit() does with shorter polynomials).
+    """
+    be = backend or default_backend()
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    if isinstance(bases, BasesHandle):
+        assert coeffs.shape[0] <= bases.n
+        return bases.backend.msm(bases.handle, coeffs)
+    bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+    assert coeffs.shape[0] == bases.shape[0], "best_multiexp: coeffs.len() != bases.len()"
+    if coeffs.shape[0] == 0:
+        return np.zeros(12, dtype=np.uint64)
+    h = BasesHandle(be, bases)
+    try:
+        return be.msm(h.handle, coeffs)
+    finally:
+        h.release()
+
+
+def best_fft(a: np.ndarray, omega, log_n: int, backend: Backend | None = None) -> None:
+    """In place; natural order in and out: a[j] <- sum_i a[i] * omega^(i*j)."""
+    be = backend or default_backend()
+    assert a.shape[0] == 1 << log_n, "best_fft: a.len() != 1 << log_n"
+    be.ntt(a, log_n, omega)

@@ -1,0 +1,203 @@
+// extern "C" surface of libzkmi355.so (see include/zkmi355.h for the contract and the reference
+// call sites each entry point stands in for).
+#include <string.h>
+#include "ctx.h"
+
+namespace zk {
+int ntt_set_lds_attr();
+int domain_lagrange_to_coeff(zk_ctx* ctx, void* d_a, uint32_t k);
+int domain_coeff_to_lagrange(zk_ctx* ctx, void* d_a, uint32_t k);
+int domain_coeff_to_extended(zk_ctx* ctx, const void* d_coeff, uint32_t k, uint32_t ek, void* d_out);
+int domain_extended_to_coeff(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek);
+int domain_divide_by_vanishing(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek);
+int fr_vec_op(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n, const u256* scalar);
+int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
+int quotient_program_release(zk_ctx* ctx, uint64_t prog);
+int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args);
+}  // namespace zk
+using namespace zk;
+
+#define LOCK std::lock_guard<std::mutex> lk__(ctx->mu)
+#define NEED_CTX if (!ctx) return ZK_ERR_ARG
+
+extern "C" {
+
+const char* zk_version(void) {
+#ifdef ZK_EMU
+    return "zkmi355 0.1 (EMULATED kernels - test build, not the product)";
+#else
+    return "zkmi355 0.1 gfx950";
+#endif
+}
+
+int zk_ctx_create(int device_id, zk_ctx** out) {
+    if (!out) return ZK_ERR_ARG;
+    *out = nullptr;
+#ifndef ZK_EMU
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ZK_ERR_NODEV;
+    if (hipSetDevice(device_id) != hipSuccess) return ZK_ERR_NODEV;
+#endif
+    zk_ctx* ctx = new zk_ctx();
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ZK_ERR_HIP; }
+    msm_set_lds_attr();
+    ntt_set_lds_attr();
+    *out = ctx;
+    return ZK_OK;
+}
+
+void zk_ctx_destroy(zk_ctx* ctx) {
+    if (!ctx) return;
+    {
+        LOCK;
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& kv : ctx->bases) (void)hipFree(kv.second.d_table);
+        ctx->bases.clear();
+        release_twiddles(ctx);
+        release_programs(ctx);
+        release_gtab(ctx);
+        zk::DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_sorted, &ctx->ws_small, &ctx->ws_sub0, &ctx->ws_sub1, &ctx->ws_cls0,
+                              &ctx->ws_cls1, &ctx->ws_tmp, &ctx->ws_ntt, &ctx->ws_ntt_in, &ctx->ws_pts};
+        for (auto* b : bufs) b->release();
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+const char* zk_last_error(zk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+static int* tune_slot(zk_ctx* ctx, const char* key) {
+    zk::Tune& t = ctx->tune;
+    struct { const char* k; int* v; } tab[] = {
+        {"msm_c", &t.msm_c}, {"msm_sort_wgs", &t.msm_sort_wgs}, {"msm_sort_threads", &t.msm_sort_threads},
+        {"msm_target_threads", &t.msm_target_threads}, {"msm_min_chunk", &t.msm_min_chunk}, {"msm_max_chunk", &t.msm_max_chunk},
+        {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block},
+        {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log},
+        {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}};
+    for (auto& e : tab) if (!strcmp(e.k, key)) return e.v;
+    return nullptr;
+}
+int zk_tune_set(zk_ctx* ctx, const char* key, int value) {
+    NEED_CTX; LOCK;
+    int* s = key ? tune_slot(ctx, key) : nullptr;
+    if (!s) return ctx->fail(ZK_ERR_ARG, "zk_tune_set: unknown key '%s'", key ? key : "(null)");
+    if (value < 0) return ctx->fail(ZK_ERR_ARG, "zk_tune_set: negative value");
+    *s = value;
+    return ZK_OK;
+}
+int zk_tune_get(zk_ctx* ctx, const char* key, int* value) {
+    NEED_CTX; LOCK;
+    int* s = key ? tune_slot(ctx, key) : nullptr;
+    if (!s || !value) return ctx->fail(ZK_ERR_ARG, "zk_tune_get: unknown key '%s'", key ? key : "(null)");
+    *value = *s;
+    return ZK_OK;
+}
+int zk_timing_enable(zk_ctx* ctx, int on) { NEED_CTX; LOCK; ctx->timing = on != 0; ctx->last_ms.clear(); return ZK_OK; }
+float zk_timing_get(zk_ctx* ctx, const char* label) {
+    if (!ctx || !label) return -1.f;
+    LOCK;
+    auto it = ctx->last_ms.find(label);
+    return it == ctx->last_ms.end() ? -1.f : it->second;
+}
+
+#define ENTER NEED_CTX; LOCK; ZK_HIP(hipSetDevice(ctx->device))
+
+int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** dptr) { ENTER; if (!dptr) return ctx->fail(ZK_ERR_ARG, "null"); ZK_HIP(hipMalloc(dptr, bytes ? bytes : 32)); return ZK_OK; }
+int zk_dev_free(zk_ctx* ctx, void* dptr) { ENTER; ZK_HIP(hipFree(dptr)); return ZK_OK; }
+int zk_dev_upload(zk_ctx* ctx, void* dptr, const void* host, size_t bytes) {
+    ENTER; if ((!dptr || !host) && bytes) return ctx->fail(ZK_ERR_ARG, "zk_dev_upload: null");
+    ZK_HIP(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream)); ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
+}
+int zk_dev_download(zk_ctx* ctx, void* host, const void* dptr, size_t bytes) {
+    ENTER; if ((!dptr || !host) && bytes) return ctx->fail(ZK_ERR_ARG, "zk_dev_download: null");
+    ZK_HIP(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream)); ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
+}
+int zk_dev_sync(zk_ctx* ctx) { ENTER; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
+
+// ---- MSM ----------------------------------------------------------------------------------------
+int zk_bases_register(zk_ctx* ctx, const void* p, size_t n, uint64_t* h) { ENTER; return msm_register(ctx, p, n, false, h); }
+int zk_bases_register_dev(zk_ctx* ctx, const void* p, size_t n, uint64_t* h) { ENTER; return msm_register(ctx, p, n, true, h); }
+int zk_bases_release(zk_ctx* ctx, uint64_t h) { ENTER; return msm_release(ctx, h); }
+int zk_msm(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { ENTER; return msm_run(ctx, b, s, n, false, out, 0); }
+int zk_msm_dev(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { ENTER; return msm_run(ctx, b, s, n, true, out, 0); }
+int zk_msm_partial_dev(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { ENTER; return msm_run(ctx, b, s, n, true, out, 1); }
+int zk_g1_sum_xyzz(const void* xyzz, size_t count, void* out) { if (!xyzz || !out) return ZK_ERR_ARG; return g1_sum_xyzz_host(xyzz, count, out); }
+int zk_g1_fixed_base_mul_dev(zk_ctx* ctx, const void* s, size_t n, void* out) { ENTER; return g1_fixed_base_mul(ctx, s, n, out); }
+
+// ---- NTT / domain -------------------------------------------------------------------------------
+static int with_host_buffer(zk_ctx* ctx, void* host_in_out, size_t in_bytes, size_t buf_bytes, size_t out_bytes, void** dbuf) {
+    ZK_HIP(ctx->ws_ntt_in.ensure(buf_bytes));
+    *dbuf = ctx->ws_ntt_in.p;
+    (void)out_bytes;
+    ZK_HIP(hipMemcpyAsync(*dbuf, host_in_out, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ZK_OK;
+}
+static int finish_host(zk_ctx* ctx, void* host, const void* dbuf, size_t bytes) {
+    ZK_HIP(hipMemcpyAsync(host, dbuf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+static u256 load_host_fr(const void* p) { u256 o; memcpy(&o, p, 32); return o; }
+
+int zk_ntt_dev(zk_ctx* ctx, void* a, uint32_t log_n, const void* omega) {
+    ENTER; if (!omega) return ctx->fail(ZK_ERR_ARG, "zk_ntt: null omega");
+    int rc = ntt_dev(ctx, a, log_n, load_host_fr(omega), nullptr); if (rc) return rc;
+    ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
+}
+int zk_ntt(zk_ctx* ctx, void* a, uint32_t log_n, const void* omega) {
+    ENTER; if (!omega || !a) return ctx->fail(ZK_ERR_ARG, "zk_ntt: null pointer");
+    if (log_n > 27) return ctx->fail(ZK_ERR_LIMIT, "zk_ntt: log_n = %u > 27", log_n);
+    void* d; size_t bytes = (size_t)32 << log_n;
+    int rc = with_host_buffer(ctx, a, bytes, bytes, bytes, &d); if (rc) return rc;
+    rc = ntt_dev(ctx, d, log_n, load_host_fr(omega), nullptr); if (rc) return rc;
+    return finish_host(ctx, a, d, bytes);
+}
+int zk_lagrange_to_coeff_dev(zk_ctx* ctx, void* a, uint32_t k) { ENTER; int rc = domain_lagrange_to_coeff(ctx, a, k); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
+int zk_coeff_to_lagrange_dev(zk_ctx* ctx, void* a, uint32_t k) { ENTER; int rc = domain_coeff_to_lagrange(ctx, a, k); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
+int zk_coeff_to_extended_dev(zk_ctx* ctx, const void* c, uint32_t k, uint32_t ek, void* out) { ENTER; int rc = domain_coeff_to_extended(ctx, c, k, ek, out); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
+int zk_extended_to_coeff_dev(zk_ctx* ctx, void* a, uint32_t k, uint32_t ek) { ENTER; int rc = domain_extended_to_coeff(ctx, a, k, ek); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
+int zk_divide_by_vanishing_poly_dev(zk_ctx* ctx, void* a, uint32_t k, uint32_t ek) { ENTER; return domain_divide_by_vanishing(ctx, a, k, ek); }
+
+int zk_lagrange_to_coeff(zk_ctx* ctx, void* a, uint32_t k) {
+    ENTER; if (!a || k > 27) return ctx->fail(ZK_ERR_ARG, "zk_lagrange_to_coeff: bad argument");
+    void* d; size_t bytes = (size_t)32 << k;
+    int rc = with_host_buffer(ctx, a, bytes, bytes, bytes, &d); if (rc) return rc;
+    rc = domain_lagrange_to_coeff(ctx, d, k); if (rc) return rc;
+    return finish_host(ctx, a, d, bytes);
+}
+int zk_coeff_to_extended(zk_ctx* ctx, const void* c, uint32_t k, uint32_t ek, void* out) {
+    ENTER; if (!c || !out || k > ek || ek > 27) return ctx->fail(ZK_ERR_ARG, "zk_coeff_to_extended: bad argument");
+    size_t inb = (size_t)32 << k, outb = (size_t)32 << ek;
+    ZK_HIP(ctx->ws_ntt_in.ensure(inb + outb));
+    void* din = ctx->ws_ntt_in.p; void* dout = (char*)din + inb;
+    ZK_HIP(hipMemcpyAsync(din, c, inb, hipMemcpyHostToDevice, ctx->stream));
+    int rc = domain_coeff_to_extended(ctx, din, k, ek, dout); if (rc) return rc;
+    return finish_host(ctx, out, dout, outb);
+}
+int zk_extended_to_coeff(zk_ctx* ctx, void* a, uint32_t k, uint32_t ek) {
+    ENTER; if (!a || k > ek || ek > 27) return ctx->fail(ZK_ERR_ARG, "zk_extended_to_coeff: bad argument");
+    void* d; size_t bytes = (size_t)32 << ek;
+    int rc = with_host_buffer(ctx, a, bytes, bytes, bytes, &d); if (rc) return rc;
+    rc = domain_extended_to_coeff(ctx, d, k, ek); if (rc) return rc;
+    return finish_host(ctx, a, d, bytes);
+}
+
+// ---- vectors ------------------------------------------------------------------------------------
+static int vec_sync(zk_ctx* ctx, int rc) { if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
+int zk_fr_mul_dev(zk_ctx* ctx, const void* a, const void* b, void* o, size_t n) { ENTER; return vec_sync(ctx, fr_vec_op(ctx, 0, a, b, o, n, nullptr)); }
+int zk_fr_add_dev(zk_ctx* ctx, const void* a, const void* b, void* o, size_t n) { ENTER; return vec_sync(ctx, fr_vec_op(ctx, 1, a, b, o, n, nullptr)); }
+int zk_fr_sub_dev(zk_ctx* ctx, const void* a, const void* b, void* o, size_t n) { ENTER; return vec_sync(ctx, fr_vec_op(ctx, 2, a, b, o, n, nullptr)); }
+int zk_fr_scale_dev(zk_ctx* ctx, const void* a, const void* s, void* o, size_t n) {
+    ENTER; if (!s) return ctx->fail(ZK_ERR_ARG, "zk_fr_scale_dev: null scalar");
+    u256 sc = load_host_fr(s); return vec_sync(ctx, fr_vec_op(ctx, 3, a, nullptr, o, n, &sc));
+}
+int zk_fq_mul_dev(zk_ctx* ctx, const void* a, const void* b, void* o, size_t n) { ENTER; return vec_sync(ctx, fr_vec_op(ctx, 4, a, b, o, n, nullptr)); }
+
+// ---- quotient -----------------------------------------------------------------------------------
+int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog) { ENTER; return quotient_program_load(ctx, blob, len, prog); }
+int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog) { ENTER; return quotient_program_release(ctx, prog); }
+int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args); }
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// Library context shared by the MSM / NTT / quotient translation units.
+#pragma once
+#include <stdarg.h>
+#include <string.h>
+#include <stdio.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "ec.cuh"
+#include "../../include/zkmi355.h"
+
+namespace zk {
+
+// Tunables (settable through zk_tune_set; defaults chosen for MI355X)
+struct Tune {
+    int msm_c = 0;               // 0 = pick from n
+    int msm_sort_wgs = 256;      // workgroups of the counting-sort kernels (one per CU)
+    int msm_sort_threads = 1024;
+    int msm_target_threads = 1 << 19;  // sub-bucket count the accumulate launch aims for
+    int msm_min_chunk = 16;      // min pairs per accumulate thread
+    int msm_max_chunk = 512;
+    int msm_merge_fanin = 8;
+    int msm_tree_fanin = 4;
+    int msm_block = 128;         // threads per workgroup of the curve-arithmetic kernels
+    int ntt_tile_log = 11;       // log2(elements) of the LDS tile of one NTT workgroup
+    int ntt_threads = 256;
+    int ntt_max_radix_log = 8;
+    int vec_block = 256;
+    int quot_threads = 128;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct BaseTable {
+    void* d_table = nullptr;  // [W][n] affine points: table[j*n + i] = 2^(c*j) * P_i
+    size_t n = 0;
+    int c = 0, W = 0;
+};
+
+struct TwiddleSet {           // per (omega, log_n)
+    uint32_t log_n = 0;
+    u256 omega;
+    void* d_lo = nullptr;     // omega^e, e < 2^lo_bits
+    void* d_hi = nullptr;     // omega^(e << lo_bits)
+    uint32_t lo_bits = 0;
+    void* d_stage[3] = {nullptr, nullptr, nullptr};  // per pass: omega_R^k, k < R/2
+    uint32_t radix_log[3] = {0, 0, 0};
+    int passes = 0;
+};
+
+struct QuotProgram;  // quotient.hip
+
+}  // namespace zk
+
+struct zk_ctx {
+    int device = 0;
+    std::mutex mu;            // calls are serialised per context (thread-safe, blocking)
+    std::string err;
+    hipStream_t stream = nullptr;
+    zk::Tune tune;
+    uint64_t next_handle = 1;
+    std::map<uint64_t, zk::BaseTable> bases;
+    std::vector<zk::TwiddleSet> twiddles;
+    std::map<uint64_t, zk::QuotProgram*> programs;
+    // workspaces (grow-only)
+    zk::DevBuf ws_scalars, ws_sorted, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts;
+    // last-call kernel timing (ms), filled when timing is enabled
+    bool timing = false;
+    std::map<std::string, float> last_ms;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define ZK_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return ctx->fail(ZK_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+#define ZK_CHECK_LAUNCH() ZK_HIP(hipGetLastError())
+
+namespace zk {
+struct EvTimer {
+    zk_ctx* ctx; const char* label; hipEvent_t a = nullptr, b = nullptr; bool on;
+    EvTimer(zk_ctx* c, const char* l) : ctx(c), label(l), on(c->timing) {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, ctx->stream); }
+    }
+    void stop() { if (on) (void)hipEventRecord(b, ctx->stream); }
+    void resolve() {
+        if (!on) return;
+        (void)hipEventSynchronize(b);
+        float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+        ctx->last_ms[label] += ms; ctx->last_ms[std::string(label) + "#n"] += 1.0f;
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    }
+};
+
+// implemented in the respective translation units
+int msm_register(zk_ctx* ctx, const void* pts, size_t n, bool on_device, uint64_t* handle);
+int msm_release(zk_ctx* ctx, uint64_t handle);
+int msm_run(zk_ctx* ctx, uint64_t handle, const void* scalars, size_t n, bool on_device, void* out, int partial);
+int g1_sum_xyzz_host(const void* xyzz, size_t count, void* out_jac);
+int g1_fixed_base_mul(zk_ctx* ctx, const void* d_scalars, size_t n, void* d_out_affine);
+void release_gtab(zk_ctx* ctx);
+int msm_set_lds_attr();
+struct NttFuse {              // optional fused pre/post operations (EvaluationDomain wrappers)
+    const void* src = nullptr; // read the input from here instead of `a` (device)
+    uint32_t n_valid = 0;      // inputs with index >= n_valid are zero (0 = all valid)
+    int pre_zeta = 0;          // input i *= ZETA^(i mod 3)            (coeff_to_extended)
+    int post_scale = 0;        // output *= scale
+    u256 scale;
+    int post_zeta_inv = 0;     // output i *= ZETA^-(i mod 3)          (extended_to_coeff)
+};
+int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const NttFuse* fuse);
+void release_twiddles(zk_ctx* ctx);
+void release_programs(zk_ctx* ctx);
+}  // namespace zk

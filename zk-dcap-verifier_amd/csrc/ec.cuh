@@ -1,0 +1,147 @@
+// BN254 G1 (y^2 = x^3 + 3 over Fq) group law for the MSM kernels.
+//
+// Bases cross the FFI as halo2curves G1Affine {x, y} (Montgomery Fq, identity = (0,0));
+// accumulators live in extended Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2,
+// identity = ZZ == 0) because the mixed addition is the cheapest complete-enough formula
+// without inversions: 8M + 2S (EFD madd-2008-s), vs 7M + 4S for Jacobian madd-2007-bl that
+// halo2curves uses on the CPU.  Results are canonical after normalisation, so the choice of
+// coordinates is invisible to the caller (SURVEY.md App. C.1 "GPU freedom").
+#pragma once
+#include "field.cuh"
+
+namespace zk {
+
+struct Affine {
+    u256 x, y;
+};
+struct XYZZ {
+    u256 x, y, zz, zzz;
+};
+
+ZK_HD bool affine_is_identity(const Affine& p) { return Fq::is_zero(p.x) && Fq::is_zero(p.y); }
+ZK_HD bool xyzz_is_identity(const XYZZ& p) { return Fq::is_zero(p.zz); }
+ZK_HD XYZZ xyzz_identity() {
+    XYZZ o;
+    o.x = Fq::zero(); o.y = Fq::zero(); o.zz = Fq::zero(); o.zzz = Fq::zero();
+    return o;
+}
+ZK_HD XYZZ xyzz_from_affine(const Affine& p) {
+    XYZZ o;
+    if (affine_is_identity(p)) return xyzz_identity();
+    o.x = p.x; o.y = p.y; o.zz = Fq::one(); o.zzz = Fq::one();
+    return o;
+}
+
+// 2*(x1, y1) for an affine point (mdbl-2008-s-1, a = 0)
+ZK_HD XYZZ xyzz_mdbl(const u256& x1, const u256& y1) {
+    XYZZ o;
+    u256 U = Fq::dbl(y1);
+    u256 V = Fq::sqr(U);
+    u256 W = Fq::mul(U, V);
+    u256 S = Fq::mul(x1, V);
+    u256 X2 = Fq::sqr(x1);
+    u256 M = Fq::add(Fq::dbl(X2), X2);
+    o.x = Fq::sub(Fq::sqr(M), Fq::dbl(S));
+    o.y = Fq::sub(Fq::mul(M, Fq::sub(S, o.x)), Fq::mul(W, y1));
+    o.zz = V;
+    o.zzz = W;
+    return o;
+}
+// dbl-2008-s-1
+ZK_HD XYZZ xyzz_dbl(const XYZZ& p) {
+    if (xyzz_is_identity(p)) return p;
+    XYZZ o;
+    u256 U = Fq::dbl(p.y);
+    u256 V = Fq::sqr(U);
+    u256 W = Fq::mul(U, V);
+    u256 S = Fq::mul(p.x, V);
+    u256 X2 = Fq::sqr(p.x);
+    u256 M = Fq::add(Fq::dbl(X2), X2);
+    o.x = Fq::sub(Fq::sqr(M), Fq::dbl(S));
+    o.y = Fq::sub(Fq::mul(M, Fq::sub(S, o.x)), Fq::mul(W, p.y));
+    o.zz = Fq::mul(V, p.zz);
+    o.zzz = Fq::mul(W, p.zzz);
+    return o;
+}
+// acc += (x2, y2)    (madd-2008-s; y2 already carries the sign)
+ZK_HD void xyzz_madd(XYZZ& acc, const u256& x2, const u256& y2) {
+    if (xyzz_is_identity(acc)) {
+        acc.x = x2; acc.y = y2; acc.zz = Fq::one(); acc.zzz = Fq::one();
+        return;
+    }
+    u256 U2 = Fq::mul(x2, acc.zz);
+    u256 S2 = Fq::mul(y2, acc.zzz);
+    u256 P = Fq::sub(U2, acc.x);
+    u256 R = Fq::sub(S2, acc.y);
+    if (Fq::is_zero(P)) {  // same x: doubling or cancellation (rare; bases repeat or P + (-P))
+        if (Fq::is_zero(R)) acc = xyzz_mdbl(x2, y2);
+        else acc = xyzz_identity();
+        return;
+    }
+    u256 PP = Fq::sqr(P);
+    u256 PPP = Fq::mul(P, PP);
+    u256 Q = Fq::mul(acc.x, PP);
+    u256 X3 = Fq::sub(Fq::sub(Fq::sqr(R), PPP), Fq::dbl(Q));
+    u256 Y3 = Fq::sub(Fq::mul(R, Fq::sub(Q, X3)), Fq::mul(acc.y, PPP));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = Fq::mul(acc.zz, PP);
+    acc.zzz = Fq::mul(acc.zzz, PPP);
+}
+ZK_HD void xyzz_madd_signed(XYZZ& acc, const Affine& p, bool negate) {
+    if (affine_is_identity(p)) return;
+    u256 y = negate ? Fq::neg(p.y) : p.y;
+    xyzz_madd(acc, p.x, y);
+}
+// acc += q   (add-2008-s)
+ZK_HD void xyzz_add(XYZZ& acc, const XYZZ& q) {
+    if (xyzz_is_identity(q)) return;
+    if (xyzz_is_identity(acc)) { acc = q; return; }
+    u256 U1 = Fq::mul(acc.x, q.zz);
+    u256 U2 = Fq::mul(q.x, acc.zz);
+    u256 S1 = Fq::mul(acc.y, q.zzz);
+    u256 S2 = Fq::mul(q.y, acc.zzz);
+    u256 P = Fq::sub(U2, U1);
+    u256 R = Fq::sub(S2, S1);
+    if (Fq::is_zero(P)) {
+        if (Fq::is_zero(R)) acc = xyzz_dbl(acc);
+        else acc = xyzz_identity();
+        return;
+    }
+    u256 PP = Fq::sqr(P);
+    u256 PPP = Fq::mul(P, PP);
+    u256 Q = Fq::mul(U1, PP);
+    u256 X3 = Fq::sub(Fq::sub(Fq::sqr(R), PPP), Fq::dbl(Q));
+    u256 Y3 = Fq::sub(Fq::mul(R, Fq::sub(Q, X3)), Fq::mul(S1, PPP));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = Fq::mul(Fq::mul(acc.zz, q.zz), PP);
+    acc.zzz = Fq::mul(Fq::mul(acc.zzz, q.zzz), PPP);
+}
+
+ZK_HD Affine load_affine(const void* base, size_t idx) {
+    Affine p;
+    p.x = load_u256(base, 2 * idx);
+    p.y = load_u256(base, 2 * idx + 1);
+    return p;
+}
+ZK_HD void store_affine(void* base, size_t idx, const Affine& p) {
+    store_u256(base, 2 * idx, p.x);
+    store_u256(base, 2 * idx + 1, p.y);
+}
+ZK_HD XYZZ load_xyzz(const void* base, size_t idx) {
+    XYZZ p;
+    p.x = load_u256(base, 4 * idx);
+    p.y = load_u256(base, 4 * idx + 1);
+    p.zz = load_u256(base, 4 * idx + 2);
+    p.zzz = load_u256(base, 4 * idx + 3);
+    return p;
+}
+ZK_HD void store_xyzz(void* base, size_t idx, const XYZZ& p) {
+    store_u256(base, 4 * idx, p.x);
+    store_u256(base, 4 * idx + 1, p.y);
+    store_u256(base, 4 * idx + 2, p.zz);
+    store_u256(base, 4 * idx + 3, p.zzz);
+}
+
+}  // namespace zk

@@ -1,0 +1,195 @@
+// BN254 Fq / Fr arithmetic for gfx950 (CDNA4): 8 x 32-bit limbs, Montgomery form, R = 2^256.
+//
+// Memory layout is exactly halo2curves::bn256::{Fq,Fr} ([u64;4] little endian ==
+// [u32;8] little endian on this target), so buffers cross the FFI with zero conversion
+// (halo2curves 0.3.1 @ bdb2e66, Cargo.lock:1329-1344).
+//
+// CDNA4 has no 64x64 multiplier in the VALU; the widest integer multiply is
+// v_mad_u64_u32 (32x32+64 -> 64).  mont_mul below is a CIOS Montgomery product built on
+// that instruction; both moduli are < 2^254 so the running value never exceeds 8 limbs + 1 bit
+// and a single conditional subtraction finishes the reduction.
+#pragma once
+#include "rt.h"
+#include <stdint.h>
+#include "bn254_consts.h"
+
+#define ZK_HD __host__ __device__ __forceinline__
+
+namespace zk {
+
+struct alignas(16) u256 {
+    uint32_t v[8];
+};
+
+struct FqParams {
+    static constexpr uint64_t P[4] = BN254_FQ_MODULUS;
+    static constexpr uint64_t R[4] = BN254_FQ_R;
+    static constexpr uint64_t R2[4] = BN254_FQ_R2;
+    static constexpr uint32_t INV = BN254_FQ_INV32;
+};
+struct FrParams {
+    static constexpr uint64_t P[4] = BN254_FR_MODULUS;
+    static constexpr uint64_t R[4] = BN254_FR_R;
+    static constexpr uint64_t R2[4] = BN254_FR_R2;
+    static constexpr uint32_t INV = BN254_FR_INV32;
+};
+
+template <class FP>
+struct Field {
+    // compile-time limb accessors (fold to literals once loops are unrolled)
+    static ZK_HD constexpr uint32_t p(int i) { return (uint32_t)(FP::P[i >> 1] >> (32 * (i & 1))); }
+    static ZK_HD constexpr uint32_t r(int i) { return (uint32_t)(FP::R[i >> 1] >> (32 * (i & 1))); }
+    static ZK_HD constexpr uint32_t r2(int i) { return (uint32_t)(FP::R2[i >> 1] >> (32 * (i & 1))); }
+
+    static ZK_HD u256 zero() {
+        u256 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = 0;
+        return o;
+    }
+    static ZK_HD u256 one() {  // Montgomery 1
+        u256 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = r(i);
+        return o;
+    }
+    static ZK_HD u256 R2() {
+        u256 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = r2(i);
+        return o;
+    }
+    static ZK_HD bool is_zero(const u256& a) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= a.v[i];
+        return o == 0;
+    }
+    static ZK_HD bool eq(const u256& a, const u256& b) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+        return o == 0;
+    }
+
+    // r = a - p if a >= p else a     (a < 2p)
+    static ZK_HD u256 reduce_once(const u256& a) {
+        u256 d;
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(a.v[i], p(i), br, &br);
+        u256 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = br ? a.v[i] : d.v[i];
+        return o;
+    }
+    static ZK_HD u256 add(const u256& a, const u256& b) {
+        u256 s;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s.v[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
+        return reduce_once(s);  // p < 2^254 => a + b < 2^255, no carry out
+    }
+    static ZK_HD u256 sub(const u256& a, const u256& b) {
+        u256 d;
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(a.v[i], b.v[i], br, &br);
+        uint32_t mask = 0u - br;  // add p back if we borrowed
+        uint32_t c = 0;
+        u256 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = __builtin_addc(d.v[i], p(i) & mask, c, &c);
+        return o;
+    }
+    static ZK_HD u256 neg(const u256& a) {
+        u256 d;
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(p(i), a.v[i], br, &br);
+        bool z = is_zero(a);
+        u256 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = z ? 0u : d.v[i];
+        return o;
+    }
+    static ZK_HD u256 dbl(const u256& a) { return add(a, a); }
+
+    // Montgomery product a*b*R^-1 mod p.  CIOS over 32-bit limbs; every inner step is one
+    // 32x32+64 multiply-add (v_mad_u64_u32) plus the propagation of a 32-bit carry.
+    static ZK_HD u256 mul(const u256& a, const u256& b) {
+        uint32_t t[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint64_t s = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
+                t[j] = (uint32_t)s;
+                c = s >> 32;
+            }
+            uint32_t t8 = t[8] + (uint32_t)c;  // < 2^32: total stays < 2p*2^32-ish, see header
+            uint32_t m = t[0] * FP::INV;
+            c = ((uint64_t)m * p(0) + t[0]) >> 32;
+#pragma unroll
+            for (int j = 1; j < 8; j++) {
+                uint64_t s = (uint64_t)m * p(j) + t[j] + c;
+                t[j - 1] = (uint32_t)s;
+                c = s >> 32;
+            }
+            uint64_t s = (uint64_t)t8 + c;
+            t[7] = (uint32_t)s;
+            t[8] = (uint32_t)(s >> 32);
+        }
+        u256 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = t[i];
+        return reduce_once(o);  // t[8] == 0 here because p < 2^254 (result < 2p < 2^255)
+    }
+    static ZK_HD u256 sqr(const u256& a) { return mul(a, a); }
+
+    static ZK_HD u256 from_mont(const u256& a) {
+        u256 o1 = zero();
+        o1.v[0] = 1;
+        return mul(a, o1);
+    }
+    static ZK_HD u256 to_mont(const u256& a) { return mul(a, R2()); }
+
+    // a^e, e given as canonical 8x32 limbs (variable-time, top-down square & multiply)
+    static ZK_HD u256 pow(const u256& a, const u256& e) {
+        u256 acc = one();
+        for (int i = 255; i >= 0; i--) {
+            acc = sqr(acc);
+            if ((e.v[i >> 5] >> (i & 31)) & 1) acc = mul(acc, a);
+        }
+        return acc;
+    }
+    static ZK_HD u256 inv(const u256& a) {  // Fermat; 0 -> 0
+        u256 e;
+#pragma unroll
+        for (int i = 0; i < 8; i++) e.v[i] = p(i);
+        e.v[0] -= 2;
+        return pow(a, e);
+    }
+};
+
+using Fq = Field<FqParams>;
+using Fr = Field<FrParams>;
+
+ZK_HD u256 load_u256(const void* base, size_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(base) + 2 * idx;
+    uint4 lo = q[0], hi = q[1];
+    u256 o;
+    o.v[0] = lo.x; o.v[1] = lo.y; o.v[2] = lo.z; o.v[3] = lo.w;
+    o.v[4] = hi.x; o.v[5] = hi.y; o.v[6] = hi.z; o.v[7] = hi.w;
+    return o;
+}
+ZK_HD void store_u256(void* base, size_t idx, const u256& a) {
+    uint4* q = reinterpret_cast<uint4*>(base) + 2 * idx;
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+}  // namespace zk

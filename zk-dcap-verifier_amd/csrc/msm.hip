@@ -1,0 +1,591 @@
+// BN254 G1 multi-scalar multiplication for MI355X (gfx950).
+//
+// Replaces halo2_proofs (zkwebauthn @ c254c75, Cargo.lock:1314-1327) src/arithmetic.rs
+// best_multiexp — the CPU algorithm there is a per-thread chunked Pippenger with unsigned
+// c = ceil(ln n)-bit windows.  This is NOT that algorithm moved to a GPU; the
+// result (a G1 point) is canonical, so the design is free and is built for this chip:
+//
+//  * KZG bases are fixed per SRS, and the GPU has 288 GB of HBM, so registration expands the table
+//    to all window multiples T[j][i] = 2^(c*j) * P_i.  Every (scalar, window) pair then lands in ONE
+//    shared set of 2^(c-1) buckets: no per-window bucket reduction, no doublings at the end.
+//  * signed c-bit digits (c <= 16) halve the bucket count: the whole bucket histogram (<= 128 KiB)
+//    fits the 160 KiB LDS of one CU, so the counting sort that groups pairs by bucket runs on LDS
+//    atomics and touches HBM only for the scalars and the sorted 4-byte point references.
+//  * buckets are cut into sub-buckets of <= L pairs, one thread each (XYZZ mixed adds, 8M + 2S),
+//    so degenerate scalar columns (all ones, bytes, ...) cannot serialise on one thread; sub-buckets
+//    are merged by fan-in rounds.
+//  * bucket reduction sum_w w * B_w is done by weight bits: C_t = sum_{w: bit t} B_w are plain tree
+//    sums (depth log instead of the serial running sum), and the host folds sum_t 2^t C_t.
+//
+// Integer-ALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md for the roofline accounting.
+#include "ctx.h"
+#include <algorithm>
+#include <math.h>
+
+namespace zk {
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+// Signed-digit recoding of a canonical 254-bit scalar: digits d_j in [-(2^(c-1)-1), 2^(c-1)],
+// sum_j d_j 2^(c j) = s.  f(j, magnitude >= 1, negative).
+template <class F>
+ZK_HD void for_each_digit(u256 s, int c, int W, F&& f) {
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int j = 0; j < W; j++) {
+        uint32_t d = (s.v[0] & mask) + carry;
+#pragma unroll
+        for (int i = 0; i < 7; i++) s.v[i] = (s.v[i] >> c) | (s.v[i + 1] << (32 - c));
+        s.v[7] >>= c;
+        if (d > half) {
+            carry = 1;
+            uint32_t m = (1u << c) - d;
+            if (m) f(j, m, true);
+        } else {
+            carry = 0;
+            if (d) f(j, d, false);
+        }
+    }
+}
+
+// largest b in [0, B) with arr[b] <= j  (arr is a non-decreasing exclusive scan, arr[0] = 0)
+ZK_HD uint32_t find_segment(const uint32_t* arr, uint32_t B, uint32_t j) {
+    uint32_t lo = 0, hi = B;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (arr[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+ZK_HD uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------------
+// counting sort of (scalar, window) pairs by bucket — histogram in LDS
+// ------------------------------------------------------------------------------------------------
+ZK_KERNEL void msm_hist_kernel(const void* scalars, uint32_t n, int c, int W, uint32_t* ghist) {
+    ZK_DYN_SHARED(uint32_t, lh);
+    const uint32_t B = 1u << (c - 1);
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lh[b] = 0;
+    __syncthreads();
+    const uint32_t chunk = ceil_div(n, gridDim.x);
+    const uint32_t lo = blockIdx.x * chunk;
+    const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        u256 s = Fr::from_mont(load_u256(scalars, i));
+        for_each_digit(s, c, W, [&](int, uint32_t mag, bool) { atomicAdd(&lh[mag - 1], 1u); });
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
+        uint32_t v = lh[b];
+        if (v) atomicAdd(&ghist[b], v);
+    }
+}
+
+// single workgroup: exclusive scans of the bucket sizes and of the sub-bucket counts
+//   off[b]    = first sorted slot of bucket b            (off[B] = number of pairs)
+//   suboff[b] = first sub-bucket of bucket b             (suboff[B] = number of sub-buckets)
+//   info[0]   = max sub-buckets of any bucket, info[1] = number of sub-buckets
+ZK_KERNEL void msm_scan_kernel(const uint32_t* hist, uint32_t B, uint32_t L, uint32_t* off, uint32_t* cursor,
+                               uint32_t* suboff, uint32_t* info) {
+    __shared__ uint32_t sa[1024], sb[1024];
+    __shared__ uint32_t smax;
+    const uint32_t T = blockDim.x, tid = threadIdx.x;
+    const uint32_t ipt = ceil_div(B, T);
+    const uint32_t lo = tid * ipt < B ? tid * ipt : B;
+    const uint32_t hi = lo + ipt < B ? lo + ipt : B;
+    uint32_t a = 0, s = 0, mx = 0;
+    for (uint32_t b = lo; b < hi; b++) {
+        uint32_t cnt = hist[b], sbk = ceil_div(cnt, L);
+        a += cnt; s += sbk; mx = sbk > mx ? sbk : mx;
+    }
+    sa[tid] = a; sb[tid] = s;
+    if (tid == 0) smax = 0;
+    __syncthreads();
+    atomicMax(&smax, mx);
+    for (uint32_t d = 1; d < T; d <<= 1) {
+        uint32_t va = tid >= d ? sa[tid - d] : 0, vb = tid >= d ? sb[tid - d] : 0;
+        __syncthreads();
+        sa[tid] += va; sb[tid] += vb;
+        __syncthreads();
+    }
+    uint32_t ea = sa[tid] - a, es = sb[tid] - s;
+    for (uint32_t b = lo; b < hi; b++) {
+        uint32_t cnt = hist[b];
+        off[b] = ea; cursor[b] = ea; suboff[b] = es;
+        ea += cnt; es += ceil_div(cnt, L);
+    }
+    if (tid == T - 1) {
+        off[B] = sa[T - 1]; suboff[B] = sb[T - 1];
+        info[0] = smax; info[1] = sb[T - 1];
+    }
+}
+
+// second pass of the counting sort: every workgroup re-derives its chunk's LDS histogram, reserves
+// a contiguous range per bucket from the global cursors, then drops point references in place.
+// reference = (negative << 31) | (window * n_table + scalar index)
+ZK_KERNEL void msm_scatter_kernel(const void* scalars, uint32_t n, int c, int W, uint32_t n_table, uint32_t* cursor,
+                                  uint32_t* sorted) {
+    ZK_DYN_SHARED(uint32_t, lh);
+    const uint32_t B = 1u << (c - 1);
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lh[b] = 0;
+    __syncthreads();
+    const uint32_t chunk = ceil_div(n, gridDim.x);
+    const uint32_t lo = blockIdx.x * chunk;
+    const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        u256 s = Fr::from_mont(load_u256(scalars, i));
+        for_each_digit(s, c, W, [&](int, uint32_t mag, bool) { atomicAdd(&lh[mag - 1], 1u); });
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
+        uint32_t v = lh[b];
+        lh[b] = v ? atomicAdd(&cursor[b], v) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        u256 s = Fr::from_mont(load_u256(scalars, i));
+        for_each_digit(s, c, W, [&](int j, uint32_t mag, bool neg) {
+            uint32_t pos = atomicAdd(&lh[mag - 1], 1u);
+            sorted[pos] = (neg ? 0x80000000u : 0u) | ((uint32_t)j * n_table + i);
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bucket accumulation: one thread per sub-bucket (<= L references), XYZZ mixed additions
+// ------------------------------------------------------------------------------------------------
+ZK_KERNEL void msm_accumulate_kernel(const void* table, const uint32_t* sorted, const uint32_t* off,
+                                     const uint32_t* suboff, uint32_t B, uint32_t L, void* sub0) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= suboff[B]) return;
+    const uint32_t b = find_segment(suboff, B, j);
+    const uint32_t k = j - suboff[b];
+    uint32_t p = off[b] + k * L;
+    const uint32_t bend = off[b + 1];
+    const uint32_t end = p + L < bend ? p + L : bend;
+    XYZZ acc = xyzz_identity();
+    uint32_t ref = sorted[p];
+    Affine pt = load_affine(table, ref & 0x7fffffffu);
+    while (true) {
+        const uint32_t cur_ref = ref;
+        const Affine cur = pt;
+        ++p;
+        if (p < end) {  // fetch the next point while the current addition runs
+            ref = sorted[p];
+            pt = load_affine(table, ref & 0x7fffffffu);
+        }
+        xyzz_madd_signed(acc, cur, (cur_ref >> 31) != 0);
+        if (p >= end) break;
+    }
+    store_xyzz(sub0, j, acc);
+}
+
+// fan-in merge of the sub-buckets of each bucket; round r reads `in`, writes `out` (ping-pong).
+// After r_eff = ceil(log_M(max_s)) rounds bucket b sits at index suboff[b] of buffer (r_eff & 1).
+ZK_KERNEL void msm_merge_kernel(const void* in, void* out, const uint32_t* suboff, uint32_t B, uint32_t M,
+                                uint32_t Mpow_prev, const uint32_t* info) {
+    if (Mpow_prev >= info[0]) return;  // every bucket already has a single entry
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= suboff[B]) return;
+    const uint32_t b = find_segment(suboff, B, j);
+    const uint32_t k = j - suboff[b];
+    const uint32_t s_b = suboff[b + 1] - suboff[b];
+    const uint32_t cnt_prev = ceil_div(s_b, Mpow_prev);
+    const uint32_t cnt_cur = ceil_div(cnt_prev, M);
+    if (k >= cnt_cur) return;
+    const uint32_t base = suboff[b] + k * M;
+    XYZZ acc = load_xyzz(in, base);
+    for (uint32_t m = 1; m < M && k * M + m < cnt_prev; m++) xyzz_add(acc, load_xyzz(in, base + m));
+    store_xyzz(out, suboff[b] + k, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bucket reduction by weight bits.  Bucket b has weight w = b + 1 in [1, 2^(c-1)].
+//   class t < c-1 : { w < 2^(c-1) : bit t of w set }   (2^(c-2) members)
+//   class c-1     : { w = 2^(c-1) }                     (1 member)
+// result = sum_t 2^t * C_t with C_t the plain sum of class t.
+// ------------------------------------------------------------------------------------------------
+ZK_KERNEL void msm_class_first_kernel(const void* subA, const void* subB, const uint32_t* suboff, const uint32_t* info,
+                                      uint32_t Mmerge, int c, uint32_t M, uint32_t groups, void* out) {
+    const uint32_t max_s = info[0];
+    uint32_t pw = 1, r = 0;
+    while (pw < max_s) { pw *= Mmerge; r++; }
+    const void* buf = (r & 1) ? subB : subA;
+    const uint32_t t = blockIdx.y;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    XYZZ acc = xyzz_identity();
+    if ((int)t == c - 1) {
+        const uint32_t b = (1u << (c - 1)) - 1;
+        if (g == 0 && suboff[b + 1] > suboff[b]) acc = load_xyzz(buf, suboff[b]);
+    } else {
+        const uint32_t Kc = c >= 2 ? 1u << (c - 2) : 0;
+        for (uint32_t m = 0; m < M; m++) {
+            const uint32_t k = g * M + m;
+            if (k >= Kc) break;
+            const uint32_t w = ((k >> t) << (t + 1)) | (1u << t) | (k & ((1u << t) - 1u));
+            const uint32_t b = w - 1;
+            if (suboff[b + 1] > suboff[b]) xyzz_add(acc, load_xyzz(buf, suboff[b]));
+        }
+    }
+    store_xyzz(out, (size_t)t * groups + g, acc);
+}
+ZK_KERNEL void msm_class_round_kernel(const void* in, uint32_t count_in, void* out, uint32_t count_out, uint32_t M) {
+    const uint32_t t = blockIdx.y;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count_out) return;
+    const size_t base = (size_t)t * count_in;
+    XYZZ acc = load_xyzz(in, base + (size_t)g * M);
+    for (uint32_t m = 1; m < M && g * M + m < count_in; m++) xyzz_add(acc, load_xyzz(in, base + (size_t)g * M + m));
+    store_xyzz(out, (size_t)t * count_out + g, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// base-table expansion (registration time)
+// ------------------------------------------------------------------------------------------------
+ZK_KERNEL void g1_affine_to_xyzz_kernel(const void* aff, uint32_t n, void* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    store_xyzz(out, i, xyzz_from_affine(load_affine(aff, i)));
+}
+ZK_KERNEL void g1_dbl_times_kernel(void* pts, uint32_t n, int times) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XYZZ p = load_xyzz(pts, i);
+    for (int k = 0; k < times; k++) p = xyzz_dbl(p);
+    store_xyzz(pts, i, p);
+}
+// XYZZ -> affine with one inversion per `chunk` points (Montgomery's trick); out.x doubles as the
+// prefix-product scratch between the two sweeps.
+ZK_KERNEL void g1_batch_to_affine_kernel(const void* in, uint32_t n, uint32_t chunk, void* out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo64 = (uint64_t)t * chunk;
+    if (lo64 >= n) return;
+    const uint32_t lo = (uint32_t)lo64;
+    const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+    u256 acc = Fq::one();
+    for (uint32_t k = lo; k < hi; k++) {
+        u256 zz = load_u256(in, 4 * (size_t)k + 2), zzz = load_u256(in, 4 * (size_t)k + 3);
+        store_u256(out, 2 * (size_t)k, acc);
+        if (!Fq::is_zero(zz)) acc = Fq::mul(acc, Fq::mul(zz, zzz));
+    }
+    u256 inv = Fq::inv(acc);
+    for (uint32_t k = hi; k-- > lo;) {
+        XYZZ p = load_xyzz(in, k);
+        Affine o;
+        if (Fq::is_zero(p.zz)) {
+            o.x = Fq::zero(); o.y = Fq::zero();
+        } else {
+            u256 pre = load_u256(out, 2 * (size_t)k);
+            u256 I = Fq::mul(inv, pre);  // 1 / (zz * zzz)
+            inv = Fq::mul(inv, Fq::mul(p.zz, p.zzz));
+            o.x = Fq::mul(p.x, Fq::mul(I, p.zzz));  // X / ZZ
+            o.y = Fq::mul(p.y, Fq::mul(I, p.zz));   // Y / ZZZ
+        }
+        store_affine(out, k, o);
+    }
+}
+
+// out[i] = [s_i] G via an 8-bit fixed-window table of the generator: gtab[w][d-1] = d * 256^w * G
+ZK_KERNEL void g1_fixed_base_kernel(const void* scalars, uint32_t n, const void* gtab, void* out_xyzz) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u256 s = Fr::from_mont(load_u256(scalars, i));
+    XYZZ acc = xyzz_identity();
+    for (int w = 0; w < 32; w++) {
+        uint32_t d = (s.v[w >> 2] >> (8 * (w & 3))) & 0xffu;
+        if (d) {
+            Affine p = load_affine(gtab, (size_t)w * 255 + (d - 1));
+            xyzz_madd(acc, p.x, p.y);
+        }
+    }
+    store_xyzz(out_xyzz, i, acc);
+}
+// gtab build: row w from row w-1: entry(d) of row w = 256 * entry(d) of row w-1; row 0 = d*G
+ZK_KERNEL void g1_gtab_row0_kernel(void* row_xyzz) {  // 255 threads: d*G by double-and-add
+    const uint32_t d = threadIdx.x + 1;
+    if (d > 255) return;
+    Affine g;
+    g.x = Fq::one();
+    g.y = Fq::dbl(Fq::one());  // generator (1, 2)
+    XYZZ acc = xyzz_identity();
+    for (int b = 7; b >= 0; b--) {
+        acc = xyzz_dbl(acc);
+        if ((d >> b) & 1) xyzz_madd(acc, g.x, g.y);
+    }
+    store_xyzz(row_xyzz, threadIdx.x, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int windows_for(int c) { return 254 / c + 1; }
+
+static int pick_c(size_t n, const Tune& t) {
+    if (t.msm_c >= 3 && t.msm_c <= 16) return t.msm_c;
+    int best = 3;
+    double best_cost = 1e300;
+    for (int c = 3; c <= 16; c++) {
+        double cost = (double)n * windows_for(c) + 24.0 * (double)(1u << (c - 1));
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
+// Expand `n` affine points (device) into the window-multiple table.
+static int build_table(zk_ctx* ctx, const void* d_pts, size_t n, BaseTable& bt) {
+    const int c = bt.c, W = bt.W;
+    const size_t tbytes = (size_t)W * n * 64;
+    ZK_HIP(hipMalloc(&bt.d_table, tbytes));
+    ZK_HIP(hipMemcpyAsync(bt.d_table, d_pts, n * 64, hipMemcpyDeviceToDevice, ctx->stream));
+    if (W > 1) {
+        ZK_HIP(ctx->ws_pts.ensure(n * 128));
+        const int blk = ctx->tune.msm_block;
+        const uint32_t grid = (uint32_t)((n + blk - 1) / blk);
+        ZK_LAUNCH(g1_affine_to_xyzz_kernel, grid, blk, 0, ctx->stream, d_pts, (uint32_t)n, ctx->ws_pts.p);
+        ZK_CHECK_LAUNCH();
+        const uint32_t chunk = 32;
+        const uint32_t bgrid = (uint32_t)(((n + chunk - 1) / chunk + blk - 1) / blk);
+        for (int j = 1; j < W; j++) {
+            ZK_LAUNCH(g1_dbl_times_kernel, grid, blk, 0, ctx->stream, ctx->ws_pts.p, (uint32_t)n, c);
+            ZK_CHECK_LAUNCH();
+            ZK_LAUNCH(g1_batch_to_affine_kernel, bgrid, blk, 0, ctx->stream, (const void*)ctx->ws_pts.p, (uint32_t)n, chunk,
+                      (void*)((char*)bt.d_table + (size_t)j * n * 64));
+            ZK_CHECK_LAUNCH();
+        }
+    }
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+int msm_register(zk_ctx* ctx, const void* pts, size_t n, bool on_device, uint64_t* handle) {
+    if (!pts || !handle || n == 0) return ctx->fail(ZK_ERR_ARG, "zk_bases_register: null/empty");
+    BaseTable bt;
+    bt.n = n;
+    bt.c = pick_c(n, ctx->tune);
+    bt.W = windows_for(bt.c);
+    if ((uint64_t)bt.W * n >= (1ull << 31)) return ctx->fail(ZK_ERR_LIMIT, "zk_bases_register: W*n = %llu exceeds 2^31", (unsigned long long)bt.W * n);
+    const void* d_pts = pts;
+    if (!on_device) {
+        ZK_HIP(ctx->ws_tmp.ensure(n * 64));
+        ZK_HIP(hipMemcpyAsync(ctx->ws_tmp.p, pts, n * 64, hipMemcpyHostToDevice, ctx->stream));
+        d_pts = ctx->ws_tmp.p;
+    }
+    int rc = build_table(ctx, d_pts, n, bt);
+    if (rc) { if (bt.d_table) (void)hipFree(bt.d_table); return rc; }
+    *handle = ctx->next_handle++;
+    ctx->bases[*handle] = bt;
+    return ZK_OK;
+}
+
+int msm_release(zk_ctx* ctx, uint64_t handle) {
+    auto it = ctx->bases.find(handle);
+    if (it == ctx->bases.end()) return ctx->fail(ZK_ERR_ARG, "zk_bases_release: unknown handle %llu", (unsigned long long)handle);
+    (void)hipFree(it->second.d_table);
+    ctx->bases.erase(it);
+    return ZK_OK;
+}
+
+static void xyzz_to_jacobian_host(const XYZZ& p, void* out96) {
+    u256* o = reinterpret_cast<u256*>(out96);
+    if (xyzz_is_identity(p)) { o[0] = Fq::zero(); o[1] = Fq::zero(); o[2] = Fq::zero(); return; }
+    u256 I = Fq::inv(Fq::mul(p.zz, p.zzz));
+    o[0] = Fq::mul(p.x, Fq::mul(I, p.zzz));
+    o[1] = Fq::mul(p.y, Fq::mul(I, p.zz));
+    o[2] = Fq::one();
+}
+
+// core: leaves the c class sums in host memory and folds them.  out_xyzz (128 B) receives the
+// unnormalised result.
+static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* d_scal, size_t n, XYZZ* out_xyzz) {
+    const int c = bt.c, W = bt.W;
+    const uint32_t B = 1u << (c - 1);
+    const Tune& tn = ctx->tune;
+    const uint64_t pairs_max = (uint64_t)n * W;
+    uint32_t L = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pairs_max / (uint64_t)tn.msm_target_threads, (uint64_t)tn.msm_min_chunk),
+                                              (uint64_t)tn.msm_max_chunk);
+    const uint64_t S_cap = pairs_max / L + B + 1;
+    const uint32_t M = (uint32_t)tn.msm_merge_fanin, TM = (uint32_t)tn.msm_tree_fanin;
+
+    // small buffers: hist[B] off[B+1] cursor[B] suboff[B+1] info[4]
+    const size_t small_words = (size_t)4 * B + 8;
+    ZK_HIP(ctx->ws_small.ensure(small_words * 4));
+    uint32_t* d_hist = (uint32_t*)ctx->ws_small.p;
+    uint32_t* d_off = d_hist + B;
+    uint32_t* d_cursor = d_off + B + 1;
+    uint32_t* d_suboff = d_cursor + B;
+    uint32_t* d_info = d_suboff + B + 1;
+    ZK_HIP(ctx->ws_sorted.ensure(pairs_max * 4 + 16));
+    ZK_HIP(ctx->ws_sub0.ensure(S_cap * 128));
+    ZK_HIP(ctx->ws_sub1.ensure(S_cap * 128));  // merged entries stay at bucket-relative slots
+    const uint32_t Kc = c >= 2 ? 1u << (c - 2) : 1;
+    const uint32_t groups0 = ceil_div(Kc, TM);
+    ZK_HIP(ctx->ws_cls0.ensure((size_t)c * groups0 * 128));
+    ZK_HIP(ctx->ws_cls1.ensure((size_t)c * ceil_div(groups0, TM) * 128 + 128));
+
+    hipStream_t st = ctx->stream;
+    ZK_HIP(hipMemsetAsync(d_hist, 0, (size_t)B * 4, st));
+    int wgs = tn.msm_sort_wgs;
+    {   // do not spread tiny inputs over many workgroups (each one flushes the full histogram)
+        uint64_t per = (uint64_t)tn.msm_sort_threads * 4;
+        uint64_t want = (n + per - 1) / per;
+        if (want < (uint64_t)wgs) wgs = (int)std::max<uint64_t>(want, 1);
+    }
+    const size_t lds = (size_t)B * 4;
+    EvTimer t_sort(ctx, "msm_sort");
+    ZK_LAUNCH(msm_hist_kernel, wgs, tn.msm_sort_threads, lds, st, d_scal, (uint32_t)n, c, W, d_hist);
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(msm_scan_kernel, 1, 1024, 0, st, (const uint32_t*)d_hist, B, L, d_off, d_cursor, d_suboff, d_info);
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(msm_scatter_kernel, wgs, tn.msm_sort_threads, lds, st, d_scal, (uint32_t)n, c, W, (uint32_t)bt.n, d_cursor,
+              (uint32_t*)ctx->ws_sorted.p);
+    ZK_CHECK_LAUNCH();
+    t_sort.stop();
+
+    const int blk = tn.msm_block;
+    EvTimer t_acc(ctx, "msm_accumulate");
+    ZK_LAUNCH(msm_accumulate_kernel, (uint32_t)((S_cap + blk - 1) / blk), blk, 0, st, (const void*)bt.d_table,
+              (const uint32_t*)ctx->ws_sorted.p, (const uint32_t*)d_off, (const uint32_t*)d_suboff, B, L, ctx->ws_sub0.p);
+    ZK_CHECK_LAUNCH();
+    t_acc.stop();
+
+    EvTimer t_red(ctx, "msm_reduce");
+    // merge rounds: worst case one bucket holds every pair
+    {
+        uint64_t max_s_bound = pairs_max / L + 1;
+        uint64_t pw = 1;
+        int r = 0;
+        while (pw < max_s_bound) {
+            void* in = (r & 1) ? ctx->ws_sub1.p : ctx->ws_sub0.p;
+            void* out = (r & 1) ? ctx->ws_sub0.p : ctx->ws_sub1.p;
+            // threads needed this round: at most ceil(S/pw) + B entries are live, but indices are
+            // bucket-relative, so launch over all sub-buckets of round 0 (idle threads exit early)
+            ZK_LAUNCH(msm_merge_kernel, (uint32_t)((S_cap + blk - 1) / blk), blk, 0, st, (const void*)in, out,
+                      (const uint32_t*)d_suboff, B, M, (uint32_t)pw, (const uint32_t*)d_info);
+            ZK_CHECK_LAUNCH();
+            pw *= M;
+            r++;
+        }
+    }
+    // class sums
+    uint32_t count = groups0;
+    ZK_LAUNCH(msm_class_first_kernel, dim3(ceil_div(groups0, (uint32_t)blk), c), blk, 0, st, (const void*)ctx->ws_sub0.p,
+              (const void*)ctx->ws_sub1.p, (const uint32_t*)d_suboff, (const uint32_t*)d_info, M, c, TM, groups0, ctx->ws_cls0.p);
+    ZK_CHECK_LAUNCH();
+    int flip = 0;
+    while (count > 1) {
+        uint32_t nxt = ceil_div(count, TM);
+        void* in = flip ? ctx->ws_cls1.p : ctx->ws_cls0.p;
+        void* out = flip ? ctx->ws_cls0.p : ctx->ws_cls1.p;
+        ZK_LAUNCH(msm_class_round_kernel, dim3(ceil_div(nxt, (uint32_t)blk), c), blk, 0, st, (const void*)in, count, out, nxt, TM);
+        ZK_CHECK_LAUNCH();
+        count = nxt;
+        flip ^= 1;
+    }
+    t_red.stop();
+    std::vector<XYZZ> cls(c);
+    ZK_HIP(hipMemcpyAsync(cls.data(), flip ? ctx->ws_cls1.p : ctx->ws_cls0.p, (size_t)c * 128, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    t_sort.resolve(); t_acc.resolve(); t_red.resolve();
+    // sum_t 2^t C_t, Horner from the top class
+    XYZZ acc = cls[c - 1];
+    for (int t = c - 2; t >= 0; t--) {
+        acc = xyzz_dbl(acc);
+        xyzz_add(acc, cls[t]);
+    }
+    *out_xyzz = acc;
+    return ZK_OK;
+}
+
+int msm_run(zk_ctx* ctx, uint64_t handle, const void* scalars, size_t n, bool on_device, void* out, int partial) {
+    auto it = ctx->bases.find(handle);
+    if (it == ctx->bases.end()) return ctx->fail(ZK_ERR_ARG, "zk_msm: unknown bases handle %llu", (unsigned long long)handle);
+    const BaseTable& bt = it->second;
+    if (!out || (!scalars && n)) return ctx->fail(ZK_ERR_ARG, "zk_msm: null pointer");
+    if (n > bt.n) return ctx->fail(ZK_ERR_ARG, "zk_msm: n = %zu exceeds registered table size %zu", n, bt.n);
+    XYZZ res = xyzz_identity();
+    if (n > 0) {
+        const void* d_scal = scalars;
+        if (!on_device) {
+            ZK_HIP(ctx->ws_scalars.ensure(n * 32));
+            ZK_HIP(hipMemcpyAsync(ctx->ws_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+            d_scal = ctx->ws_scalars.p;
+        }
+        int rc = msm_core(ctx, bt, d_scal, n, &res);
+        if (rc) return rc;
+    }
+    if (partial) memcpy(out, &res, 128);
+    else xyzz_to_jacobian_host(res, out);
+    return ZK_OK;
+}
+
+int g1_sum_xyzz_host(const void* xyzz, size_t count, void* out_jac) {
+    const XYZZ* p = reinterpret_cast<const XYZZ*>(xyzz);
+    XYZZ acc = xyzz_identity();
+    for (size_t i = 0; i < count; i++) xyzz_add(acc, p[i]);
+    xyzz_to_jacobian_host(acc, out_jac);
+    return ZK_OK;
+}
+
+// fixed-base batch multiplication ------------------------------------------------------------------
+struct GTab { void* d = nullptr; };
+static std::map<zk_ctx*, GTab> g_gtabs;
+static std::mutex g_gtab_mu;
+
+static int ensure_gtab(zk_ctx* ctx, void** out) {
+    std::lock_guard<std::mutex> lk(g_gtab_mu);
+    GTab& g = g_gtabs[ctx];
+    if (!g.d) {
+        void* row = nullptr; void* tab = nullptr;
+        ZK_HIP(hipMalloc(&row, 255 * 128));
+        ZK_HIP(hipMalloc(&tab, (size_t)32 * 255 * 64));
+        ZK_LAUNCH(g1_gtab_row0_kernel, 1, 256, 0, ctx->stream, row);
+        ZK_CHECK_LAUNCH();
+        for (int w = 0; w < 32; w++) {
+            if (w) { ZK_LAUNCH(g1_dbl_times_kernel, 1, 256, 0, ctx->stream, row, 255u, 8); ZK_CHECK_LAUNCH(); }
+            ZK_LAUNCH(g1_batch_to_affine_kernel, 1, 64, 0, ctx->stream, (const void*)row, 255u, 4u, (void*)((char*)tab + (size_t)w * 255 * 64));
+            ZK_CHECK_LAUNCH();
+        }
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(row);
+        g.d = tab;
+    }
+    *out = g.d;
+    return ZK_OK;
+}
+void release_gtab(zk_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_gtab_mu);
+    auto it = g_gtabs.find(ctx);
+    if (it != g_gtabs.end()) { if (it->second.d) (void)hipFree(it->second.d); g_gtabs.erase(it); }
+}
+
+int g1_fixed_base_mul(zk_ctx* ctx, const void* d_scalars, size_t n, void* d_out_affine) {
+    if (!d_scalars || !d_out_affine) return ctx->fail(ZK_ERR_ARG, "zk_g1_fixed_base_mul_dev: null pointer");
+    if (n == 0) return ZK_OK;
+    if (n >= (1ull << 31)) return ctx->fail(ZK_ERR_LIMIT, "zk_g1_fixed_base_mul_dev: n too large");
+    void* gtab = nullptr;
+    int rc = ensure_gtab(ctx, &gtab);
+    if (rc) return rc;
+    ZK_HIP(ctx->ws_pts.ensure(n * 128));
+    const int blk = ctx->tune.msm_block;
+    ZK_LAUNCH(g1_fixed_base_kernel, (uint32_t)((n + blk - 1) / blk), blk, 0, ctx->stream, d_scalars, (uint32_t)n, (const void*)gtab, ctx->ws_pts.p);
+    ZK_CHECK_LAUNCH();
+    const uint32_t chunk = 32;
+    ZK_LAUNCH(g1_batch_to_affine_kernel, (uint32_t)(((n + chunk - 1) / chunk + blk - 1) / blk), blk, 0, ctx->stream, (const void*)ctx->ws_pts.p,
+              (uint32_t)n, chunk, d_out_affine);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+int msm_set_lds_attr() {
+#ifndef ZK_EMU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msm_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msm_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+    return 0;
+}
+
+}  // namespace zk

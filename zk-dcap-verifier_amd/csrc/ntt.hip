@@ -1,0 +1,397 @@
+// Radix-2^r multi-pass NTT over BN254 Fr for MI355X (gfx950).
+//
+// Replaces halo2_proofs (zkwebauthn @ c254c75, Cargo.lock:1314-1327) src/arithmetic.rs best_fft
+// (in place, natural order in and out, out[j] = sum_i a[i] omega^(ij)) and the
+// EvaluationDomain wrappers of src/poly/domain.rs (App. C.3), whose scaling steps are fused here
+// into the first load / last store of the transform.
+//
+// The CPU algorithm (bit-reverse, then log n radix-2 sweeps over the whole array) would cost log n
+// HBM round trips.  Here the transform is factored N = R1 * R2 (* R3): each pass loads a tile of
+// R x C elements into LDS (two 16-byte planes so that neighbouring lanes hit distinct banks),
+// runs all log R butterfly stages there, applies the inter-pass twiddle on the way out and writes
+// C-element (C*32 B) contiguous runs.  The digit-reversed placement of the last pass replaces the
+// bit-reversal pass, so natural order is kept with 2-3 HBM round trips in total.
+#include "ctx.h"
+
+namespace zk {
+
+struct NttPassArgs {
+    const void* src;
+    void* dst;
+    uint32_t log_n;
+    uint32_t blk_log;   // log2 of the sub-transform this pass works inside
+    uint32_t r;         // log2 radix of this pass
+    uint32_t c_log;     // log2 columns per tile
+    uint32_t q_log;     // final pass: log2 of the fast output digit range (Q)
+    uint32_t p_log;     // final pass: log2 of the middle digit range (P)
+    const void* stage_tw;   // omega_R^k, k < R/2
+    const void* tw_lo;      // omega^e, e < 2^lo_bits
+    const void* tw_hi;      // omega^(h << lo_bits)
+    uint32_t lo_bits;
+    // fused operations
+    uint32_t n_valid;       // first pass only (0 = all)
+    int pre_zeta;
+    int post_scale;
+    int post_zeta_inv;
+    u256 scale;
+};
+
+ZK_HD uint32_t bitrev(uint32_t x, uint32_t bits) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+ZK_HD u256 zeta_pow(uint32_t k) {  // ZETA^k, k in {1, 2}
+    const uint64_t z1[4] = BN254_FR_ZETA_M, z2[4] = BN254_FR_ZETA2_M;
+    u256 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)((k == 1 ? z1[i >> 1] : z2[i >> 1]) >> (32 * (i & 1)));
+    return o;
+}
+ZK_HD u256 ntt_load_input(const NttPassArgs& a, size_t idx) {
+    if (a.n_valid && idx >= a.n_valid) return Fr::zero();
+    u256 v = load_u256(a.src, idx);
+    if (a.pre_zeta) {
+        uint32_t m = (uint32_t)idx % 3u;
+        if (m) v = Fr::mul(v, zeta_pow(m));
+    }
+    return v;
+}
+ZK_HD u256 ntt_post(const NttPassArgs& a, u256 v, size_t out_idx) {
+    if (a.post_scale) v = Fr::mul(v, a.scale);
+    if (a.post_zeta_inv) {
+        uint32_t m = (uint32_t)out_idx % 3u;
+        if (m) v = Fr::mul(v, zeta_pow(3 - m));  // ZETA^-m = ZETA^(3-m)
+    }
+    return v;
+}
+ZK_HD void lds_put(uint4* lo, uint4* hi, uint32_t idx, const u256& v) {
+    lo[idx] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+    hi[idx] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+}
+ZK_HD u256 lds_get(const uint4* lo, const uint4* hi, uint32_t idx) {
+    uint4 l = lo[idx], h = hi[idx];
+    u256 o;
+    o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w;
+    o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w;
+    return o;
+}
+
+// all log R radix-2 DIT stages on the tile held in LDS (rows were stored bit-reversed)
+__device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r, uint32_t c_log, const void* stage_tw) {
+    const uint32_t C = 1u << c_log;
+    const uint32_t nbf = (1u << (r - 1)) << c_log;  // butterflies per stage in the tile
+    for (uint32_t s = 0; s < r; s++) {
+        const uint32_t half = 1u << s;
+        for (uint32_t q = threadIdx.x; q < nbf; q += blockDim.x) {
+            const uint32_t col = q & (C - 1), bq = q >> c_log;
+            const uint32_t grp = bq >> s, pos = bq & (half - 1);
+            const uint32_t i0 = ((grp << (s + 1)) + pos) * C + col, i1 = i0 + half * C;
+            u256 x = lds_get(lo, hi, i0), y = lds_get(lo, hi, i1);
+            if (pos) y = Fr::mul(y, load_u256(stage_tw, (size_t)pos << (r - 1 - s)));
+            lds_put(lo, hi, i0, Fr::add(x, y));
+            lds_put(lo, hi, i1, Fr::sub(x, y));
+        }
+        __syncthreads();
+    }
+}
+
+// non-final pass: rows are `cols` apart inside a sub-transform of size 2^blk_log; in/out share
+// the same addresses; the output row j of column m is multiplied by omega_blk^(m*j).
+ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
+    ZK_DYN_SHARED(uint4, smem);
+    const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
+    uint4* lo = smem;
+    uint4* hi = smem + tile;
+    const uint32_t cols_log = a.blk_log - a.r;
+    const uint32_t tiles_per_blk_log = cols_log - a.c_log;
+    const uint32_t t = blockIdx.x;
+    const size_t o = t >> tiles_per_blk_log;
+    const uint32_t m0 = (t & ((1u << tiles_per_blk_log) - 1)) << a.c_log;
+    const size_t base = (o << a.blk_log) + m0;
+    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+        const uint32_t col = e & (C - 1), row = e >> a.c_log;
+        const size_t idx = base + ((size_t)row << cols_log) + col;
+        lds_put(lo, hi, bitrev(row, a.r) * C + col, ntt_load_input(a, idx));
+    }
+    __syncthreads();
+    ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw);
+    const uint32_t sh = a.log_n - a.blk_log;
+    const uint32_t lomask = (1u << a.lo_bits) - 1;
+    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+        const uint32_t col = e & (C - 1), row = e >> a.c_log;
+        u256 v = lds_get(lo, hi, e);
+        const uint32_t ex = ((m0 + col) * row) << sh;  // < 2^log_n
+        if (ex) {
+            u256 tw = load_u256(a.tw_lo, ex & lomask);
+            const uint32_t h = ex >> a.lo_bits;
+            if (h) tw = Fr::mul(tw, load_u256(a.tw_hi, h));
+            v = Fr::mul(v, tw);
+        }
+        store_u256(a.dst, base + ((size_t)row << cols_log) + col, v);
+    }
+}
+
+// final pass: the sub-transform is contiguous (size R); outer index o = j1 * P + jm; the result
+// row goes to out[j1 + Q * (jm + P * row)] — the digit reversal that restores natural order.
+ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
+    ZK_DYN_SHARED(uint4, smem);
+    const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
+    uint4* lo = smem;
+    uint4* hi = smem + tile;
+    const uint32_t t = blockIdx.x;
+    const uint32_t jm = t & ((1u << a.p_log) - 1);
+    const uint32_t j10 = (t >> a.p_log) << a.c_log;
+    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+        const uint32_t row = e & (R - 1), col = e >> a.r;
+        const size_t o = ((size_t)(j10 + col) << a.p_log) + jm;
+        lds_put(lo, hi, bitrev(row, a.r) * C + col, ntt_load_input(a, (o << a.r) + row));
+    }
+    __syncthreads();
+    ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw);
+    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+        const uint32_t col = e & (C - 1), row = e >> a.c_log;
+        const size_t out_idx = (size_t)(j10 + col) + (((size_t)jm + ((size_t)row << a.p_log)) << a.q_log);
+        store_u256(a.dst, out_idx, ntt_post(a, lds_get(lo, hi, e), out_idx));
+    }
+}
+
+// out[k] = base^(k * 1), k < count (each thread: square-and-multiply over the bits of k)
+ZK_KERNEL void fr_pow_table_kernel(u256 base, uint32_t count, void* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    u256 acc = Fr::one();
+    for (int b = 31; b >= 0; b--) {
+        acc = Fr::sqr(acc);
+        if ((k >> b) & 1) acc = Fr::mul(acc, base);
+    }
+    store_u256(out, k, acc);
+}
+
+// element-wise helpers ---------------------------------------------------------------------------
+ZK_KERNEL void fr_vec_kernel(int op, const void* x, const void* y, void* out, size_t n, u256 scalar) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        u256 a = load_u256(x, i), o;
+        switch (op) {
+            case 0: o = Fr::mul(a, load_u256(y, i)); break;
+            case 1: o = Fr::add(a, load_u256(y, i)); break;
+            case 2: o = Fr::sub(a, load_u256(y, i)); break;
+            case 3: o = Fr::mul(a, scalar); break;
+            default: o = Fq::mul(a, load_u256(y, i)); break;  // 4: Fq product (curve-field parity tests)
+        }
+        store_u256(out, i, o);
+    }
+}
+// a[i] *= t[i mod 2^t_log]
+ZK_KERNEL void fr_mul_periodic_kernel(void* a, size_t n, const void* t, uint32_t t_log) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) store_u256(a, i, Fr::mul(load_u256(a, i), load_u256(t, i & ((1u << t_log) - 1))));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static u256 fr_pow2k_host(u256 x, uint32_t k) {  // x^(2^k)
+    for (uint32_t i = 0; i < k; i++) x = Fr::sqr(x);
+    return x;
+}
+
+static void plan_passes(uint32_t log_n, const Tune& tn, uint32_t rl[3], int* passes) {
+    uint32_t rmax = (uint32_t)tn.ntt_max_radix_log;
+    if (rmax > (uint32_t)tn.ntt_tile_log) rmax = tn.ntt_tile_log;
+    if (rmax < 1) rmax = 1;
+    int p = (int)((log_n + rmax - 1) / rmax);
+    if (p < 1) p = 1;
+    if (p > 3) p = 3;
+    rl[0] = rl[1] = rl[2] = 0;
+    uint32_t rem = log_n;
+    for (int i = 0; i < p; i++) {
+        uint32_t r = (rem + (p - i) - 1) / (p - i);
+        rl[i] = r;
+        rem -= r;
+    }
+    *passes = p;
+}
+
+static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleSet** out) {
+    uint32_t rl[3];
+    int passes;
+    plan_passes(log_n, ctx->tune, rl, &passes);
+    for (auto& t : ctx->twiddles)
+        if (t.log_n == log_n && Fr::eq(t.omega, omega) && t.passes == passes && t.radix_log[0] == rl[0] && t.radix_log[1] == rl[1] &&
+            t.radix_log[2] == rl[2]) { *out = &t; return ZK_OK; }
+    TwiddleSet ts;
+    ts.log_n = log_n; ts.omega = omega; ts.passes = passes;
+    for (int i = 0; i < 3; i++) ts.radix_log[i] = rl[i];
+    ts.lo_bits = log_n < 10 ? log_n : 10;
+    const int blk = 256;
+    const uint32_t nlo = 1u << ts.lo_bits, nhi = 1u << (log_n - ts.lo_bits);
+    ZK_HIP(hipMalloc(&ts.d_lo, (size_t)nlo * 32));
+    ZK_HIP(hipMalloc(&ts.d_hi, (size_t)nhi * 32));
+    ZK_LAUNCH(fr_pow_table_kernel, (nlo + blk - 1) / blk, blk, 0, ctx->stream, omega, nlo, ts.d_lo);
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(fr_pow_table_kernel, (nhi + blk - 1) / blk, blk, 0, ctx->stream, fr_pow2k_host(omega, ts.lo_bits), nhi, ts.d_hi);
+    ZK_CHECK_LAUNCH();
+    for (int i = 0; i < passes; i++) {
+        const uint32_t half = rl[i] ? 1u << (rl[i] - 1) : 1;
+        ZK_HIP(hipMalloc(&ts.d_stage[i], (size_t)half * 32));
+        ZK_LAUNCH(fr_pow_table_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, fr_pow2k_host(omega, log_n - rl[i]), half, ts.d_stage[i]);
+        ZK_CHECK_LAUNCH();
+    }
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->twiddles.push_back(ts);
+    *out = &ctx->twiddles.back();
+    return ZK_OK;
+}
+
+void release_twiddles(zk_ctx* ctx) {
+    for (auto& t : ctx->twiddles) {
+        if (t.d_lo) (void)hipFree(t.d_lo);
+        if (t.d_hi) (void)hipFree(t.d_hi);
+        for (int i = 0; i < 3; i++) if (t.d_stage[i]) (void)hipFree(t.d_stage[i]);
+    }
+    ctx->twiddles.clear();
+}
+
+int ntt_set_lds_attr() {
+#ifndef ZK_EMU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+    return 0;
+}
+
+// In-place (on d_a) natural-order NTT of 2^log_n elements; fuse may redirect the input.
+int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const NttFuse* fuse) {
+    if (!d_a) return ctx->fail(ZK_ERR_ARG, "zk_ntt: null pointer");
+    if (log_n > 27) return ctx->fail(ZK_ERR_LIMIT, "zk_ntt: log_n = %u > 27", log_n);
+    const size_t N = (size_t)1 << log_n;
+    NttFuse nf;
+    if (fuse) nf = *fuse;
+    const void* src0 = nf.src ? nf.src : d_a;
+    if (log_n == 0) {
+        if (src0 != d_a) ZK_HIP(hipMemcpyAsync(d_a, src0, 32, hipMemcpyDeviceToDevice, ctx->stream));
+        if (nf.post_scale) {
+            ZK_LAUNCH(fr_vec_kernel, 1, 64, 0, ctx->stream, 3, (const void*)d_a, (const void*)d_a, d_a, (size_t)1, nf.scale);
+            ZK_CHECK_LAUNCH();
+        }
+        return ZK_OK;
+    }
+    TwiddleSet* ts;
+    int rc = get_twiddles(ctx, log_n, omega, &ts);
+    if (rc) return rc;
+    const Tune& tn = ctx->tune;
+    const uint32_t tl = (uint32_t)tn.ntt_tile_log;
+    ZK_HIP(ctx->ws_ntt.ensure(N * 32));
+    void* tmp = ctx->ws_ntt.p;
+    const int P = ts->passes;
+    // data flow: pass 0 reads src0; intermediate passes live in tmp; the final pass writes d_a.
+    uint32_t blk_log = log_n;
+    for (int p = 0; p < P; p++) {
+        NttPassArgs a;
+        memset(&a, 0, sizeof a);
+        const bool first = p == 0, last = p == P - 1;
+        a.src = first ? src0 : tmp;
+        a.dst = last ? d_a : tmp;
+        if (first && last && src0 == d_a) a.dst = tmp;  // single pass cannot scatter in place
+        a.log_n = log_n; a.blk_log = blk_log; a.r = ts->radix_log[p];
+        a.stage_tw = ts->d_stage[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits;
+        if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; }
+        if (last) { a.post_scale = nf.post_scale; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
+        const uint32_t room = tl > a.r ? tl - a.r : 0;
+        if (!last) {
+            const uint32_t cols_log = blk_log - a.r;
+            a.c_log = room < cols_log ? room : cols_log;
+            const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
+            const size_t lds = ((size_t)32 << (a.r + a.c_log));
+            ZK_LAUNCH(ntt_strided_pass_kernel, grid, tn.ntt_threads, lds, ctx->stream, a);
+            ZK_CHECK_LAUNCH();
+        } else {
+            // o = j1 * Pm + jm with j1 the digit of pass 0 (Q = R_0) and jm the digit of pass 1 (if 3 passes)
+            a.q_log = P >= 2 ? ts->radix_log[0] : 0;
+            a.p_log = P == 3 ? ts->radix_log[1] : 0;
+            a.c_log = room < a.q_log ? room : a.q_log;
+            const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
+            const size_t lds = ((size_t)32 << (a.r + a.c_log));
+            ZK_LAUNCH(ntt_final_pass_kernel, grid, tn.ntt_threads, lds, ctx->stream, a);
+            ZK_CHECK_LAUNCH();
+            if (a.dst != d_a) ZK_HIP(hipMemcpyAsync(d_a, a.dst, N * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        blk_log -= a.r;
+    }
+    return ZK_OK;
+}
+
+// ---- EvaluationDomain constants (host, Fr arithmetic of field.cuh compiled for the CPU) ---------
+static u256 fr_const(const uint64_t (&l)[4]) {
+    u256 o;
+    for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)(l[i >> 1] >> (32 * (i & 1)));
+    return o;
+}
+u256 domain_omega(uint32_t k) {  // ROOT_OF_UNITY^(2^(S-k))
+    const uint64_t r[4] = BN254_FR_ROOT_OF_UNITY_M;
+    return fr_pow2k_host(fr_const(r), BN254_FR_S - k);
+}
+u256 fr_two_inv_pow(uint32_t k) {  // (2^k)^-1
+    const uint64_t ti[4] = BN254_FR_TWO_INV_M;
+    u256 t = fr_const(ti), acc = Fr::one();
+    for (uint32_t i = 0; i < k; i++) acc = Fr::mul(acc, t);
+    return acc;
+}
+
+int domain_lagrange_to_coeff(zk_ctx* ctx, void* d_a, uint32_t k) {
+    if (k > BN254_FR_S) return ctx->fail(ZK_ERR_ARG, "k = %u > S", k);
+    NttFuse f;
+    f.post_scale = 1; f.scale = fr_two_inv_pow(k);
+    return ntt_dev(ctx, d_a, k, Fr::inv(domain_omega(k)), &f);
+}
+int domain_coeff_to_lagrange(zk_ctx* ctx, void* d_a, uint32_t k) {
+    if (k > BN254_FR_S) return ctx->fail(ZK_ERR_ARG, "k = %u > S", k);
+    return ntt_dev(ctx, d_a, k, domain_omega(k), nullptr);
+}
+int domain_coeff_to_extended(zk_ctx* ctx, const void* d_coeff, uint32_t k, uint32_t ek, void* d_out) {
+    if (ek > BN254_FR_S || k > ek || !d_coeff || !d_out) return ctx->fail(ZK_ERR_ARG, "zk_coeff_to_extended: bad k/extended_k/pointer");
+    NttFuse f;
+    f.src = d_coeff; f.n_valid = 1u << k; f.pre_zeta = 1;
+    return ntt_dev(ctx, d_out, ek, domain_omega(ek), &f);
+}
+int domain_extended_to_coeff(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek) {
+    if (ek > BN254_FR_S || k > ek) return ctx->fail(ZK_ERR_ARG, "zk_extended_to_coeff: bad k/extended_k");
+    NttFuse f;
+    f.post_scale = 1; f.scale = fr_two_inv_pow(ek); f.post_zeta_inv = 1;
+    return ntt_dev(ctx, d_a, ek, Fr::inv(domain_omega(ek)), &f);
+}
+int domain_divide_by_vanishing(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek) {
+    if (ek > BN254_FR_S || k > ek || ek - k > 6) return ctx->fail(ZK_ERR_ARG, "zk_divide_by_vanishing_poly: bad k/extended_k");
+    // t_evaluations[i] = (ZETA^n * (ext_omega^n)^i - 1)^-1
+    const uint64_t z[4] = BN254_FR_ZETA_M;
+    u256 zn = fr_pow2k_host(fr_const(z), k), won = fr_pow2k_host(domain_omega(ek), k);
+    const uint32_t nt = 1u << (ek - k);
+    std::vector<u256> t(nt);
+    u256 cur = zn;
+    for (uint32_t i = 0; i < nt; i++) { t[i] = Fr::inv(Fr::sub(cur, Fr::one())); cur = Fr::mul(cur, won); }
+    ZK_HIP(ctx->ws_tmp.ensure(nt * 32));
+    ZK_HIP(hipMemcpyAsync(ctx->ws_tmp.p, t.data(), nt * 32, hipMemcpyHostToDevice, ctx->stream));
+    const size_t N = (size_t)1 << ek;
+    const int blk = ctx->tune.vec_block;
+    size_t grid = (N + blk - 1) / blk; if (grid > 4096) grid = 4096;
+    ZK_LAUNCH(fr_mul_periodic_kernel, (uint32_t)grid, blk, 0, ctx->stream, d_a, N, (const void*)ctx->ws_tmp.p, ek - k);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipStreamSynchronize(ctx->stream));  // t lives on this frame
+    return ZK_OK;
+}
+int fr_vec_op(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n, const u256* scalar) {
+    if (!a || !out || (!b && op != 3)) return ctx->fail(ZK_ERR_ARG, "vector op: null pointer");
+    if (n == 0) return ZK_OK;
+    const int blk = ctx->tune.vec_block;
+    size_t grid = (n + blk - 1) / blk; if (grid > 4096) grid = 4096;
+    u256 s = scalar ? *scalar : Fr::one();
+    ZK_LAUNCH(fr_vec_kernel, (uint32_t)grid, blk, 0, ctx->stream, op, a, b ? b : a, out, n, s);
+    ZK_CHECK_LAUNCH();
+    return ZK_OK;
+}
+
+}  // namespace zk

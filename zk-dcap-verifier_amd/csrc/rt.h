@@ -1,0 +1,20 @@
+// Runtime glue.  The product build (default) is plain HIP for gfx950.
+//
+// With -DZK_EMU the SAME kernel sources are compiled as host C++ and every workgroup is run on
+// CPU threads (tests/csrc/emu_rt.h).  That build exists only so the kernels' index logic
+// (counting sort, sub-bucket splitting, tree rounds, NTT addressing ...) can be exercised by
+// `pytest -m "not gpu"` in a container without a GPU.  It is test infrastructure: the product
+// library libzkmi355.so is never built with ZK_EMU and has no CPU path.
+#pragma once
+#ifdef ZK_EMU
+#include "../../tests/csrc/emu_rt.h"
+#else
+#include <hip/hip_runtime.h>
+#define ZK_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (smem), (stream), __VA_ARGS__)
+// dynamic LDS, 16-byte aligned base (guide G17)
+#define ZK_DYN_SHARED(type, name)                                              \
+    extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
+    type* name = reinterpret_cast<type*>(name##_raw)
+#define ZK_KERNEL __global__
+#endif

@@ -1,0 +1,40 @@
+"""halo2_proofs::poly::kzg::commitment::ParamsKZG (commit side), MI355X edition.
+
+Mirrors (halo2_proofs 0.2.0 @ zkwebauthn c254c75) src/poly/kzg/commitment.rs:
+    commit_lagrange(poly, _blind) = best_multiexp(poly.values, g_lagrange[..n])
+    commit(poly, _blind)          = best_multiexp(poly.values, g[..n])
+(the Blind argument is ignored for KZG).  The two base tables are uploaded to
+HBM once, when the params object is created — the analogue of gen_srs()/ParamsKZG::read at
+circuits/src/sgx_dcap_verifier.rs:799.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import Backend, default_backend
+from .arithmetic import BasesHandle, best_multiexp
+
+
+class ParamsKZG:
+    def __init__(self, k: int, g: np.ndarray, g_lagrange: np.ndarray, backend: Backend | None = None):
+        self.backend = backend or default_backend()
+        self.k, self.n = k, 1 << k
+        g = np.ascontiguousarray(g, dtype=np.uint64).reshape(-1, 8)
+        g_lagrange = np.ascontiguousarray(g_lagrange, dtype=np.uint64).reshape(-1, 8)
+        assert g.shape[0] == self.n and g_lagrange.shape[0] == self.n
+        self.g = BasesHandle(self.backend, g)
+        self.g_lagrange = BasesHandle(self.backend, g_lagrange)
+
+    def commit(self, poly: np.ndarray) -> np.ndarray:
+        poly = np.asarray(poly, dtype=np.uint64).reshape(-1, 4)
+        assert poly.shape[0] <= self.n
+        return best_multiexp(poly, self.g)
+
+    def commit_lagrange(self, poly: np.ndarray) -> np.ndarray:
+        poly = np.asarray(poly, dtype=np.uint64).reshape(-1, 4)
+        assert poly.shape[0] == self.n
+        return best_multiexp(poly, self.g_lagrange)
+
+    def release(self):
+        self.g.release()
+        self.g_lagrange.release()

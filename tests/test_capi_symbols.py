@@ -1,0 +1,46 @@
+"""The product library loads on a CPU-only machine and exports every symbol include/zkmi355.h
+declares; creating a context without a GPU fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "zkmi355.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(built):
+    import zk_dcap_verifier_amd as z
+    lib = C.CDLL(z.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/zkmi355.h but not exported"
+    lib.zk_version.restype = C.c_char_p
+    assert b"gfx950" in lib.zk_version() and b"EMULATED" not in lib.zk_version()
+
+
+def test_no_cpu_fallback(built):
+    import torch
+    import zk_dcap_verifier_amd as z
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(z.ZkError) as e:
+        z.Backend(0)
+    assert e.value.code == -3
+
+
+def test_product_never_references_oracle_or_emulator():
+    pkg = os.path.join(ROOT, "zk-dcap-verifier_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp")) and f != "rt.h":
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle" not in txt.replace("no CPU", "") or f == "_lib.py" and "import oracle" not in txt, f
+                assert "libzkmi355_emu" not in txt, f

@@ -1,0 +1,72 @@
+"""Kernel index logic on CPU: the product's kernel SOURCES compiled against the test-only emulator
+(tests/csrc/emu_rt.h) and compared with the oracle.  This is not a product path — see rt.h."""
+import pytest
+
+import parity_cases as pc
+
+
+def test_vec_ops(emu, orc, pyref):
+    pc.check_vec_ops(emu, orc, pyref, 77)
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 7, 9, 10, 12])
+def test_ntt(emu, orc, pyref, log_n):
+    pc.check_ntt(emu, orc, pyref, log_n)
+
+
+@pytest.mark.parametrize("tile,radix", [(4, 2), (5, 5), (8, 3)])
+def test_ntt_other_plans(emu, orc, pyref, tile, radix):
+    emu.tune(ntt_tile_log=tile, ntt_max_radix_log=radix)
+    try:
+        for log_n in (3, 6, 8):
+            pc.check_ntt(emu, orc, pyref, log_n, seed=log_n)
+    finally:
+        emu.tune(ntt_tile_log=6, ntt_max_radix_log=4)
+
+
+@pytest.mark.parametrize("j,k", [(4, 5), (5, 6), (3, 4), (9, 3), (2, 4)])
+def test_domain(emu, orc, pyref, j, k):
+    pc.check_domain(emu, orc, pyref, j, k)
+
+
+@pytest.mark.parametrize("n,c", [(1, 0), (2, 0), (5, 0), (33, 0), (200, 5), (300, 7), (700, 0)])
+def test_msm_uniform(emu, orc, pyref, n, c):
+    emu.tune(msm_c=c)
+    try:
+        pc.check_msm(emu, orc, pyref, n, seed=n)
+    finally:
+        emu.tune(msm_c=0)
+
+
+@pytest.mark.parametrize("kind", ["ones", "zeros", "witness", "minus_one"])
+def test_msm_degenerate_scalar_columns(emu, orc, pyref, kind):
+    pc.check_msm(emu, orc, pyref, 257, seed=9, kind=kind)          # one heavy bucket -> several merge rounds
+
+
+def test_msm_repeated_and_identity_bases(emu, orc, pyref):
+    pc.check_msm(emu, orc, pyref, 100, seed=10, repeat_bases=True, with_identity=True)
+
+
+def test_msm_prefix_of_resident_table(emu, orc, pyref):
+    pc.check_msm_prefix_and_handle(emu, orc, pyref, 90)
+
+
+def test_fixed_base_mul(emu, orc, pyref):
+    pc.check_fixed_base(emu, orc, pyref, 40)
+
+
+def test_error_paths(emu, orc, pyref):
+    import numpy as np
+    import zk_dcap_verifier_amd as z
+    with pytest.raises(z.ZkError):
+        emu.msm(12345, np.zeros((1, 4), dtype=np.uint64))           # unknown handle
+    with pytest.raises(z.ZkError):
+        emu.tune(no_such_key=1)
+    sc, bases = pc.msm_inputs(orc, pyref, 8, 1)
+    h = z.arithmetic.BasesHandle(emu, bases)
+    with pytest.raises(z.ZkError):
+        emu.msm(h.handle, np.zeros((9, 4), dtype=np.uint64))        # more scalars than bases
+    assert (emu.msm(h.handle, np.zeros((0, 4), dtype=np.uint64)) == 0).all()   # empty MSM = identity
+    h.release()
+    with pytest.raises(AssertionError):
+        z.arithmetic.best_multiexp(sc[:3], bases)                   # halo2: assert_eq!(coeffs.len(), bases.len())

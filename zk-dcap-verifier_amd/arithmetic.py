@@ -39,7 +39,6 @@ def best_multiexp(coeffs, bases, backend: Backend | None = None) -> np.ndarray:
     coeffs.len() == bases.len() for raw arrays; with a handle, len(coeffs) <= handle.n (a prefix of
     the table is used, as commit() does with shorter polynomials).
     """
-    be = backend or default_backend()
     coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
     if isinstance(bases, BasesHandle):
         assert coeffs.shape[0] <= bases.n
@@ -48,6 +47,7 @@ def best_multiexp(coeffs, bases, backend: Backend | None = None) -> np.ndarray:
     assert coeffs.shape[0] == bases.shape[0], "best_multiexp: coeffs.len() != bases.len()"
     if coeffs.shape[0] == 0:
         return np.zeros(12, dtype=np.uint64)
+    be = backend or default_backend()
     h = BasesHandle(be, bases)
     try:
         return be.msm(h.handle, coeffs)

@@ -1,0 +1,124 @@
+"""evaluate_h: (1) the oracle against the polynomial-identity DEFINITION (pure Python ints);
+(2) the product's compiled micro-program (emulator on CPU) against the oracle."""
+import random
+
+import pytest
+
+import parity_cases as pc
+import quotient_cases as qc
+from zk_dcap_verifier_amd import evaluation as ev
+
+
+def test_oracle_evaluate_h_matches_polynomial_definition(orc, pyref):
+    """Random low-degree polynomials; the numerator at extended row i must equal the Horner-in-y fold of
+    the identities evaluated at the POINT x_i = ZETA * ext_omega^i, with rotations as x -> omega^rot x
+    (SURVEY.md App. C.4 / the identities listed in halo2's evaluate_h)."""
+    p, rnd = pyref, random.Random(12)
+    k, deg = 3, 4
+    dom = p.Domain(deg, k)
+    n, size, ek = 1 << k, 1 << dom.extended_k, dom.extended_k
+    R = p.R
+
+    def rp():
+        return [rnd.randrange(R) for _ in range(n)]              # a polynomial = n coefficients
+
+    fixed, advice = [rp()], [rp(), rp()]
+    l0, l_last, l_act = rp(), rp(), rp()
+    sigma, zs = [rp(), rp(), rp()], [rp(), rp()]                     # 3 permutation columns, chunk 2 -> 2 sets
+    lk_z, lk_a, lk_s = rp(), rp(), rp()
+    beta, gamma, theta, y = (rnd.randrange(R) for _ in range(4))
+    cst = rnd.randrange(R)
+    blinding = 5
+    perm_cols = [(0, 0), (0, 1), (1, 0)]
+    # gate: previous*y + fixed0 * (advice0(X) * advice1(wX) - cst)
+    g = ev.Graph()
+    c0 = g.add_constant(orc.fr_from_ints([cst])[0])
+    r0, r1 = g.add_rotation(0), g.add_rotation(1)
+    m = g.add_calculation(ev.MUL, ev.vs(ev.ADVICE, 0, r0), ev.vs(ev.ADVICE, 1, r1))
+    s = g.add_calculation(ev.SUB, m, c0)
+    gate = g.add_calculation(ev.MUL, ev.vs(ev.FIXED, 0, r0), s)
+    g.add_calculation(ev.HORNER, ev.vs(ev.PREVIOUS), [gate], ev.vs(ev.Y))
+    # lookup: (advice0 * theta + advice1 + beta) * (fixed0 + gamma)
+    lg = ev.Graph()
+    q0 = lg.add_rotation(0)
+    ci = lg.add_calculation(ev.HORNER, ev.vs(ev.ADVICE, 0, q0), [ev.vs(ev.ADVICE, 1, q0)], ev.vs(ev.THETA))
+    a1 = lg.add_calculation(ev.ADD, ci, ev.vs(ev.BETA))
+    b1 = lg.add_calculation(ev.ADD, ev.vs(ev.FIXED, 0, q0), ev.vs(ev.GAMMA))
+    lg.add_calculation(ev.MUL, a1, b1)
+    prog = ev.Program(k=k, extended_k=ek, n_fixed=1, n_advice=2, n_instance=0, n_challenges=0, blinding_factors=blinding, cs_degree=deg,
+                      perm_columns=perm_cols, custom_gates=g, lookups=[lg])
+    odom = orc.Domain(deg, k)
+
+    def cos(poly):
+        return odom.coeff_to_extended(orc.fr_from_ints(poly))
+
+    def M(v):
+        return orc.fr_from_ints([v])[0]
+
+    got = orc.fr_to_ints(orc.evaluate_h(prog.to_blob(), [cos(f) for f in fixed], [cos(a) for a in advice], [], cos(l0), cos(l_last), cos(l_act),
+                                        [cos(s_) for s_ in sigma], [cos(z_) for z_ in zs], [cos(lk_z)], [cos(lk_a)], [cos(lk_s)], [],
+                                        M(beta), M(gamma), M(theta), M(y), size))
+    w = dom.omega
+    E = p.poly_eval
+    col = {(0, 0): advice[0], (0, 1): advice[1], (1, 0): fixed[0]}
+    for i in range(size):
+        x = dom.extended_point(i)
+        xn, xp, xl = x * w % R, x * pow(w, -1, R) % R, x * pow(w, -(blinding + 1), R) % R
+
+        def fold(v_, t):
+            return (v_ * y + t) % R
+
+        v = 0
+        v = fold(v, E(fixed[0], x) * (E(advice[0], x) * E(advice[1], xn) - cst))
+        v = fold(v, (1 - E(zs[0], x)) * E(l0, x))
+        v = fold(v, (E(zs[1], x) ** 2 - E(zs[1], x)) * E(l_last, x))
+        v = fold(v, (E(zs[1], x) - E(zs[0], xl)) * E(l0, x))
+        dj = 0
+        for s_idx, chunk in enumerate(([0, 1], [2])):
+            left, right = E(zs[s_idx], xn), E(zs[s_idx], x)
+            for j in chunk:
+                vv = E(col[perm_cols[j]], x)
+                left = left * (vv + beta * E(sigma[j], x) + gamma) % R
+                right = right * (vv + pow(p.DELTA, dj, R) * beta * x + gamma) % R
+                dj += 1
+            v = fold(v, (left - right) * E(l_act, x))
+        tv = ((E(advice[0], x) * theta + E(advice[1], x)) + beta) * (E(fixed[0], x) + gamma) % R
+        a_, s_, z_ = E(lk_a, x), E(lk_s, x), E(lk_z, x)
+        v = fold(v, (1 - z_) * E(l0, x))
+        v = fold(v, (z_ * z_ - z_) * E(l_last, x))
+        v = fold(v, (E(lk_z, xn) * (a_ + beta) * (s_ + gamma) - z_ * tv) * E(l_act, x))
+        v = fold(v, (a_ - s_) * E(l0, x))
+        v = fold(v, (a_ - s_) * (a_ - E(lk_a, xp)) * E(l_act, x))
+        assert got[i] == v % R, i
+
+
+SHAPES = [(1, dict(k=3, cs_degree=4, n_fixed=2, n_advice=3, n_instance=1, n_challenges=2, n_perm=5, n_lookups=2)),
+          (2, dict(k=4, cs_degree=5, n_fixed=1, n_advice=2, n_instance=0, n_challenges=0, n_perm=3, n_lookups=1)),
+          (3, dict(k=3, cs_degree=3, n_fixed=1, n_advice=1, n_instance=0, n_challenges=1, n_perm=0, n_lookups=0)),
+          (4, dict(k=2, cs_degree=9, n_fixed=3, n_advice=4, n_instance=2, n_challenges=1, n_perm=8, n_lookups=3))]
+
+
+@pytest.mark.parametrize("seed,shape", SHAPES)
+def test_emulated_quotient_vs_oracle(emu, orc, pyref, seed, shape):
+    prog = qc.build_program(orc, pyref, seed=seed, **shape)
+    qc.run_case(emu, orc, pyref, pc, prog, seed=seed)
+
+
+def test_quotient_rejects_malformed_programs(emu, orc, pyref):
+    import zk_dcap_verifier_amd as z
+    with pytest.raises(z.ZkError):
+        emu.quotient_program_load(b"\x00" * 64)
+    prog = qc.build_program(orc, pyref, k=3, cs_degree=4, n_fixed=1, n_advice=1, n_instance=0, n_challenges=0, n_perm=2, n_lookups=1, seed=9)
+    blob = prog.to_blob()
+    with pytest.raises(z.ZkError):
+        emu.quotient_program_load(blob[: (len(blob) // 2) & ~3])         # truncated
+    prog.custom_gates.calculations[0] = (ev.MUL, 0, (ev.vs(ev.ADVICE, 99, 0), ev.vs(ev.BETA)))
+    with pytest.raises(z.ZkError):
+        emu.quotient_program_load(prog.to_blob())                        # column index out of range
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,shape", SHAPES + [(5, dict(k=10, cs_degree=5, n_fixed=4, n_advice=6, n_instance=1, n_challenges=1, n_perm=7, n_lookups=3))])
+def test_gpu_quotient_vs_oracle(gpu, orc, pyref, seed, shape):
+    prog = qc.build_program(orc, pyref, seed=seed, gate_ops=60 if shape["k"] >= 10 else 24, **shape)
+    qc.run_case(gpu, orc, pyref, pc, prog, seed=seed)

@@ -5,6 +5,7 @@
 
 namespace zk {
 int ntt_set_lds_attr();
+int quotient_set_lds_attr();
 int domain_lagrange_to_coeff(zk_ctx* ctx, void* d_a, uint32_t k);
 int domain_coeff_to_lagrange(zk_ctx* ctx, void* d_a, uint32_t k);
 int domain_coeff_to_extended(zk_ctx* ctx, const void* d_coeff, uint32_t k, uint32_t ek, void* d_out);
@@ -43,6 +44,7 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ZK_ERR_HIP; }
     msm_set_lds_attr();
     ntt_set_lds_attr();
+    quotient_set_lds_attr();
     *out = ctx;
     return ZK_OK;
 }

@@ -395,3 +395,14 @@ int fr_vec_op(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size
 }
 
 }  // namespace zk
+
+namespace zk {
+// power tables of omega (shared with the quotient kernel for extended_omega^idx)
+int ntt_pow_tables(zk_ctx* ctx, uint32_t log_n, const u256& omega, const void** lo, const void** hi, uint32_t* lo_bits) {
+    TwiddleSet* ts;
+    int rc = get_twiddles(ctx, log_n, omega, &ts);
+    if (rc) return rc;
+    *lo = ts->d_lo; *hi = ts->d_hi; *lo_bits = ts->lo_bits;
+    return ZK_OK;
+}
+}  // namespace zk

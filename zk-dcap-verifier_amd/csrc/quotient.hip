@@ -1,9 +1,565 @@
-// placeholder until the interpreter lands (same commit series)
+// h(X) numerator on the extended coset — replaces halo2_proofs (zkwebauthn @ c254c75,
+// Cargo.lock:1314-1327) src/plonk/evaluation.rs Evaluator::evaluate_h.
+//
+// halo2 walks the extended rows three times on the CPU (custom gates; permutation; each lookup),
+// re-reading `values` every time.  Here the proving key's GraphEvaluator programs, the permutation
+// argument and the lookup arguments are compiled ONCE (at zk_quotient_program_load) into a single
+// straight-line micro-program, so that one kernel launch evaluates a row completely: every coset
+// column is read exactly once per rotation (HBM-bound in the ideal), the running value lives in
+// registers, and the few live intermediates sit in LDS slots assigned by a linear-scan allocator
+// (slot-major layout: lane-consecutive 16-byte accesses, conflict free).
+//
+// The micro-ISA (one uint4 per instruction) is internal; the input format is the "ZKQ1" blob
+// documented in INTEGRATION.md.
 #include "ctx.h"
+#include <algorithm>
+
 namespace zk {
-struct QuotProgram { int dummy; };
-int quotient_program_load(zk_ctx* ctx, const void*, size_t, uint64_t*) { return ctx->fail(ZK_ERR_PROGRAM, "quotient: not built yet"); }
-int quotient_program_release(zk_ctx* ctx, uint64_t) { return ctx->fail(ZK_ERR_ARG, "quotient: unknown program"); }
-int quotient_run(zk_ctx* ctx, uint64_t, const zk_quotient_args*) { return ctx->fail(ZK_ERR_PROGRAM, "quotient: not built yet"); }
-void release_programs(zk_ctx*) {}
+
+int ntt_pow_tables(zk_ctx* ctx, uint32_t log_n, const u256& omega, const void** lo, const void** hi, uint32_t* lo_bits);
+u256 domain_omega(uint32_t k);
+
+enum { VS_CONST = 0, VS_INTER, VS_FIXED, VS_ADVICE, VS_INSTANCE, VS_CHALLENGE, VS_BETA, VS_GAMMA, VS_THETA, VS_Y, VS_PREV };
+enum { OP_ADD = 0, OP_SUB, OP_MUL, OP_SQUARE, OP_DOUBLE, OP_NEGATE, OP_HORNER, OP_STORE };
+// micro-ops
+enum { M_ADD = 0, M_SUB, M_MUL, M_SQR, M_DBL, M_NEG, M_MOV, M_MULADD };
+enum { K_SLOT = 0, K_CONST, K_COL, K_ACC, K_XPOW };
+
+struct QuotProgram {
+    uint32_t k = 0, ek = 0, n_fixed = 0, n_advice = 0, n_instance = 0, n_challenges = 0, blinding = 0, degree = 0;
+    uint32_t n_perm_cols = 0, n_sets = 0, n_lookups = 0;
+    std::vector<uint32_t> perm_cols;      // pairs (type, index)
+    std::vector<uint4> code;
+    std::vector<u256> graph_consts;       // constants that come with the program
+    std::vector<int32_t> rotations;       // distinct rotations (rows)
+    uint32_t n_slots = 0, n_cols = 0;
+    // constant table layout (indices)
+    uint32_t c_zero = 0, c_one = 0, c_chal = 0, c_beta = 0, c_gamma = 0, c_theta = 0, c_y = 0, c_delta = 0, n_consts = 0;
+    // column ids
+    uint32_t col_fixed = 0, col_advice = 0, col_instance = 0, col_l0 = 0, col_llast = 0, col_lactive = 0, col_sigma = 0, col_z = 0,
+             col_lk_z = 0, col_lk_a = 0, col_lk_s = 0;
+    bool uses_xpow = false;
+    void* d_code = nullptr;
+    void* d_consts = nullptr;
+    void* d_cols = nullptr;
+    void* d_rot = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------
+// interpreter kernel
+// ------------------------------------------------------------------------------------------------
+#ifdef ZK_EMU
+#define ZK_UNIFORM(x) (x)
+#else
+#define ZK_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#endif
+
+struct QuotArgs {
+    const uint4* code;
+    uint32_t n_instr;
+    const void* consts;
+    const void* const* cols;
+    const uint32_t* rot_off;   // row offsets (already scaled, non-negative, < size)
+    uint32_t size_log;
+    const void* tw_lo;
+    const void* tw_hi;
+    uint32_t lo_bits;
+    int uses_xpow;
+    void* out;
+};
+
+ZK_KERNEL void quotient_kernel(QuotArgs q) {
+    ZK_DYN_SHARED(uint4, smem);
+    const uint32_t T = blockDim.x, tid = threadIdx.x;
+    const uint32_t idx = blockIdx.x * T + tid;
+    const uint32_t mask = (1u << q.size_log) - 1u;
+    u256 acc = Fr::zero(), xpow = Fr::one();
+    if (q.uses_xpow) {  // extended_omega^idx
+        xpow = load_u256(q.tw_lo, idx & ((1u << q.lo_bits) - 1u));
+        const uint32_t h = idx >> q.lo_bits;
+        if (h) xpow = Fr::mul(xpow, load_u256(q.tw_hi, h));
+    }
+    auto fetch = [&](uint32_t src) -> u256 {
+        const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
+        switch (kind) {
+            case K_SLOT: {
+                uint4 l = smem[(2 * pay) * T + tid], h = smem[(2 * pay + 1) * T + tid];
+                u256 o;
+                o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w;
+                return o;
+            }
+            case K_CONST: return load_u256(q.consts, pay);
+            case K_COL: {
+                const uint32_t row = (idx + q.rot_off[pay & 0xffu]) & mask;
+                return load_u256(q.cols[pay >> 8], row);
+            }
+            case K_ACC: return acc;
+            default: return xpow;
+        }
+    };
+    for (uint32_t pc = 0; pc < q.n_instr; pc++) {
+        const uint4 ins = q.code[pc];
+        const uint32_t w0 = ZK_UNIFORM(ins.x), sa = ZK_UNIFORM(ins.y), sb = ZK_UNIFORM(ins.z), sc = ZK_UNIFORM(ins.w);
+        const uint32_t op = w0 & 0xffu;
+        u256 a = fetch(sa), r;
+        switch (op) {
+            case M_ADD: r = Fr::add(a, fetch(sb)); break;
+            case M_SUB: r = Fr::sub(a, fetch(sb)); break;
+            case M_MUL: r = Fr::mul(a, fetch(sb)); break;
+            case M_SQR: r = Fr::sqr(a); break;
+            case M_DBL: r = Fr::dbl(a); break;
+            case M_NEG: r = Fr::neg(a); break;
+            case M_MULADD: r = Fr::add(Fr::mul(a, fetch(sb)), fetch(sc)); break;
+            default: r = a; break;
+        }
+        if ((w0 >> 8) & 0xffu) {
+            acc = r;
+        } else {
+            const uint32_t slot = w0 >> 16;
+            smem[(2 * slot) * T + tid] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+            smem[(2 * slot + 1) * T + tid] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+        }
+    }
+    store_u256(q.out, idx, acc);
 }
+
+// ------------------------------------------------------------------------------------------------
+// compiler: ZKQ1 blob -> micro-program
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct VSrc { uint32_t kind, a, b; };
+struct Calc { uint32_t op, target; VSrc s0, s1; std::vector<VSrc> parts; };
+struct Graph {
+    std::vector<u256> constants;
+    std::vector<int32_t> rotations;
+    uint32_t num_intermediates = 0;
+    std::vector<Calc> calcs;
+};
+
+struct Reader {
+    const uint32_t* w; size_t n, pos = 0; bool ok = true;
+    uint32_t get() { if (pos >= n) { ok = false; return 0; } return w[pos++]; }
+    VSrc vs() { VSrc v; v.kind = get(); v.a = get(); v.b = get(); return v; }
+};
+
+bool read_graph(Reader& r, Graph& g) {
+    uint32_t nc = r.get();
+    if (!r.ok || nc > (1u << 20)) return false;
+    for (uint32_t i = 0; i < nc; i++) { u256 c; for (int j = 0; j < 8; j++) c.v[j] = r.get(); g.constants.push_back(c); }
+    uint32_t nr = r.get();
+    if (!r.ok || nr > 255) return false;
+    for (uint32_t i = 0; i < nr; i++) g.rotations.push_back((int32_t)r.get());
+    g.num_intermediates = r.get();
+    uint32_t ncalc = r.get();
+    if (!r.ok || ncalc > (1u << 22)) return false;
+    for (uint32_t i = 0; i < ncalc; i++) {
+        Calc c;
+        c.op = r.get(); c.target = r.get(); c.s0 = r.vs();
+        c.s1 = VSrc{0, 0, 0};
+        if (c.op == OP_ADD || c.op == OP_SUB || c.op == OP_MUL) c.s1 = r.vs();
+        else if (c.op == OP_HORNER) {
+            c.s1 = r.vs();
+            uint32_t np = r.get();
+            if (!r.ok || np > (1u << 20)) return false;
+            for (uint32_t p = 0; p < np; p++) c.parts.push_back(r.vs());
+        } else if (c.op > OP_STORE) return false;
+        if (!r.ok || c.target >= g.num_intermediates) return false;
+        g.calcs.push_back(c);
+    }
+    return r.ok;
+}
+
+// virtual-register program
+struct VIns { uint32_t op; int dst; /* -1 = ACC, else vreg */ uint32_t src[3]; int vsrc[3]; /* vreg id when kind==SLOT */ int nsrc; };
+
+struct Builder {
+    QuotProgram& P;
+    std::vector<VIns> ins;
+    int next_vreg = 0;
+    explicit Builder(QuotProgram& p) : P(p) {}
+    static uint32_t enc(uint32_t kind, uint32_t pay) { return (kind << 28) | pay; }
+    struct Opnd { uint32_t word; int vreg; };
+    Opnd slot(int v) { return Opnd{enc(K_SLOT, 0), v}; }
+    Opnd cst(uint32_t i) { return Opnd{enc(K_CONST, i), -1}; }
+    Opnd acc() { return Opnd{enc(K_ACC, 0), -1}; }
+    Opnd xpow() { P.uses_xpow = true; return Opnd{enc(K_XPOW, 0), -1}; }
+    uint32_t rot_id(int32_t rot) {
+        for (size_t i = 0; i < P.rotations.size(); i++) if (P.rotations[i] == rot) return (uint32_t)i;
+        P.rotations.push_back(rot);
+        return (uint32_t)P.rotations.size() - 1;
+    }
+    Opnd col(uint32_t col_id, int32_t rot) { return Opnd{enc(K_COL, (col_id << 8) | rot_id(rot)), -1}; }
+    int emit(uint32_t op, int dst, std::initializer_list<Opnd> ops) {
+        VIns v; v.op = op; v.dst = dst; v.nsrc = 0;
+        for (auto& o : ops) { v.src[v.nsrc] = o.word; v.vsrc[v.nsrc] = o.vreg; v.nsrc++; }
+        for (int i = v.nsrc; i < 3; i++) { v.src[i] = enc(K_CONST, P.c_zero); v.vsrc[i] = -1; }
+        ins.push_back(v);
+        return dst;
+    }
+    int tmp(uint32_t op, std::initializer_list<Opnd> ops) { return emit(op, next_vreg++, ops); }
+    void fold(Opnd term) { emit(M_MULADD, -1, {acc(), cst(P.c_y), term}); }   // value = value*y + term
+};
+
+}  // namespace
+
+static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, QuotProgram& P) {
+    Reader r{words, nwords};
+    if (r.get() != 0x31514B5Au) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: bad magic");
+    P.k = r.get(); P.ek = r.get(); P.n_fixed = r.get(); P.n_advice = r.get(); P.n_instance = r.get(); P.n_challenges = r.get();
+    P.blinding = r.get(); P.degree = r.get(); P.n_perm_cols = r.get();
+    if (!r.ok || P.ek > 27 || P.k > P.ek || P.n_perm_cols > 4096 || P.n_fixed > 65536 || P.n_advice > 65536 || P.n_instance > 65536)
+        return ctx->fail(ZK_ERR_PROGRAM, "quotient program: header out of range");
+    for (uint32_t i = 0; i < 2 * P.n_perm_cols; i++) P.perm_cols.push_back(r.get());
+    P.n_lookups = r.get();
+    if (!r.ok || P.n_lookups > 4096) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: truncated header");
+    Graph custom;
+    std::vector<Graph> lookups(P.n_lookups);
+    if (!read_graph(r, custom)) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: malformed custom-gate graph");
+    for (auto& g : lookups) if (!read_graph(r, g)) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: malformed lookup graph");
+    if (P.n_perm_cols && P.degree < 3) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: cs_degree < 3 with a permutation");
+    const uint32_t chunk_len = P.n_perm_cols ? P.degree - 2 : 1;
+    P.n_sets = P.n_perm_cols ? (P.n_perm_cols + chunk_len - 1) / chunk_len : 0;
+
+    // column ids
+    uint32_t c = 0;
+    P.col_fixed = c; c += P.n_fixed;
+    P.col_advice = c; c += P.n_advice;
+    P.col_instance = c; c += P.n_instance;
+    P.col_l0 = c++; P.col_llast = c++; P.col_lactive = c++;
+    P.col_sigma = c; c += P.n_perm_cols;
+    P.col_z = c; c += P.n_sets;
+    P.col_lk_z = c; c += P.n_lookups;
+    P.col_lk_a = c; c += P.n_lookups;
+    P.col_lk_s = c; c += P.n_lookups;
+    P.n_cols = c;
+    if (c >= (1u << 20)) return ctx->fail(ZK_ERR_LIMIT, "quotient program: too many columns");
+    // constant table: graph constants first
+    std::vector<uint32_t> gbase;   // base index of each graph's constants
+    auto add_consts = [&](const Graph& g) { gbase.push_back((uint32_t)P.graph_consts.size()); for (auto& k : g.constants) P.graph_consts.push_back(k); };
+    add_consts(custom);
+    for (auto& g : lookups) add_consts(g);
+    uint32_t ci = (uint32_t)P.graph_consts.size();
+    P.c_zero = ci++; P.c_one = ci++;
+    P.c_chal = ci; ci += P.n_challenges;
+    P.c_beta = ci++; P.c_gamma = ci++; P.c_theta = ci++; P.c_y = ci++;
+    P.c_delta = ci; ci += P.n_perm_cols;
+    P.n_consts = ci;
+
+    Builder B(P);
+    // ---- graphs -------------------------------------------------------------------------------
+    auto run_graph = [&](const Graph& g, uint32_t cbase, bool prev_is_acc, int* result_vreg) -> int {
+        std::vector<int> cur(g.num_intermediates, -1);   // intermediate -> current vreg
+        auto opnd = [&](const VSrc& s, bool* ok) -> Builder::Opnd {
+            switch (s.kind) {
+                case VS_CONST: if (s.a >= g.constants.size()) *ok = false; return B.cst(cbase + s.a);
+                case VS_INTER: if (s.a >= cur.size() || cur[s.a] < 0) { *ok = false; return B.cst(P.c_zero); } return B.slot(cur[s.a]);
+                case VS_FIXED: if (s.a >= P.n_fixed || s.b >= g.rotations.size()) { *ok = false; return B.cst(P.c_zero); } return B.col(P.col_fixed + s.a, g.rotations[s.b]);
+                case VS_ADVICE: if (s.a >= P.n_advice || s.b >= g.rotations.size()) { *ok = false; return B.cst(P.c_zero); } return B.col(P.col_advice + s.a, g.rotations[s.b]);
+                case VS_INSTANCE: if (s.a >= P.n_instance || s.b >= g.rotations.size()) { *ok = false; return B.cst(P.c_zero); } return B.col(P.col_instance + s.a, g.rotations[s.b]);
+                case VS_CHALLENGE: if (s.a >= P.n_challenges) *ok = false; return B.cst(P.c_chal + s.a);
+                case VS_BETA: return B.cst(P.c_beta);
+                case VS_GAMMA: return B.cst(P.c_gamma);
+                case VS_THETA: return B.cst(P.c_theta);
+                case VS_Y: return B.cst(P.c_y);
+                case VS_PREV: return prev_is_acc ? B.acc() : B.cst(P.c_zero);
+                default: *ok = false; return B.cst(P.c_zero);
+            }
+        };
+        int last = -1;
+        for (auto& k : g.calcs) {
+            bool ok = true;
+            Builder::Opnd a = opnd(k.s0, &ok);
+            int v = -1;
+            switch (k.op) {
+                case OP_ADD: v = B.tmp(M_ADD, {a, opnd(k.s1, &ok)}); break;
+                case OP_SUB: v = B.tmp(M_SUB, {a, opnd(k.s1, &ok)}); break;
+                case OP_MUL: v = B.tmp(M_MUL, {a, opnd(k.s1, &ok)}); break;
+                case OP_SQUARE: v = B.tmp(M_SQR, {a}); break;
+                case OP_DOUBLE: v = B.tmp(M_DBL, {a}); break;
+                case OP_NEGATE: v = B.tmp(M_NEG, {a}); break;
+                case OP_STORE: v = B.tmp(M_MOV, {a}); break;
+                case OP_HORNER: {
+                    Builder::Opnd factor = opnd(k.s1, &ok);
+                    if (k.parts.empty()) { v = B.tmp(M_MOV, {a}); break; }
+                    Builder::Opnd curv = a;
+                    for (auto& p : k.parts) { v = B.tmp(M_MULADD, {curv, factor, opnd(p, &ok)}); curv = B.slot(v); }
+                    break;
+                }
+                default: ok = false;
+            }
+            if (!ok) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: operand out of range in a calculation");
+            cur[k.target] = v;
+            last = v;
+        }
+        *result_vreg = last;
+        return ZK_OK;
+    };
+    int res = -1;
+    int rc = run_graph(custom, gbase[0], true, &res);
+    if (rc) return rc;
+    if (res >= 0) B.emit(M_MOV, -1, {B.slot(res)});
+    else B.emit(M_MOV, -1, {B.cst(P.c_zero)});   // no custom gates: value = 0 (GraphEvaluator returns zero)
+
+    const Builder::Opnd one = B.cst(P.c_one), beta = B.cst(P.c_beta), gamma = B.cst(P.c_gamma);
+    const Builder::Opnd l0 = B.col(P.col_l0, 0), llast = B.col(P.col_llast, 0), lact = B.col(P.col_lactive, 0);
+    // ---- permutation argument ------------------------------------------------------------------
+    if (P.n_sets) {
+        const int32_t last_rot = -(int32_t)(P.blinding + 1);
+        auto z = [&](uint32_t s, int32_t rot) { return B.col(P.col_z + s, rot); };
+        int t = B.tmp(M_SUB, {one, z(0, 0)});
+        t = B.tmp(M_MUL, {B.slot(t), l0});
+        B.fold(B.slot(t));
+        t = B.tmp(M_SQR, {z(P.n_sets - 1, 0)});
+        t = B.tmp(M_SUB, {B.slot(t), z(P.n_sets - 1, 0)});
+        t = B.tmp(M_MUL, {B.slot(t), llast});
+        B.fold(B.slot(t));
+        for (uint32_t s = 1; s < P.n_sets; s++) {
+            t = B.tmp(M_SUB, {z(s, 0), z(s - 1, last_rot)});
+            t = B.tmp(M_MUL, {B.slot(t), l0});
+            B.fold(B.slot(t));
+        }
+        for (uint32_t s = 0; s < P.n_sets; s++) {
+            const uint32_t c0 = s * chunk_len, c1 = std::min(c0 + chunk_len, P.n_perm_cols);
+            auto vcol = [&](uint32_t j) {
+                const uint32_t ty = P.perm_cols[2 * j], ix = P.perm_cols[2 * j + 1];
+                return B.col((ty == 0 ? P.col_advice : ty == 1 ? P.col_fixed : P.col_instance) + ix, 0);
+            };
+            for (uint32_t j = c0; j < c1; j++) {
+                const uint32_t ty = P.perm_cols[2 * j], ix = P.perm_cols[2 * j + 1];
+                if (ty > 2 || ix >= (ty == 0 ? P.n_advice : ty == 1 ? P.n_fixed : P.n_instance))
+                    return ctx->fail(ZK_ERR_PROGRAM, "quotient program: permutation column out of range");
+            }
+            int left = -1, right = -1;
+            for (uint32_t j = c0; j < c1; j++) {
+                int u = B.tmp(M_MULADD, {beta, B.col(P.col_sigma + j, 0), vcol(j)});
+                u = B.tmp(M_ADD, {B.slot(u), gamma});
+                left = B.tmp(M_MUL, {left < 0 ? z(s, 1) : B.slot(left), B.slot(u)});
+            }
+            for (uint32_t j = c0; j < c1; j++) {
+                int u = B.tmp(M_MULADD, {B.cst(P.c_delta + j), B.xpow(), vcol(j)});
+                u = B.tmp(M_ADD, {B.slot(u), gamma});
+                right = B.tmp(M_MUL, {right < 0 ? z(s, 0) : B.slot(right), B.slot(u)});
+            }
+            t = B.tmp(M_SUB, {B.slot(left), B.slot(right)});
+            t = B.tmp(M_MUL, {B.slot(t), lact});
+            B.fold(B.slot(t));
+        }
+    }
+    // ---- lookup arguments ----------------------------------------------------------------------
+    for (uint32_t n = 0; n < P.n_lookups; n++) {
+        int tv = -1;
+        rc = run_graph(lookups[n], gbase[1 + n], false, &tv);
+        if (rc) return rc;
+        const Builder::Opnd table_value = tv >= 0 ? B.slot(tv) : B.cst(P.c_zero);
+        auto zc = [&](int32_t rot) { return B.col(P.col_lk_z + n, rot); };
+        auto ac = [&](int32_t rot) { return B.col(P.col_lk_a + n, rot); };
+        const Builder::Opnd sc = B.col(P.col_lk_s + n, 0);
+        int ams = B.tmp(M_SUB, {ac(0), sc});
+        int t = B.tmp(M_SUB, {one, zc(0)});
+        t = B.tmp(M_MUL, {B.slot(t), l0});
+        B.fold(B.slot(t));
+        t = B.tmp(M_SQR, {zc(0)});
+        t = B.tmp(M_SUB, {B.slot(t), zc(0)});
+        t = B.tmp(M_MUL, {B.slot(t), llast});
+        B.fold(B.slot(t));
+        t = B.tmp(M_ADD, {ac(0), beta});
+        int u = B.tmp(M_ADD, {sc, gamma});
+        t = B.tmp(M_MUL, {B.slot(t), B.slot(u)});
+        t = B.tmp(M_MUL, {B.slot(t), zc(1)});
+        u = B.tmp(M_MUL, {zc(0), table_value});
+        t = B.tmp(M_SUB, {B.slot(t), B.slot(u)});
+        t = B.tmp(M_MUL, {B.slot(t), lact});
+        B.fold(B.slot(t));
+        t = B.tmp(M_MUL, {B.slot(ams), l0});
+        B.fold(B.slot(t));
+        t = B.tmp(M_SUB, {ac(0), ac(-1)});
+        t = B.tmp(M_MUL, {B.slot(t), B.slot(ams)});
+        t = B.tmp(M_MUL, {B.slot(t), lact});
+        B.fold(B.slot(t));
+    }
+    if (P.rotations.size() > 255) return ctx->fail(ZK_ERR_LIMIT, "quotient program: more than 255 distinct rotations");
+
+    // ---- dead-code elimination + linear-scan slot allocation -------------------------------------
+    const int nv = B.next_vreg;
+    std::vector<int> last_use(nv, -1);
+    std::vector<char> keep(B.ins.size(), 1);
+    for (int pass = 0; pass < 2; pass++) {   // one backward sweep removes chains of dead values
+        std::fill(last_use.begin(), last_use.end(), -1);
+        for (size_t i = 0; i < B.ins.size(); i++) if (keep[i]) for (int s = 0; s < B.ins[i].nsrc; s++) if (B.ins[i].vsrc[s] >= 0) last_use[B.ins[i].vsrc[s]] = (int)i;
+        for (size_t i = B.ins.size(); i-- > 0;) {
+            if (!keep[i] || B.ins[i].dst < 0) continue;
+            bool used = false;
+            for (size_t j = i + 1; j < B.ins.size() && !used; j++) if (keep[j]) for (int s = 0; s < B.ins[j].nsrc; s++) if (B.ins[j].vsrc[s] == B.ins[i].dst) used = true;
+            if (!used) keep[i] = 0;
+        }
+    }
+    std::fill(last_use.begin(), last_use.end(), -1);
+    for (size_t i = 0; i < B.ins.size(); i++) if (keep[i]) for (int s = 0; s < B.ins[i].nsrc; s++) if (B.ins[i].vsrc[s] >= 0) last_use[B.ins[i].vsrc[s]] = (int)i;
+    std::vector<int> slot_of(nv, -1);
+    std::vector<int> free_slots;
+    uint32_t n_slots = 0;
+    for (size_t i = 0; i < B.ins.size(); i++) {
+        if (!keep[i]) continue;
+        VIns& v = B.ins[i];
+        uint32_t w[3];
+        for (int s = 0; s < 3; s++) {
+            w[s] = v.src[s];
+            if (s < v.nsrc && v.vsrc[s] >= 0) {
+                if (slot_of[v.vsrc[s]] < 0) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: intermediate read before it is written");
+                w[s] = Builder::enc(K_SLOT, (uint32_t)slot_of[v.vsrc[s]]);
+            }
+        }
+        for (int s = 0; s < v.nsrc; s++)   // operands die here -> their slots may be reused by dst
+            if (v.vsrc[s] >= 0 && last_use[v.vsrc[s]] == (int)i && slot_of[v.vsrc[s]] >= 0) {
+                bool dup = false;
+                for (int q = 0; q < s; q++) if (v.vsrc[q] == v.vsrc[s]) dup = true;
+                if (!dup) free_slots.push_back(slot_of[v.vsrc[s]]);
+            }
+        uint32_t w0 = v.op;
+        if (v.dst < 0) w0 |= 1u << 8;
+        else {
+            int sl;
+            if (!free_slots.empty()) { std::sort(free_slots.begin(), free_slots.end(), std::greater<int>()); sl = free_slots.back(); free_slots.pop_back(); }
+            else sl = (int)n_slots++;
+            slot_of[v.dst] = sl;
+            if (sl >= 65536) return ctx->fail(ZK_ERR_LIMIT, "quotient program: too many live intermediates");
+            w0 |= (uint32_t)sl << 16;
+        }
+        P.code.push_back(make_uint4(w0, w[0], w[1], w[2]));
+    }
+    P.n_slots = n_slots ? n_slots : 1;
+    return ZK_OK;
+}
+
+int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog) {
+    if (!blob || !prog || len < 48 || (len & 3)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_load: bad blob pointer/length");
+    std::vector<uint32_t> words(len / 4);
+    memcpy(words.data(), blob, len);
+    QuotProgram* P = new QuotProgram();
+    int rc = compile_program(ctx, words.data(), words.size(), *P);
+    if (rc) { delete P; return rc; }
+    if ((size_t)P->n_slots * 64 * 32 > 160 * 1024) {
+        delete P;
+        return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %u live intermediates; this build keeps at most 80 in LDS", P->n_slots);
+    }
+    hipError_t e = hipMalloc(&P->d_code, P->code.size() * 16 + 16);
+    if (e == hipSuccess) e = hipMalloc(&P->d_consts, (size_t)P->n_consts * 32 + 32);
+    if (e == hipSuccess) e = hipMalloc(&P->d_cols, (size_t)P->n_cols * sizeof(void*) + 8);
+    if (e == hipSuccess) e = hipMalloc(&P->d_rot, (P->rotations.size() + 1) * 4);
+    if (e == hipSuccess) e = hipMemcpy(P->d_code, P->code.data(), P->code.size() * 16, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (P->d_code) (void)hipFree(P->d_code);
+        if (P->d_consts) (void)hipFree(P->d_consts);
+        if (P->d_cols) (void)hipFree(P->d_cols);
+        if (P->d_rot) (void)hipFree(P->d_rot);
+        delete P;
+        return ctx->fail(ZK_ERR_HIP, "zk_quotient_program_load: device allocation failed");
+    }
+    *prog = ctx->next_handle++;
+    ctx->programs[*prog] = P;
+    return ZK_OK;
+}
+
+static void free_program(QuotProgram* P) {
+    if (P->d_code) (void)hipFree(P->d_code);
+    if (P->d_consts) (void)hipFree(P->d_consts);
+    if (P->d_cols) (void)hipFree(P->d_cols);
+    if (P->d_rot) (void)hipFree(P->d_rot);
+    delete P;
+}
+int quotient_program_release(zk_ctx* ctx, uint64_t prog) {
+    auto it = ctx->programs.find(prog);
+    if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_release: unknown program %llu", (unsigned long long)prog);
+    free_program(it->second);
+    ctx->programs.erase(it);
+    return ZK_OK;
+}
+void release_programs(zk_ctx* ctx) {
+    for (auto& kv : ctx->programs) free_program(kv.second);
+    ctx->programs.clear();
+}
+
+int quotient_set_lds_attr() {
+#ifndef ZK_EMU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+    return 0;
+}
+
+int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a) {
+    auto it = ctx->programs.find(prog);
+    if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_dev: unknown program %llu", (unsigned long long)prog);
+    QuotProgram& P = *it->second;
+    if (!a || !a->out || !a->l0 || !a->l_last || !a->l_active_row || !a->beta || !a->gamma || !a->theta || !a->y)
+        return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_dev: null argument");
+    if (a->n_sets != P.n_sets) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_dev: n_sets = %u but the program has %u permutation sets", a->n_sets, P.n_sets);
+    if ((P.n_fixed && !a->fixed) || (P.n_advice && !a->advice) || (P.n_instance && !a->instance) || (P.n_perm_cols && !a->perm_cosets) ||
+        (P.n_sets && !a->perm_products) || (P.n_lookups && (!a->lookup_product || !a->lookup_input || !a->lookup_table)) ||
+        (P.n_challenges && !a->challenges))
+        return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_dev: missing column array");
+    // column pointer table
+    std::vector<const void*> cols(P.n_cols, nullptr);
+    for (uint32_t i = 0; i < P.n_fixed; i++) cols[P.col_fixed + i] = a->fixed[i];
+    for (uint32_t i = 0; i < P.n_advice; i++) cols[P.col_advice + i] = a->advice[i];
+    for (uint32_t i = 0; i < P.n_instance; i++) cols[P.col_instance + i] = a->instance[i];
+    cols[P.col_l0] = a->l0; cols[P.col_llast] = a->l_last; cols[P.col_lactive] = a->l_active_row;
+    for (uint32_t i = 0; i < P.n_perm_cols; i++) cols[P.col_sigma + i] = a->perm_cosets[i];
+    for (uint32_t i = 0; i < P.n_sets; i++) cols[P.col_z + i] = a->perm_products[i];
+    for (uint32_t i = 0; i < P.n_lookups; i++) {
+        cols[P.col_lk_z + i] = a->lookup_product[i]; cols[P.col_lk_a + i] = a->lookup_input[i]; cols[P.col_lk_s + i] = a->lookup_table[i];
+    }
+    for (auto p : cols) if (!p) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_dev: null column pointer");
+    // constants of this run
+    auto rd = [](const void* p) { u256 o; memcpy(&o, p, 32); return o; };
+    std::vector<u256> consts(P.n_consts);
+    for (size_t i = 0; i < P.graph_consts.size(); i++) consts[i] = P.graph_consts[i];
+    consts[P.c_zero] = Fr::zero(); consts[P.c_one] = Fr::one();
+    for (uint32_t i = 0; i < P.n_challenges; i++) consts[P.c_chal + i] = rd((const char*)a->challenges + 32 * i);
+    const u256 beta = rd(a->beta);
+    consts[P.c_beta] = beta; consts[P.c_gamma] = rd(a->gamma); consts[P.c_theta] = rd(a->theta); consts[P.c_y] = rd(a->y);
+    {   // delta_j = beta * ZETA * DELTA^j  (current_delta of evaluate_h without the omega^idx factor)
+        const uint64_t zl[4] = BN254_FR_ZETA_M, dl[4] = BN254_FR_DELTA_M;
+        u256 zeta, delta;
+        for (int i = 0; i < 8; i++) { zeta.v[i] = (uint32_t)(zl[i >> 1] >> (32 * (i & 1))); delta.v[i] = (uint32_t)(dl[i >> 1] >> (32 * (i & 1))); }
+        u256 cur = Fr::mul(beta, zeta);
+        for (uint32_t j = 0; j < P.n_perm_cols; j++) { consts[P.c_delta + j] = cur; cur = Fr::mul(cur, delta); }
+    }
+    const uint32_t size_log = P.ek;
+    const uint64_t size = 1ull << size_log;
+    const int64_t rot_scale = 1ll << (P.ek - P.k);
+    std::vector<uint32_t> rot_off(P.rotations.size() + 1, 0);
+    for (size_t i = 0; i < P.rotations.size(); i++) {
+        int64_t v = ((int64_t)P.rotations[i] * rot_scale) % (int64_t)size;
+        if (v < 0) v += (int64_t)size;
+        rot_off[i] = (uint32_t)v;
+    }
+    hipStream_t st = ctx->stream;
+    ZK_HIP(hipMemcpyAsync(P.d_consts, consts.data(), consts.size() * 32, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(P.d_cols, cols.data(), cols.size() * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(P.d_rot, rot_off.data(), rot_off.size() * 4, hipMemcpyHostToDevice, st));
+    QuotArgs q;
+    memset(&q, 0, sizeof q);
+    q.code = (const uint4*)P.d_code; q.n_instr = (uint32_t)P.code.size(); q.consts = P.d_consts;
+    q.cols = (const void* const*)P.d_cols; q.rot_off = (const uint32_t*)P.d_rot; q.size_log = size_log; q.out = a->out;
+    q.uses_xpow = P.uses_xpow ? 1 : 0;
+    if (P.uses_xpow) {
+        int rc = ntt_pow_tables(ctx, P.ek, domain_omega(P.ek), &q.tw_lo, &q.tw_hi, &q.lo_bits);
+        if (rc) return rc;
+    }
+    uint32_t T = (uint32_t)ctx->tune.quot_threads;
+    if (T > size) T = (uint32_t)size;
+    while (T > 64 && (size_t)P.n_slots * T * 32 > 64 * 1024) T >>= 1;
+    if (T < 1) T = 1;
+    const size_t lds = (size_t)P.n_slots * T * 32;
+    if (lds > 160 * 1024) return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %zu bytes of LDS", lds);
+    EvTimer tq(ctx, "quotient");
+    ZK_LAUNCH(quotient_kernel, (uint32_t)(size / T), T, lds, st, q);
+    ZK_CHECK_LAUNCH();
+    tq.stop();
+    ZK_HIP(hipStreamSynchronize(st));
+    tq.resolve();
+    return ZK_OK;
+}
+
+}  // namespace zk

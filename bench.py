@@ -1,0 +1,377 @@
+#!/usr/bin/env python3
+"""bench.py — proofs/hour of the sgx_dcap_verifier k=19 prover hot path on MI355X (BASELINE.json
+configs[1]) and, as extras, the BN254 MSM Mscalar/s at 2^24 (configs[2]) and batched NTT (configs[3]).
+
+A "step" is one pass of the GPU hot path of ONE proof over synthetic inputs already resident in HBM:
+the MSM / NTT / quotient call list of halo2 `create_proof` (SURVEY.md §3.1, §8d cfg 2) for the
+circuit shape A advice columns, L lookups, P permutation products, degree d:
+    (A + 3L + P + 1 + (d-1) + 2) MSMs of 2^k,  (A + 3L + P) iNTT(2^k),  (A + 3L + P) coeff->extended NTT(2^ek),
+    one evaluate_h pass over 2^ek rows, divide_by_vanishing, one extended->coeff iNTT(2^ek).
+Host work of create_proof (witness synthesis, lookup sorting, grand products, transcript) is NOT
+part of the step: the reference's Rust prover cannot be built here (no cargo, un-vendored crates),
+so the metric is the hot-path throughput and says so in `metric`.
+
+N > 1: one process per GPU, every rank proves its own stream of proofs (weak scaling, no data-path
+collective); the MSM-sharded path (base table split over ranks, 128-byte partial points all-gathered
+over RCCL) is timed separately and reported under "extra".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def rand_fr(n, seed):
+    """n values < 2^253 < r as (n, 4) uint64 — used directly as Montgomery-form field elements."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 61) - 1)
+    return a
+
+
+def witness_like(n, seed):
+    """90 % zeros, 8 % bytes, 2 % uniform (SURVEY.md 8d cfg 2), canonical small values in Montgomery
+    form would need a field multiplication; for the bucket distribution it is enough that the
+    *canonical* value is small, so build canonical values and convert with the known R on the GPU side
+    is unnecessary: zeros stay zeros; for the rest we place small canonical values * R mod r."""
+    rng = np.random.default_rng(seed)
+    u = rng.random(n)
+    vals = np.zeros((n, 4), dtype=np.uint64)
+    small = np.nonzero((u >= 0.9) & (u < 0.98))[0]
+    Rm = (1 << 256) % R_MOD
+    table = np.array([[(b * Rm % R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for b in range(256)], dtype=np.uint64)
+    vals[small] = table[rng.integers(0, 256, size=small.size)]
+    big = np.nonzero(u >= 0.98)[0]
+    vals[big] = rand_fr(big.size, seed + 1)
+    return vals
+
+
+def sgx_shaped_program(z, k, ek, A, F, L, n_perm, d):
+    """Synthetic proving-key program with the census of the sgx circuit:
+    degree-3 gates q*(a + b*c - d) on the Fp-chip columns, 4-5 expression lookups compressed with theta."""
+    ev = z.evaluation
+    one = np.array([(((1 << 256) % R_MOD) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    g = ev.Graph()
+    g.add_constant(one)
+    r = [g.add_rotation(x) for x in (0, 1, 2, 3)]
+    gates = []
+    for i in range(min(A, 24)):
+        a, b, c, dd = (ev.vs(ev.ADVICE, i, r[j]) for j in range(4))
+        t = g.add_calculation(ev.MUL, b, c)
+        t = g.add_calculation(ev.ADD, a, t)
+        t = g.add_calculation(ev.SUB, t, dd)
+        gates.append(g.add_calculation(ev.MUL, ev.vs(ev.FIXED, i % F, r[0]), t))
+    g.add_calculation(ev.HORNER, ev.vs(ev.PREVIOUS), gates, ev.vs(ev.Y))
+    lookups = []
+    for n in range(L):
+        lg = ev.Graph()
+        r0 = lg.add_rotation(0)
+        m = 4 if n % 2 == 0 else 5
+        sel = ev.vs(ev.FIXED, n % F, r0)
+        ins = [lg.add_calculation(ev.MUL, sel, ev.vs(ev.ADVICE, (n + j) % A, r0)) for j in range(m)]
+        ci = lg.add_calculation(ev.HORNER, ins[0], ins[1:], ev.vs(ev.THETA))
+        ct = lg.add_calculation(ev.HORNER, ev.vs(ev.FIXED, (n + 1) % F, r0), [ev.vs(ev.FIXED, (n + 1 + j) % F, r0) for j in range(1, m)], ev.vs(ev.THETA))
+        a1 = lg.add_calculation(ev.ADD, ci, ev.vs(ev.BETA))
+        b1 = lg.add_calculation(ev.ADD, ct, ev.vs(ev.GAMMA))
+        lg.add_calculation(ev.MUL, a1, b1)
+        lookups.append(lg)
+    return ev.Program(k=k, extended_k=ek, n_fixed=F, n_advice=A, n_instance=0, n_challenges=0, blinding_factors=5, cs_degree=d,
+                      perm_columns=[(0, i % A) for i in range(n_perm)], custom_gates=g, lookups=lookups)
+
+
+class ProofWorkload:
+    def __init__(self, z, be, k, A, F, L, n_perm, d):
+        self.z, self.be, self.k, self.A, self.F, self.L, self.d = z, be, k, A, F, L, d
+        self.n = 1 << k
+        ek = k
+        while (1 << ek) < self.n * (d - 1):
+            ek += 1
+        self.ek, self.en = ek, 1 << ek
+        chunk = d - 2
+        self.P = (n_perm + chunk - 1) // chunk
+        self.n_perm = n_perm
+        n = self.n
+        # SRS-shaped base tables: g, g_lagrange = n points with random discrete logs (fixed-base mul on GPU)
+        self.tables = []
+        for seed in (20241008, 20241009):
+            ks = be.to_device(rand_fr(n, seed))
+            pts = be.alloc(n * 64)
+            be.g1_fixed_base_mul(ks, n, pts)
+            self.tables.append(be.bases_register((pts, n)))
+            ks.free()
+            pts.free()
+        self.g, self.g_lagrange = self.tables
+        # resident columns (Lagrange form): half uniform, half witness-like sparse
+        ncol = A + 3 * L + self.P
+        self.cols = [be.to_device(rand_fr(n, 100 + i) if i % 2 == 0 else witness_like(n, 100 + i)) for i in range(ncol)]
+        self.work = [be.alloc(n * 32) for _ in range(ncol)]            # per-proof copies that the iNTT overwrites
+        self.hpoly = be.to_device(rand_fr(n, 7))
+        # extended cosets: advice + perm z + 3 per lookup are produced per proof; fixed / sigma / l* are pk data
+        self.ext_dyn = [be.alloc(self.en * 32) for _ in range(ncol)]
+        # proving-key cosets: distinct HBM buffers (no aliasing, so cache reuse is not flattered),
+        # filled on the GPU from one uploaded random column scaled by distinct constants
+        seed_col = be.to_device(rand_fr(self.en, 300))
+        mults = rand_fr(F + n_perm + 3, 301)
+
+        def derived(i):
+            b = be.alloc(self.en * 32)
+            be.fr_scale_dev(seed_col, mults[i], b, self.en)
+            return b
+        self.ext_fixed = [derived(i) for i in range(F)]
+        self.ext_sigma = [derived(F + i) for i in range(n_perm)]
+        self.ext_l = [derived(F + n_perm + i) for i in range(3)]
+        seed_col.free()
+        self.h_ext = be.alloc(self.en * 32)
+        self.prog = sgx_shaped_program(z, k, ek, A, F, L, n_perm, d)
+        self.evaluator = z.evaluation.Evaluator(self.prog, backend=be)
+        self.scal = rand_fr(4, 9)
+        self.n_msm = A + 3 * L + self.P + 1 + (d - 1) + 2
+        self.n_intt = ncol
+        self.n_ext = ncol
+
+    def step(self):
+        be, n, k, ek = self.be, self.n, self.k, self.ek
+        A, L, P = self.A, self.L, self.P
+        lib, ctx = be.lib, be.ctx
+        # phases 2-5: commitments in Lagrange basis
+        for c in self.cols:
+            be.msm(self.g_lagrange, c, n)
+        be.msm(self.g, self.hpoly, n)                                   # vanishing random poly
+        # phase 6: lagrange -> coeff -> extended coset
+        for c, w, e in zip(self.cols, self.work, self.ext_dyn):
+            be.fr_scale_dev(c, self.scal[0], w, n)                      # per-proof copy (blinding changes every proof)
+            be.lagrange_to_coeff_dev(w, k)
+            be.coeff_to_extended_dev(w, k, ek, e)
+        adv = self.ext_dyn[:A]
+        zs = self.ext_dyn[A:A + P]
+        lk = self.ext_dyn[A + P:]
+        self.evaluator.evaluate_h(fixed=self.ext_fixed, advice=adv, instance=[], l0=self.ext_l[0], l_last=self.ext_l[1], l_active_row=self.ext_l[2],
+                                  perm_cosets=self.ext_sigma, perm_products=zs, lookup_product=lk[0:L], lookup_input=lk[L:2 * L],
+                                  lookup_table=lk[2 * L:3 * L], challenges=[], beta=self.scal[0], gamma=self.scal[1], theta=self.scal[2],
+                                  y=self.scal[3], out=self.h_ext)
+        # phase 7: h = numerator / (X^n - 1), back to coefficients, commit the d-1 pieces
+        be.divide_by_vanishing_poly_dev(self.h_ext, k, ek)
+        be.extended_to_coeff_dev(self.h_ext, k, ek)
+        for i in range(self.d - 1):
+            be.msm(self.g, self.h_ext.ptr + i * n * 32, n)
+        # phase 9: SHPLONK h(X) and linearisation commitments
+        be.msm(self.g, self.work[0], n)
+        be.msm(self.g, self.work[1], n)
+
+
+def cpu_baseline(cfg, threads):
+    """Oracle ("port": C restatement of halo2's CPU algorithms, oracle/bn254_oracle.c) timed on a bounded
+    sample of the same op-mix and extrapolated to one proof.  Checker code, never the thing shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    k, ek = cfg["k"], cfg["ek"]
+    n = 1 << k
+    sc = rand_fr(n, 1)
+    bases = orc.gen_bases_arith(5, 3, n, threads=threads)
+    t = time.time(); orc.best_multiexp(sc, bases, threads=threads); t_msm = time.time() - t
+    w = orc.Domain(cfg["d"], k)
+    t = time.time(); w.lagrange_to_coeff(sc, threads=threads); t_intt = time.time() - t
+    t = time.time(); w.coeff_to_extended(sc, threads=threads); t_ext = time.time() - t
+    # quotient on 2^14 rows of the same program shape, scaled by rows
+    import zk_dcap_verifier_amd as z
+    ks = 12
+    prog = sgx_shaped_program(z, ks, ks + (ek - k), cfg["A"], cfg["F"], cfg["L"], cfg["n_perm"], cfg["d"])
+    size = 1 << (ks + ek - k)
+    col = rand_fr(size, 3)
+    P = (cfg["n_perm"] + cfg["d"] - 3) // (cfg["d"] - 2)
+    t = time.time()
+    orc.evaluate_h(prog.to_blob(), [col] * cfg["F"], [col] * cfg["A"], [], col, col, col, [col] * cfg["n_perm"], [col] * P, [col] * cfg["L"], [col] * cfg["L"],
+                   [col] * cfg["L"], [], col[0], col[1], col[2], col[3], size, threads=threads)
+    t_q = (time.time() - t) * ((1 << ek) / size)
+    total = cfg["n_msm"] * t_msm + cfg["n_intt"] * t_intt + (cfg["n_ext"] + 1) * t_ext + t_q
+    return {"value": round(3600.0 / total, 3), "unit": "proofs/hour", "cores": threads, "kind": "port",
+            "sample": f"1 best_multiexp(2^{k}) {t_msm:.2f}s x{cfg['n_msm']}, 1 lagrange_to_coeff {t_intt:.3f}s x{cfg['n_intt']}, "
+                      f"1 coeff_to_extended(2^{ek}) {t_ext:.3f}s x{cfg['n_ext'] + 1}, evaluate_h on 2^{ks + ek - k} rows scaled to 2^{ek} = {t_q:.2f}s; "
+                      "C restatement of halo2 CPU algorithms (pthreads), not the Rust binary"}
+
+
+def msm_microbench(be, log_n, seed, reps=3):
+    n = 1 << log_n
+    ks = be.to_device(rand_fr(n, seed))
+    pts = be.alloc(n * 64)
+    be.g1_fixed_base_mul(ks, n, pts)
+    t = time.time(); h = be.bases_register((pts, n)); t_reg = time.time() - t
+    pts.free()
+    sc = rand_fr(n, seed + 1)
+    ks.upload(sc)
+    be.msm(h, ks, n)
+    t = time.time()
+    for _ in range(reps):
+        be.msm(h, ks, n)
+    dt = (time.time() - t) / reps
+    be.bases_release(h)
+    ks.free()
+    return {"log_n": log_n, "ms": round(dt * 1e3, 3), "Mscalar_per_s": round(n / dt / 1e6, 2), "hbm_frac_algorithmic": round(96 * n / dt / 1e9 / HBM_PEAK_GBS, 5),
+            "table_expand_s": round(t_reg, 3)}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--k", type=int, default=19)
+    ap.add_argument("--advice", type=int, default=25)
+    ap.add_argument("--fixed", type=int, default=18)
+    ap.add_argument("--lookups", type=int, default=11)
+    ap.add_argument("--perm-columns", type=int, default=16)
+    ap.add_argument("--degree", type=int, default=5)
+    ap.add_argument("--no-extras", action="store_true", help="skip the MSM 2^24 / NTT 2^22 microbenchmarks and the CPU baseline")
+    args = ap.parse_args(argv)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import zk_dcap_verifier_amd as z
+    be = z.Backend(local)                      # raises if the HIP library / GPU is missing: no CPU path
+    assert "gfx950" in be.version() or os.environ.get("ZK_BENCH_PLUMBING_TEST") == "1"
+
+    wl = ProofWorkload(z, be, args.k, args.advice, args.fixed, args.lookups, args.perm_columns, args.degree)
+
+    def barrier():
+        be.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    be.timing(True)                            # HIP events on the library's stream, inside the timed region
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    dt = time.time() - t0
+    acc_ms, acc_n = be.timing_get("msm_accumulate")
+    sort_ms, _ = be.timing_get("msm_sort")
+    red_ms, _ = be.timing_get("msm_reduce")
+    q_ms, q_n = be.timing_get("quotient")
+    be.timing(False)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    proofs_per_hour = world * 3600.0 / (dt / args.steps)
+
+    extra = {"ops_per_proof": {"msm": wl.n_msm, "intt_2^k": wl.n_intt, "ntt_2^ek": wl.n_ext + 1, "quotient_rows": wl.en},
+             "kernel_ms_per_proof": {"msm_sort": round(sort_ms / args.steps, 3), "msm_accumulate": round(acc_ms / args.steps, 3),
+                                     "msm_reduce": round(red_ms / args.steps, 3), "quotient": round(q_ms / args.steps, 3) if q_ms else None}}
+    # roofline of the dominant kernel (msm_accumulate): algorithmic bytes = 96 B per (scalar, base) pair x 2^k per launch
+    avg_launch_s = max(acc_ms / max(acc_n, 1) * 1e-3, 1e-9)   # (the CPU plumbing test has no event timing)
+    achieved = 96.0 * wl.n / avg_launch_s / 1e9
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        try:
+            traffic = json.load(open(tj)).get("msm_accumulate_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "msm_accumulate_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": acc_n,
+                "note": "integer-ALU bound (v_mad_u64_u32), see DESIGN.md: int_alu_frac is the meaningful fraction",
+                "int_alu_frac": round((wl.n * (254 // 16 + 1) / avg_launch_s) / 9.35e9, 4)}
+
+    cfg = {"k": args.k, "ek": wl.ek, "A": args.advice, "F": args.fixed, "L": args.lookups, "n_perm": args.perm_columns, "d": args.degree,
+           "n_msm": wl.n_msm, "n_intt": wl.n_intt, "n_ext": wl.n_ext}
+    cpu = None
+    if rank == 0 and not args.no_extras:
+        if world == 1:
+            try:
+                cpu = cpu_baseline(cfg, os.cpu_count() or 1)
+            except Exception as e:  # the baseline is a report, never a dependency of the measurement
+                cpu = {"error": str(e)}
+            try:
+                extra["msm_2^20"] = msm_microbench(be, 20, 20241008)
+                extra["msm_2^24"] = msm_microbench(be, 24, 20241010, reps=2)
+            except Exception as e:
+                extra["msm_microbench_error"] = str(e)
+            try:
+                n22 = 1 << 22
+                cols = 25
+                buf = be.to_device(rand_fr(n22, 20241011))
+                w22 = np.array([((pow(7, (R_MOD - 1) >> 22, R_MOD) << 256) % R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+                be.ntt_dev(buf, 22, w22)
+                t = time.time()
+                for _ in range(cols):
+                    be.ntt_dev(buf, 22, w22)
+                d22 = time.time() - t
+                extra["ntt_2^22_x25"] = {"ms_per_column": round(d22 / cols * 1e3, 3), "GB_per_s_algorithmic": round(64 * n22 * cols / d22 / 1e9, 1),
+                                         "hbm_frac": round(64 * n22 * cols / d22 / 1e9 / HBM_PEAK_GBS, 4)}
+                buf.free()
+            except Exception as e:
+                extra["ntt_microbench_error"] = str(e)
+    if world > 1 and not args.no_extras:
+        # MSM with the base table sharded over the ranks: partial XYZZ points all-gathered over RCCL/xGMI
+        try:
+            logn = 24
+            n_loc = (1 << logn) // world
+            ks = be.to_device(rand_fr(n_loc, 31 + rank))
+            pts = be.alloc(n_loc * 64)
+            be.g1_fixed_base_mul(ks, n_loc, pts)
+            h = be.bases_register((pts, n_loc))
+            pts.free()
+            ks.upload(rand_fr(n_loc, 77 + rank))
+            gather = [torch.zeros(16, dtype=torch.int64, device="cuda") for _ in range(world)]
+
+            def sharded():
+                part = be.msm_partial(h, ks, n_loc)
+                mine = torch.from_numpy(part.view(np.int64)).cuda()
+                dist.all_gather(gather, mine)
+                parts = torch.stack(gather).cpu().numpy().view(np.uint64)
+                return be.g1_sum_xyzz(parts)
+            sharded()
+            barrier()
+            t = time.time()
+            for _ in range(3):
+                sharded()
+            barrier()
+            ds = (time.time() - t) / 3
+            extra["msm_sharded_2^24"] = {"ranks": world, "ms": round(ds * 1e3, 3), "Mscalar_per_s": round((1 << logn) / ds / 1e6, 2)}
+            be.bases_release(h)
+            ks.free()
+        except Exception as e:
+            extra["msm_sharded_error"] = str(e)
+
+    if rank == 0:
+        line = {"metric": "proofs/hour sgx_dcap_verifier k=19 (GPU hot path: MSM+NTT+quotient op-mix of create_proof; host witness/transcript excluded)",
+                "value": round(proofs_per_hour, 2), "unit": "proofs/hour", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (256-bit Montgomery integers)",
+                "data": "synthetic",
+                "config": {"workload": f"sgx_dcap_verifier QE3-report circuit shape, k={args.k}, extended_k={wl.ek}, A={args.advice} advice, F={args.fixed} fixed, "
+                                       f"L={args.lookups} lookups, {args.perm_columns} permutation columns (P={wl.P}), degree {args.degree}; "
+                                       f"{wl.n_msm} MSM(2^{args.k}) + {wl.n_intt} iNTT + {wl.n_ext + 1} NTT(2^{wl.ek}) + evaluate_h per proof; columns half uniform, half witness-like sparse",
+                           "parallelism": f"{world} x independent proofs (one process per GPU)"},
+                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    be.close()
+
+
+if __name__ == "__main__":
+    main()

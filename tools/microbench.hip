@@ -10,7 +10,7 @@ using namespace zk;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-constexpr int ITER = 512;
+constexpr int ITER = 8192;
 
 __global__ void k_mad64(uint32_t* out, uint32_t seed) {
     uint32_t a = threadIdx.x + seed, b = blockIdx.x * 3 + 7;

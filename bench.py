@@ -142,10 +142,14 @@ class ProofWorkload:
         be, n, k, ek = self.be, self.n, self.k, self.ek
         A, L, P = self.A, self.L, self.P
         lib, ctx = be.lib, be.ctx
-        # phases 2-5: commitments in Lagrange basis
-        for c in self.cols:
-            be.msm(self.g_lagrange, c, n)
-        be.msm(self.g, self.hpoly, n)                                   # vanishing random poly
+        # commitments, batched per proof phase exactly where create_proof's transcript allows it
+        # (all columns of a phase are committed before the next challenge is squeezed):
+        nA, nP, nL = self.A, self.P, self.L
+        adv, zs, lk = self.cols[:nA], self.cols[nA:nA + nP], self.cols[nA + nP:]
+        be.msm_batch(self.g_lagrange, adv, n)                           # phase 2: advice columns
+        be.msm_batch(self.g_lagrange, lk[nL:3 * nL], n)                 # phase 3: permuted input / table of every lookup
+        be.msm_batch(self.g_lagrange, zs + lk[:nL], n)                  # phase 4: permutation and lookup grand products
+        be.msm(self.g, self.hpoly, n)                                   # phase 5: vanishing argument's random poly
         # phase 6: lagrange -> coeff -> extended coset
         for c, w, e in zip(self.cols, self.work, self.ext_dyn):
             be.fr_scale_dev(c, self.scal[0], w, n)                      # per-proof copy (blinding changes every proof)
@@ -161,8 +165,7 @@ class ProofWorkload:
         # phase 7: h = numerator / (X^n - 1), back to coefficients, commit the d-1 pieces
         be.divide_by_vanishing_poly_dev(self.h_ext, k, ek)
         be.extended_to_coeff_dev(self.h_ext, k, ek)
-        for i in range(self.d - 1):
-            be.msm(self.g, self.h_ext.ptr + i * n * 32, n)
+        be.msm_batch(self.g, [self.h_ext.ptr + i * n * 32 for i in range(self.d - 1)], n)
         # phase 9: SHPLONK h(X) and linearisation commitments
         be.msm(self.g, self.work[0], n)
         be.msm(self.g, self.work[1], n)

@@ -75,6 +75,12 @@ int zk_bases_release(zk_ctx* ctx, uint64_t handle);
  * halo2curves G1 value.  n may be smaller than the registered table (prefix is used). */
 int zk_msm(zk_ctx* ctx, uint64_t bases, const void* scalars_host, size_t n, void* out_jacobian);
 int zk_msm_dev(zk_ctx* ctx, uint64_t bases, const void* scalars_dev, size_t n, void* out_jacobian);
+/* `count` MSMs of n scalars each against the SAME table in one call (e.g. all advice columns of
+ * a proof phase: the loop `for col in advice { params.commit_lagrange(col) }` of halo2_proofs
+ * src/plonk/prover.rs).  scalars: HOST array of `count` column pointers (host / device memory);
+ * out_jacobian: count x 96 B.  The latency-bound bucket-reduction phases are shared by the batch. */
+int zk_msm_batch(zk_ctx* ctx, uint64_t bases, const void* const* scalars_host, size_t count, size_t n, void* out_jacobian);
+int zk_msm_batch_dev(zk_ctx* ctx, uint64_t bases, const void* const* scalars_dev, size_t count, size_t n, void* out_jacobian);
 /* unnormalised partial result as 128 B XYZZ (X, Y, ZZ, ZZZ) for multi-GPU sharding: partial
  * results of the ranks are exchanged (RCCL all-gather) and combined with zk_g1_sum_xyzz. */
 int zk_msm_partial_dev(zk_ctx* ctx, uint64_t bases, const void* scalars_dev, size_t n, void* out_xyzz_host);
@@ -137,6 +143,8 @@ typedef struct zk_quotient_args {
 } zk_quotient_args;
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog);
+/* size of the compiled micro-program: instructions, live-value slots (first 6 are registers, rest LDS), columns */
+int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
 int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args);
 
 /* library / build identification */

@@ -86,6 +86,32 @@ def check_msm_prefix_and_handle(be, orc, pyref, n, seed=31):
     h.release()
 
 
+def check_msm_batch(be, orc, pyref, n, count, seed=35, device=False):
+    """zk_msm_batch: several columns (uniform, sparse, all ones, zeros ...) against one table."""
+    kinds = ["uniform", "witness", "ones", "zeros", "minus_one"]
+    cols, bases = [], None
+    for i in range(count):
+        sc, b = msm_inputs(orc, pyref, n, seed, kinds[i % len(kinds)] if i else "uniform")
+        if i % len(kinds) == 0:
+            sc = rand_fr(orc, pyref, n, seed + 13 * i)
+        bases = b
+        cols.append(sc)
+    h = z.arithmetic.BasesHandle(be, bases)
+    if device:
+        dcols = [be.to_device(c) for c in cols]
+        got = be.msm_batch(h.handle, dcols, n)
+        for d in dcols:
+            d.free()
+    else:
+        got = z.arithmetic.best_multiexp_batch(cols, h)
+    for i, sc in enumerate(cols):
+        want = orc.g1_to_affine(orc.best_multiexp(sc, bases))[0]
+        assert (got[i, :8] == want).all(), i
+        single = z.arithmetic.best_multiexp(sc, h)
+        assert (single == got[i]).all(), i
+    h.release()
+
+
 def check_ntt(be, orc, pyref, log_n, seed=41):
     n = 1 << log_n
     a = rand_fr(orc, pyref, n, seed)

@@ -51,6 +51,11 @@ def test_msm_prefix_of_resident_table(emu, orc, pyref):
     pc.check_msm_prefix_and_handle(emu, orc, pyref, 90)
 
 
+def test_msm_batch(emu, orc, pyref):
+    pc.check_msm_batch(emu, orc, pyref, 120, 6)
+    pc.check_msm_batch(emu, orc, pyref, 50, 2, seed=3, device=True)
+
+
 def test_fixed_base_mul(emu, orc, pyref):
     pc.check_fixed_base(emu, orc, pyref, 40)
 

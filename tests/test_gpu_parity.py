@@ -65,6 +65,11 @@ def test_msm_prefix_of_resident_table(gpu, orc, pyref):
     pc.check_msm_prefix_and_handle(gpu, orc, pyref, 3000)
 
 
+@pytest.mark.parametrize("n,count,device", [(3000, 7, False), (20000, 25, True), (1, 3, False)])
+def test_msm_batch(gpu, orc, pyref, n, count, device):
+    pc.check_msm_batch(gpu, orc, pyref, n, count, device=device)
+
+
 def test_fixed_base_mul(gpu, orc, pyref):
     pc.check_fixed_base(gpu, orc, pyref, 5000)
 

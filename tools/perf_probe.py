@@ -47,6 +47,19 @@ def main():
                     for _ in range(3): be.msm(h, ds, n)
                     print(json.dumps({"sweep": key, "value": v, "ms": round((time.time() - t) / 3 * 1e3, 3)}), flush=True)
                 be.tune(**{key: old})
+        if lg == 19:
+            cols = [be.to_device(rand_fr(n, 10 + i)) for i in range(25)]
+            for nb in (1, 4, 8, 25):
+                be.msm_batch(h, cols[:nb], n)
+                be.timing(True)
+                t = time.time()
+                for _ in range(3): be.msm_batch(h, cols[:nb], n)
+                dt = (time.time() - t) / 3
+                lab = {k: be.timing_get(k) for k in ("msm_sort", "msm_accumulate", "msm_reduce")}
+                be.timing(False)
+                print(json.dumps({"msm_batch": nb, "ms_total": round(dt * 1e3, 3), "ms_per_msm": round(dt * 1e3 / nb, 3),
+                                  "kernels_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in lab.items() if v[0] is not None}}), flush=True)
+            for c_ in cols: c_.free()
         be.bases_release(h); dk.free(); dp.free(); ds.free()
     for lg in [int(x) for x in os.environ.get("NTT_LOGS", "16,19,21,22").split(",")]:
         n = 1 << lg

@@ -172,6 +172,24 @@ class Backend:
             self._ck(self.lib.zk_msm_dev(self.ctx, C.c_uint64(handle), C.c_void_p(_dptr(scalars)), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def msm_batch(self, handle: int, columns, n: int | None = None) -> np.ndarray:
+        """columns: list of host (n, 4) arrays or of device buffers -> (count, 12) normalised G1."""
+        count = len(columns)
+        out = np.zeros((count, 12), dtype=np.uint64)
+        if count == 0:
+            return out
+        if isinstance(columns[0], np.ndarray):
+            cols = [np.ascontiguousarray(c, dtype=np.uint64).reshape(-1, 4) for c in columns]
+            n = cols[0].shape[0] if n is None else n
+            assert all(c.shape[0] >= n for c in cols)
+            arr = (C.c_void_p * count)(*[c.ctypes.data for c in cols])
+            self._ck(self.lib.zk_msm_batch(self.ctx, C.c_uint64(handle), arr, C.c_size_t(count), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
+        else:
+            assert n is not None
+            arr = (C.c_void_p * count)(*[_dptr(c) for c in columns])
+            self._ck(self.lib.zk_msm_batch_dev(self.ctx, C.c_uint64(handle), arr, C.c_size_t(count), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def msm_partial(self, handle: int, scalars_dev, n: int) -> np.ndarray:
         out = np.zeros(16, dtype=np.uint64)
         self._ck(self.lib.zk_msm_partial_dev(self.ctx, C.c_uint64(handle), C.c_void_p(_dptr(scalars_dev)), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
@@ -234,6 +252,11 @@ class Backend:
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
         self._ck(self.lib.zk_quotient_program_load(self.ctx, buf, C.c_size_t(len(blob)), C.byref(h)))
         return h.value
+
+    def quotient_program_info(self, prog: int) -> dict:
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self.lib.zk_quotient_program_info(self.ctx, C.c_uint64(prog), C.byref(a), C.byref(b), C.byref(c)))
+        return {"instructions": a.value, "slots": b.value, "columns": c.value}
 
     def quotient_program_release(self, prog: int):
         self._ck(self.lib.zk_quotient_program_release(self.ctx, C.c_uint64(prog)))

@@ -60,3 +60,12 @@ def best_fft(a: np.ndarray, omega, log_n: int, backend: Backend | None = None) -
     be = backend or default_backend()
     assert a.shape[0] == 1 << log_n, "best_fft: a.len() != 1 << log_n"
     be.ntt(a, log_n, omega)
+
+
+def best_multiexp_batch(columns, bases: BasesHandle) -> np.ndarray:
+    """[best_multiexp(col, bases) for col in columns] in one device call (count, 12).
+
+    halo2 commits the columns of a proof phase in a loop (src/plonk/prover.rs); the results are
+    independent, so the shim hands the whole phase to the GPU at once and the latency-bound bucket
+    reduction is paid once per phase instead of once per column."""
+    return bases.backend.msm_batch(bases.handle, list(columns))

@@ -14,6 +14,7 @@ int domain_divide_by_vanishing(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek);
 int fr_vec_op(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n, const u256* scalar);
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
+int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
 int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args);
 }  // namespace zk
 using namespace zk;
@@ -124,6 +125,8 @@ int zk_bases_register_dev(zk_ctx* ctx, const void* p, size_t n, uint64_t* h) { E
 int zk_bases_release(zk_ctx* ctx, uint64_t h) { ENTER; return msm_release(ctx, h); }
 int zk_msm(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { ENTER; return msm_run(ctx, b, s, n, false, out, 0); }
 int zk_msm_dev(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { ENTER; return msm_run(ctx, b, s, n, true, out, 0); }
+int zk_msm_batch(zk_ctx* ctx, uint64_t b, const void* const* s, size_t count, size_t n, void* out) { ENTER; return msm_run_batch(ctx, b, s, count, n, false, out, 0); }
+int zk_msm_batch_dev(zk_ctx* ctx, uint64_t b, const void* const* s, size_t count, size_t n, void* out) { ENTER; return msm_run_batch(ctx, b, s, count, n, true, out, 0); }
 int zk_msm_partial_dev(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { ENTER; return msm_run(ctx, b, s, n, true, out, 1); }
 int zk_g1_sum_xyzz(const void* xyzz, size_t count, void* out) { if (!xyzz || !out) return ZK_ERR_ARG; return g1_sum_xyzz_host(xyzz, count, out); }
 int zk_g1_fixed_base_mul_dev(zk_ctx* ctx, const void* s, size_t n, void* out) { ENTER; return g1_fixed_base_mul(ctx, s, n, out); }
@@ -199,6 +202,7 @@ int zk_fq_mul_dev(zk_ctx* ctx, const void* a, const void* b, void* o, size_t n) 
 
 // ---- quotient -----------------------------------------------------------------------------------
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog) { ENTER; return quotient_program_load(ctx, blob, len, prog); }
+int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* ni, uint32_t* ns, uint32_t* nc) { ENTER; return quotient_program_info(ctx, prog, ni, ns, nc); }
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog) { ENTER; return quotient_program_release(ctx, prog); }
 int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args); }
 

@@ -121,6 +121,7 @@ struct EvTimer {
 int msm_register(zk_ctx* ctx, const void* pts, size_t n, bool on_device, uint64_t* handle);
 int msm_release(zk_ctx* ctx, uint64_t handle);
 int msm_run(zk_ctx* ctx, uint64_t handle, const void* scalars, size_t n, bool on_device, void* out, int partial);
+int msm_run_batch(zk_ctx* ctx, uint64_t handle, const void* const* scalars, size_t nb, size_t n, bool on_device, void* out, int partial);
 int g1_sum_xyzz_host(const void* xyzz, size_t count, void* out_jac);
 int g1_fixed_base_mul(zk_ctx* ctx, const void* d_scalars, size_t n, void* d_out_affine);
 void release_gtab(zk_ctx* ctx);

@@ -62,93 +62,137 @@ ZK_HD uint32_t find_segment(const uint32_t* arr, uint32_t B, uint32_t j) {
 ZK_HD uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------------------------------------
+// launch plan shared by the kernels of one (batched) MSM call.  blockIdx.y = column of the batch.
+// ------------------------------------------------------------------------------------------------
+constexpr int MSM_MAX_LEVELS = 8;
+struct MsmPlan {
+    uint32_t n, n_table, B, L, M, R, nb;   // R = merge levels above level 0
+    int c, W;
+    const void* const* scalars;            // device array: nb column pointers
+    const void* table;
+    uint32_t* small;                       // per column: hist[B] off[B+1] cursor[B] suboff[R+1][B+1] info[4]
+    uint32_t small_stride, o_off, o_cursor, o_suboff, o_info;
+    uint32_t* sorted;                      // per column: pairs_max references
+    uint64_t sorted_stride;
+    void* sub[2];                          // level r lives in sub[r & 1]
+    uint64_t sub_stride[2];                // entries per column
+    void* cls[2];
+    uint32_t groups0;                      // entries per class after the first class kernel
+};
+ZK_HD uint32_t* plan_small(const MsmPlan& p, uint32_t col) { return p.small + (size_t)col * p.small_stride; }
+ZK_HD const uint32_t* plan_suboff(const MsmPlan& p, uint32_t col, uint32_t level) { return plan_small(p, col) + p.o_suboff + (size_t)level * (p.B + 1); }
+ZK_HD uint32_t plan_eff_levels(const MsmPlan& p, uint32_t max_s) {  // merge rounds that actually run
+    uint32_t pw = 1, r = 0;
+    while (pw < max_s && r < p.R) { pw *= p.M; r++; }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // counting sort of (scalar, window) pairs by bucket — histogram in LDS
 // ------------------------------------------------------------------------------------------------
-ZK_KERNEL void msm_hist_kernel(const void* scalars, uint32_t n, int c, int W, uint32_t* ghist) {
+ZK_KERNEL void msm_hist_kernel(MsmPlan p) {
     ZK_DYN_SHARED(uint32_t, lh);
-    const uint32_t B = 1u << (c - 1);
+    const uint32_t B = p.B, col = blockIdx.y;
+    const void* scalars = p.scalars[col];
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lh[b] = 0;
     __syncthreads();
-    const uint32_t chunk = ceil_div(n, gridDim.x);
+    const uint32_t chunk = ceil_div(p.n, gridDim.x);
     const uint32_t lo = blockIdx.x * chunk;
-    const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t hi = lo + chunk < p.n ? lo + chunk : p.n;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         u256 s = Fr::from_mont(load_u256(scalars, i));
-        for_each_digit(s, c, W, [&](int, uint32_t mag, bool) { atomicAdd(&lh[mag - 1], 1u); });
+        for_each_digit(s, p.c, p.W, [&](int, uint32_t mag, bool) { atomicAdd(&lh[mag - 1], 1u); });
     }
     __syncthreads();
+    uint32_t* ghist = plan_small(p, col);
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
         uint32_t v = lh[b];
         if (v) atomicAdd(&ghist[b], v);
     }
 }
 
-// single workgroup: exclusive scans of the bucket sizes and of the sub-bucket counts
-//   off[b]    = first sorted slot of bucket b            (off[B] = number of pairs)
-//   suboff[b] = first sub-bucket of bucket b             (suboff[B] = number of sub-buckets)
-//   info[0]   = max sub-buckets of any bucket, info[1] = number of sub-buckets
-ZK_KERNEL void msm_scan_kernel(const uint32_t* hist, uint32_t B, uint32_t L, uint32_t* off, uint32_t* cursor,
-                               uint32_t* suboff, uint32_t* info) {
-    __shared__ uint32_t sa[1024], sb[1024];
+// one workgroup per column: exclusive scans of the bucket sizes and of the entry counts of every
+// merge level (level 0 = sub-buckets of <= L pairs, level r = ceil(level r-1 / M)).
+//   off[b] = first sorted slot of bucket b, suboff[r][b] = first level-r entry of bucket b
+//   info[0] = max level-0 entries of any bucket
+ZK_KERNEL void msm_scan_kernel(MsmPlan p) {
+    __shared__ uint32_t sc[(MSM_MAX_LEVELS + 2) * 1024];
     __shared__ uint32_t smax;
-    const uint32_t T = blockDim.x, tid = threadIdx.x;
+    const uint32_t T = blockDim.x, tid = threadIdx.x, B = p.B, NV = p.R + 2;   // pairs + (R+1) levels
+    uint32_t* sm = plan_small(p, blockIdx.x);
+    const uint32_t* hist = sm;
     const uint32_t ipt = ceil_div(B, T);
     const uint32_t lo = tid * ipt < B ? tid * ipt : B;
     const uint32_t hi = lo + ipt < B ? lo + ipt : B;
-    uint32_t a = 0, s = 0, mx = 0;
+    uint32_t sum[MSM_MAX_LEVELS + 2];
+    for (uint32_t v = 0; v < NV; v++) sum[v] = 0;
+    uint32_t mx = 0;
     for (uint32_t b = lo; b < hi; b++) {
-        uint32_t cnt = hist[b], sbk = ceil_div(cnt, L);
-        a += cnt; s += sbk; mx = sbk > mx ? sbk : mx;
+        uint32_t cnt = hist[b];
+        sum[0] += cnt;
+        uint32_t e = ceil_div(cnt, p.L);
+        mx = e > mx ? e : mx;
+        for (uint32_t r = 0; r <= p.R; r++) { sum[1 + r] += e; e = ceil_div(e, p.M); }
     }
-    sa[tid] = a; sb[tid] = s;
+    for (uint32_t v = 0; v < NV; v++) sc[v * T + tid] = sum[v];
     if (tid == 0) smax = 0;
     __syncthreads();
     atomicMax(&smax, mx);
     for (uint32_t d = 1; d < T; d <<= 1) {
-        uint32_t va = tid >= d ? sa[tid - d] : 0, vb = tid >= d ? sb[tid - d] : 0;
+        uint32_t add[MSM_MAX_LEVELS + 2];
+        for (uint32_t v = 0; v < NV; v++) add[v] = tid >= d ? sc[v * T + tid - d] : 0;
         __syncthreads();
-        sa[tid] += va; sb[tid] += vb;
+        for (uint32_t v = 0; v < NV; v++) sc[v * T + tid] += add[v];
         __syncthreads();
     }
-    uint32_t ea = sa[tid] - a, es = sb[tid] - s;
+    uint32_t ex[MSM_MAX_LEVELS + 2];
+    for (uint32_t v = 0; v < NV; v++) ex[v] = sc[v * T + tid] - sum[v];
+    uint32_t* off = sm + p.o_off;
+    uint32_t* cursor = sm + p.o_cursor;
+    uint32_t* suboff = sm + p.o_suboff;
     for (uint32_t b = lo; b < hi; b++) {
         uint32_t cnt = hist[b];
-        off[b] = ea; cursor[b] = ea; suboff[b] = es;
-        ea += cnt; es += ceil_div(cnt, L);
+        off[b] = ex[0]; cursor[b] = ex[0];
+        ex[0] += cnt;
+        uint32_t e = ceil_div(cnt, p.L);
+        for (uint32_t r = 0; r <= p.R; r++) { suboff[(size_t)r * (B + 1) + b] = ex[1 + r]; ex[1 + r] += e; e = ceil_div(e, p.M); }
     }
     if (tid == T - 1) {
-        off[B] = sa[T - 1]; suboff[B] = sb[T - 1];
-        info[0] = smax; info[1] = sb[T - 1];
+        off[B] = sc[0 * T + T - 1];
+        for (uint32_t r = 0; r <= p.R; r++) suboff[(size_t)r * (B + 1) + B] = sc[(1 + r) * T + T - 1];
+        sm[p.o_info] = smax;
     }
 }
 
 // second pass of the counting sort: every workgroup re-derives its chunk's LDS histogram, reserves
 // a contiguous range per bucket from the global cursors, then drops point references in place.
 // reference = (negative << 31) | (window * n_table + scalar index)
-ZK_KERNEL void msm_scatter_kernel(const void* scalars, uint32_t n, int c, int W, uint32_t n_table, uint32_t* cursor,
-                                  uint32_t* sorted) {
+ZK_KERNEL void msm_scatter_kernel(MsmPlan p) {
     ZK_DYN_SHARED(uint32_t, lh);
-    const uint32_t B = 1u << (c - 1);
+    const uint32_t B = p.B, col = blockIdx.y;
+    const void* scalars = p.scalars[col];
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lh[b] = 0;
     __syncthreads();
-    const uint32_t chunk = ceil_div(n, gridDim.x);
+    const uint32_t chunk = ceil_div(p.n, gridDim.x);
     const uint32_t lo = blockIdx.x * chunk;
-    const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t hi = lo + chunk < p.n ? lo + chunk : p.n;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         u256 s = Fr::from_mont(load_u256(scalars, i));
-        for_each_digit(s, c, W, [&](int, uint32_t mag, bool) { atomicAdd(&lh[mag - 1], 1u); });
+        for_each_digit(s, p.c, p.W, [&](int, uint32_t mag, bool) { atomicAdd(&lh[mag - 1], 1u); });
     }
     __syncthreads();
+    uint32_t* cursor = plan_small(p, col) + p.o_cursor;
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
         uint32_t v = lh[b];
         lh[b] = v ? atomicAdd(&cursor[b], v) : 0u;
     }
     __syncthreads();
+    uint32_t* sorted = p.sorted + (size_t)col * p.sorted_stride;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         u256 s = Fr::from_mont(load_u256(scalars, i));
-        for_each_digit(s, c, W, [&](int j, uint32_t mag, bool neg) {
+        for_each_digit(s, p.c, p.W, [&](int j, uint32_t mag, bool neg) {
             uint32_t pos = atomicAdd(&lh[mag - 1], 1u);
-            sorted[pos] = (neg ? 0x80000000u : 0u) | ((uint32_t)j * n_table + i);
+            sorted[pos] = (neg ? 0x80000000u : 0u) | ((uint32_t)j * p.n_table + i);
         });
     }
 }
@@ -156,84 +200,86 @@ ZK_KERNEL void msm_scatter_kernel(const void* scalars, uint32_t n, int c, int W,
 // ------------------------------------------------------------------------------------------------
 // bucket accumulation: one thread per sub-bucket (<= L references), XYZZ mixed additions
 // ------------------------------------------------------------------------------------------------
-ZK_KERNEL void msm_accumulate_kernel(const void* table, const uint32_t* sorted, const uint32_t* off,
-                                     const uint32_t* suboff, uint32_t B, uint32_t L, void* sub0) {
+ZK_KERNEL void msm_accumulate_kernel(MsmPlan p) {
+    const uint32_t col = blockIdx.y, B = p.B;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t* suboff = plan_suboff(p, col, 0);
     if (j >= suboff[B]) return;
+    const uint32_t* off = plan_small(p, col) + p.o_off;
+    const uint32_t* sorted = p.sorted + (size_t)col * p.sorted_stride;
     const uint32_t b = find_segment(suboff, B, j);
     const uint32_t k = j - suboff[b];
-    uint32_t p = off[b] + k * L;
+    uint32_t q = off[b] + k * p.L;
     const uint32_t bend = off[b + 1];
-    const uint32_t end = p + L < bend ? p + L : bend;
+    const uint32_t end = q + p.L < bend ? q + p.L : bend;
     XYZZ acc = xyzz_identity();
-    uint32_t ref = sorted[p];
-    Affine pt = load_affine(table, ref & 0x7fffffffu);
+    uint32_t ref = sorted[q];
+    Affine pt = load_affine(p.table, ref & 0x7fffffffu);
     while (true) {
         const uint32_t cur_ref = ref;
         const Affine cur = pt;
-        ++p;
-        if (p < end) {  // fetch the next point while the current addition runs
-            ref = sorted[p];
-            pt = load_affine(table, ref & 0x7fffffffu);
+        ++q;
+        if (q < end) {  // fetch the next point while the current addition runs
+            ref = sorted[q];
+            pt = load_affine(p.table, ref & 0x7fffffffu);
         }
         xyzz_madd_signed(acc, cur, (cur_ref >> 31) != 0);
-        if (p >= end) break;
+        if (q >= end) break;
     }
-    store_xyzz(sub0, j, acc);
+    store_xyzz(p.sub[0], (size_t)col * p.sub_stride[0] + j, acc);
 }
 
-// fan-in merge of the sub-buckets of each bucket; round r reads `in`, writes `out` (ping-pong).
-// After r_eff = ceil(log_M(max_s)) rounds bucket b sits at index suboff[b] of buffer (r_eff & 1).
-ZK_KERNEL void msm_merge_kernel(const void* in, void* out, const uint32_t* suboff, uint32_t B, uint32_t M,
-                                uint32_t Mpow_prev, const uint32_t* info) {
-    if (Mpow_prev >= info[0]) return;  // every bucket already has a single entry
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= suboff[B]) return;
-    const uint32_t b = find_segment(suboff, B, j);
-    const uint32_t k = j - suboff[b];
-    const uint32_t s_b = suboff[b + 1] - suboff[b];
-    const uint32_t cnt_prev = ceil_div(s_b, Mpow_prev);
-    const uint32_t cnt_cur = ceil_div(cnt_prev, M);
-    if (k >= cnt_cur) return;
-    const uint32_t base = suboff[b] + k * M;
-    XYZZ acc = load_xyzz(in, base);
-    for (uint32_t m = 1; m < M && k * M + m < cnt_prev; m++) xyzz_add(acc, load_xyzz(in, base + m));
-    store_xyzz(out, suboff[b] + k, acc);
+// merge level r-1 -> level r: one thread per OUTPUT entry (dense), fan-in M.
+ZK_KERNEL void msm_merge_kernel(MsmPlan p, uint32_t r, uint32_t Mpow_prev) {
+    const uint32_t col = blockIdx.y, B = p.B;
+    const uint32_t* sm = plan_small(p, col);
+    if (Mpow_prev >= sm[p.o_info]) return;  // every bucket already has a single entry
+    const uint32_t* so_in = plan_suboff(p, col, r - 1);
+    const uint32_t* so_out = plan_suboff(p, col, r);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= so_out[B]) return;
+    const uint32_t b = find_segment(so_out, B, t);
+    const uint32_t k = t - so_out[b];
+    const uint32_t cnt_in = so_in[b + 1] - so_in[b];
+    const void* in = p.sub[(r - 1) & 1];
+    const size_t ibase = (size_t)col * p.sub_stride[(r - 1) & 1] + so_in[b] + (size_t)k * p.M;
+    XYZZ acc = load_xyzz(in, ibase);
+    for (uint32_t m = 1; m < p.M && k * p.M + m < cnt_in; m++) xyzz_add(acc, load_xyzz(in, ibase + m));
+    store_xyzz(p.sub[r & 1], (size_t)col * p.sub_stride[r & 1] + t, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
 // bucket reduction by weight bits.  Bucket b has weight w = b + 1 in [1, 2^(c-1)].
 //   class t < c-1 : { w < 2^(c-1) : bit t of w set }   (2^(c-2) members)
 //   class c-1     : { w = 2^(c-1) }                     (1 member)
-// result = sum_t 2^t * C_t with C_t the plain sum of class t.
+// result = sum_t 2^t * C_t with C_t the plain sum of class t.   blockIdx.y = col * c + t.
 // ------------------------------------------------------------------------------------------------
-ZK_KERNEL void msm_class_first_kernel(const void* subA, const void* subB, const uint32_t* suboff, const uint32_t* info,
-                                      uint32_t Mmerge, int c, uint32_t M, uint32_t groups, void* out) {
-    const uint32_t max_s = info[0];
-    uint32_t pw = 1, r = 0;
-    while (pw < max_s) { pw *= Mmerge; r++; }
-    const void* buf = (r & 1) ? subB : subA;
-    const uint32_t t = blockIdx.y;
+ZK_KERNEL void msm_class_first_kernel(MsmPlan p, uint32_t TM) {
+    const uint32_t col = blockIdx.y / (uint32_t)p.c, t = blockIdx.y % (uint32_t)p.c;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= groups) return;
+    if (g >= p.groups0) return;
+    const uint32_t r = plan_eff_levels(p, plan_small(p, col)[p.o_info]);
+    const uint32_t* so = plan_suboff(p, col, r);
+    const void* buf = p.sub[r & 1];
+    const size_t cbase = (size_t)col * p.sub_stride[r & 1];
     XYZZ acc = xyzz_identity();
-    if ((int)t == c - 1) {
-        const uint32_t b = (1u << (c - 1)) - 1;
-        if (g == 0 && suboff[b + 1] > suboff[b]) acc = load_xyzz(buf, suboff[b]);
+    if ((int)t == p.c - 1) {
+        const uint32_t b = p.B - 1;
+        if (g == 0 && so[b + 1] > so[b]) acc = load_xyzz(buf, cbase + so[b]);
     } else {
-        const uint32_t Kc = c >= 2 ? 1u << (c - 2) : 0;
-        for (uint32_t m = 0; m < M; m++) {
-            const uint32_t k = g * M + m;
+        const uint32_t Kc = 1u << (p.c - 2);
+        for (uint32_t m = 0; m < TM; m++) {
+            const uint32_t k = g * TM + m;
             if (k >= Kc) break;
             const uint32_t w = ((k >> t) << (t + 1)) | (1u << t) | (k & ((1u << t) - 1u));
             const uint32_t b = w - 1;
-            if (suboff[b + 1] > suboff[b]) xyzz_add(acc, load_xyzz(buf, suboff[b]));
+            if (so[b + 1] > so[b]) xyzz_add(acc, load_xyzz(buf, cbase + so[b]));
         }
     }
-    store_xyzz(out, (size_t)t * groups + g, acc);
+    store_xyzz(p.cls[0], ((size_t)col * p.c + t) * p.groups0 + g, acc);
 }
 ZK_KERNEL void msm_class_round_kernel(const void* in, uint32_t count_in, void* out, uint32_t count_out, uint32_t M) {
-    const uint32_t t = blockIdx.y;
+    const uint32_t t = blockIdx.y;  // (col, class) flattened
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= count_out) return;
     const size_t base = (size_t)t * count_in;
@@ -396,129 +442,167 @@ static void xyzz_to_jacobian_host(const XYZZ& p, void* out96) {
     o[1] = Fq::mul(p.y, Fq::mul(I, p.zz));
     o[2] = Fq::one();
 }
+// normalise a batch with ONE field inversion (Montgomery's trick)
+static void xyzz_batch_to_jacobian_host(const std::vector<XYZZ>& pts, void* out) {
+    const size_t nb = pts.size();
+    std::vector<u256> pre(nb);
+    u256 acc = Fq::one();
+    for (size_t i = 0; i < nb; i++) { pre[i] = acc; if (!xyzz_is_identity(pts[i])) acc = Fq::mul(acc, Fq::mul(pts[i].zz, pts[i].zzz)); }
+    u256 inv = Fq::inv(acc);
+    for (size_t i = nb; i-- > 0;) {
+        u256* o = reinterpret_cast<u256*>((char*)out + i * 96);
+        const XYZZ& p = pts[i];
+        if (xyzz_is_identity(p)) { o[0] = Fq::zero(); o[1] = Fq::zero(); o[2] = Fq::zero(); continue; }
+        u256 I = Fq::mul(inv, pre[i]);
+        inv = Fq::mul(inv, Fq::mul(p.zz, p.zzz));
+        o[0] = Fq::mul(p.x, Fq::mul(I, p.zzz));
+        o[1] = Fq::mul(p.y, Fq::mul(I, p.zz));
+        o[2] = Fq::one();
+    }
+}
 
-// core: leaves the c class sums in host memory and folds them.  out_xyzz (128 B) receives the
-// unnormalised result.
-static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* d_scal, size_t n, XYZZ* out_xyzz) {
+// core: nb columns of n scalars each against one table; out_xyzz[nb] receive the unnormalised sums.
+static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_ptrs, uint32_t nb, size_t n, XYZZ* out_xyzz) {
     const int c = bt.c, W = bt.W;
     const uint32_t B = 1u << (c - 1);
     const Tune& tn = ctx->tune;
     const uint64_t pairs_max = (uint64_t)n * W;
-    uint32_t L = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pairs_max / (uint64_t)tn.msm_target_threads, (uint64_t)tn.msm_min_chunk),
+    const uint32_t M = (uint32_t)std::max(2, tn.msm_merge_fanin), TM = (uint32_t)std::max(2, tn.msm_tree_fanin);
+    uint32_t L = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)nb * pairs_max / (uint64_t)tn.msm_target_threads, (uint64_t)tn.msm_min_chunk),
                                               (uint64_t)tn.msm_max_chunk);
-    const uint64_t S_cap = pairs_max / L + B + 1;
-    const uint32_t M = (uint32_t)tn.msm_merge_fanin, TM = (uint32_t)tn.msm_tree_fanin;
-
-    // small buffers: hist[B] off[B+1] cursor[B] suboff[B+1] info[4]
-    const size_t small_words = (size_t)4 * B + 8;
-    ZK_HIP(ctx->ws_small.ensure(small_words * 4));
-    uint32_t* d_hist = (uint32_t*)ctx->ws_small.p;
-    uint32_t* d_off = d_hist + B;
-    uint32_t* d_cursor = d_off + B + 1;
-    uint32_t* d_suboff = d_cursor + B;
-    uint32_t* d_info = d_suboff + B + 1;
-    ZK_HIP(ctx->ws_sorted.ensure(pairs_max * 4 + 16));
-    ZK_HIP(ctx->ws_sub0.ensure(S_cap * 128));
-    ZK_HIP(ctx->ws_sub1.ensure(S_cap * 128));  // merged entries stay at bucket-relative slots
-    const uint32_t Kc = c >= 2 ? 1u << (c - 2) : 1;
-    const uint32_t groups0 = ceil_div(Kc, TM);
-    ZK_HIP(ctx->ws_cls0.ensure((size_t)c * groups0 * 128));
-    ZK_HIP(ctx->ws_cls1.ensure((size_t)c * ceil_div(groups0, TM) * 128 + 128));
+    MsmPlan p;
+    memset(&p, 0, sizeof p);
+    p.n = (uint32_t)n; p.n_table = (uint32_t)bt.n; p.B = B; p.L = L; p.M = M; p.nb = nb; p.c = c; p.W = W;
+    // merge levels for the worst case (one bucket holds every pair)
+    uint64_t cap[MSM_MAX_LEVELS + 1];
+    cap[0] = pairs_max / L + B + 1;
+    uint32_t R = 0;
+    {
+        uint64_t worst = pairs_max / L + 1;
+        while (worst > 1 && R < MSM_MAX_LEVELS) { worst = (worst + M - 1) / M; R++; cap[R] = cap[R - 1] / M + B + 1; }
+        if (worst > 1) return ctx->fail(ZK_ERR_LIMIT, "zk_msm: merge depth exceeds %d levels (raise msm_merge_fanin)", MSM_MAX_LEVELS);
+    }
+    p.R = R;
+    p.o_off = B; p.o_cursor = p.o_off + B + 1; p.o_suboff = p.o_cursor + B; p.o_info = p.o_suboff + (R + 1) * (B + 1);
+    p.small_stride = p.o_info + 4;
+    ZK_HIP(ctx->ws_small.ensure((size_t)nb * p.small_stride * 4 + (size_t)nb * sizeof(void*) + 64));
+    p.small = (uint32_t*)ctx->ws_small.p;
+    const void** d_ptrs = (const void**)((char*)ctx->ws_small.p + (((size_t)nb * p.small_stride * 4 + 15) & ~(size_t)15));
+    p.scalars = d_ptrs;
+    p.table = bt.d_table;
+    p.sorted_stride = pairs_max + 4;
+    ZK_HIP(ctx->ws_sorted.ensure((size_t)nb * p.sorted_stride * 4));
+    p.sorted = (uint32_t*)ctx->ws_sorted.p;
+    p.sub_stride[0] = cap[0];
+    p.sub_stride[1] = R >= 1 ? cap[1] : 1;
+    ZK_HIP(ctx->ws_sub0.ensure((size_t)nb * p.sub_stride[0] * 128));
+    ZK_HIP(ctx->ws_sub1.ensure((size_t)nb * p.sub_stride[1] * 128));
+    p.sub[0] = ctx->ws_sub0.p; p.sub[1] = ctx->ws_sub1.p;
+    const uint32_t Kc = 1u << (c - 2);
+    p.groups0 = ceil_div(Kc, TM);
+    ZK_HIP(ctx->ws_cls0.ensure((size_t)nb * c * p.groups0 * 128));
+    ZK_HIP(ctx->ws_cls1.ensure((size_t)nb * c * ceil_div(p.groups0, TM) * 128 + 128));
+    p.cls[0] = ctx->ws_cls0.p; p.cls[1] = ctx->ws_cls1.p;
 
     hipStream_t st = ctx->stream;
-    ZK_HIP(hipMemsetAsync(d_hist, 0, (size_t)B * 4, st));
+    ZK_HIP(hipMemsetAsync(p.small, 0, (size_t)nb * p.small_stride * 4, st));
+    ZK_HIP(hipMemcpyAsync((void*)d_ptrs, h_scal_ptrs, (size_t)nb * sizeof(void*), hipMemcpyHostToDevice, st));
     int wgs = tn.msm_sort_wgs;
-    {   // do not spread tiny inputs over many workgroups (each one flushes the full histogram)
+    {   // do not spread small inputs over many workgroups (each one flushes the full histogram)
         uint64_t per = (uint64_t)tn.msm_sort_threads * 4;
         uint64_t want = (n + per - 1) / per;
         if (want < (uint64_t)wgs) wgs = (int)std::max<uint64_t>(want, 1);
+        if (nb > 1) wgs = std::max(1, std::min(wgs, (int)(2048 / nb) + 1));
     }
     const size_t lds = (size_t)B * 4;
     EvTimer t_sort(ctx, "msm_sort");
-    ZK_LAUNCH(msm_hist_kernel, wgs, tn.msm_sort_threads, lds, st, d_scal, (uint32_t)n, c, W, d_hist);
+    ZK_LAUNCH(msm_hist_kernel, dim3(wgs, nb), tn.msm_sort_threads, lds, st, p);
     ZK_CHECK_LAUNCH();
-    ZK_LAUNCH(msm_scan_kernel, 1, 1024, 0, st, (const uint32_t*)d_hist, B, L, d_off, d_cursor, d_suboff, d_info);
+    ZK_LAUNCH(msm_scan_kernel, nb, 1024, 0, st, p);
     ZK_CHECK_LAUNCH();
-    ZK_LAUNCH(msm_scatter_kernel, wgs, tn.msm_sort_threads, lds, st, d_scal, (uint32_t)n, c, W, (uint32_t)bt.n, d_cursor,
-              (uint32_t*)ctx->ws_sorted.p);
+    ZK_LAUNCH(msm_scatter_kernel, dim3(wgs, nb), tn.msm_sort_threads, lds, st, p);
     ZK_CHECK_LAUNCH();
     t_sort.stop();
 
     const int blk = tn.msm_block;
     EvTimer t_acc(ctx, "msm_accumulate");
-    ZK_LAUNCH(msm_accumulate_kernel, (uint32_t)((S_cap + blk - 1) / blk), blk, 0, st, (const void*)bt.d_table,
-              (const uint32_t*)ctx->ws_sorted.p, (const uint32_t*)d_off, (const uint32_t*)d_suboff, B, L, ctx->ws_sub0.p);
+    ZK_LAUNCH(msm_accumulate_kernel, dim3((uint32_t)((cap[0] + blk - 1) / blk), nb), blk, 0, st, p);
     ZK_CHECK_LAUNCH();
     t_acc.stop();
 
     EvTimer t_red(ctx, "msm_reduce");
-    // merge rounds: worst case one bucket holds every pair
     {
-        uint64_t max_s_bound = pairs_max / L + 1;
         uint64_t pw = 1;
-        int r = 0;
-        while (pw < max_s_bound) {
-            void* in = (r & 1) ? ctx->ws_sub1.p : ctx->ws_sub0.p;
-            void* out = (r & 1) ? ctx->ws_sub0.p : ctx->ws_sub1.p;
-            // threads needed this round: at most ceil(S/pw) + B entries are live, but indices are
-            // bucket-relative, so launch over all sub-buckets of round 0 (idle threads exit early)
-            ZK_LAUNCH(msm_merge_kernel, (uint32_t)((S_cap + blk - 1) / blk), blk, 0, st, (const void*)in, out,
-                      (const uint32_t*)d_suboff, B, M, (uint32_t)pw, (const uint32_t*)d_info);
+        for (uint32_t r = 1; r <= R; r++) {
+            ZK_LAUNCH(msm_merge_kernel, dim3((uint32_t)((cap[r] + blk - 1) / blk), nb), blk, 0, st, p, r, (uint32_t)std::min<uint64_t>(pw, 0xffffffffull));
             ZK_CHECK_LAUNCH();
             pw *= M;
-            r++;
         }
     }
-    // class sums
-    uint32_t count = groups0;
-    ZK_LAUNCH(msm_class_first_kernel, dim3(ceil_div(groups0, (uint32_t)blk), c), blk, 0, st, (const void*)ctx->ws_sub0.p,
-              (const void*)ctx->ws_sub1.p, (const uint32_t*)d_suboff, (const uint32_t*)d_info, M, c, TM, groups0, ctx->ws_cls0.p);
+    uint32_t count = p.groups0;
+    ZK_LAUNCH(msm_class_first_kernel, dim3(ceil_div(p.groups0, (uint32_t)blk), nb * c), blk, 0, st, p, TM);
     ZK_CHECK_LAUNCH();
     int flip = 0;
     while (count > 1) {
         uint32_t nxt = ceil_div(count, TM);
-        void* in = flip ? ctx->ws_cls1.p : ctx->ws_cls0.p;
-        void* out = flip ? ctx->ws_cls0.p : ctx->ws_cls1.p;
-        ZK_LAUNCH(msm_class_round_kernel, dim3(ceil_div(nxt, (uint32_t)blk), c), blk, 0, st, (const void*)in, count, out, nxt, TM);
+        ZK_LAUNCH(msm_class_round_kernel, dim3(ceil_div(nxt, (uint32_t)blk), nb * c), blk, 0, st, (const void*)p.cls[flip], count, p.cls[flip ^ 1], nxt, TM);
         ZK_CHECK_LAUNCH();
         count = nxt;
         flip ^= 1;
     }
     t_red.stop();
-    std::vector<XYZZ> cls(c);
-    ZK_HIP(hipMemcpyAsync(cls.data(), flip ? ctx->ws_cls1.p : ctx->ws_cls0.p, (size_t)c * 128, hipMemcpyDeviceToHost, st));
+    std::vector<XYZZ> cls((size_t)nb * c);
+    ZK_HIP(hipMemcpyAsync(cls.data(), p.cls[flip], (size_t)nb * c * 128, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     t_sort.resolve(); t_acc.resolve(); t_red.resolve();
-    // sum_t 2^t C_t, Horner from the top class
-    XYZZ acc = cls[c - 1];
-    for (int t = c - 2; t >= 0; t--) {
-        acc = xyzz_dbl(acc);
-        xyzz_add(acc, cls[t]);
+    for (uint32_t col = 0; col < nb; col++) {   // sum_t 2^t C_t, Horner from the top class
+        const XYZZ* cc = &cls[(size_t)col * c];
+        XYZZ acc = cc[c - 1];
+        for (int t = c - 2; t >= 0; t--) {
+            acc = xyzz_dbl(acc);
+            xyzz_add(acc, cc[t]);
+        }
+        out_xyzz[col] = acc;
     }
-    *out_xyzz = acc;
     return ZK_OK;
 }
 
-int msm_run(zk_ctx* ctx, uint64_t handle, const void* scalars, size_t n, bool on_device, void* out, int partial) {
+// scalars: nb pointers (host array) to host or device columns of n scalars
+int msm_run_batch(zk_ctx* ctx, uint64_t handle, const void* const* scalars, size_t nb, size_t n, bool on_device, void* out, int partial) {
     auto it = ctx->bases.find(handle);
     if (it == ctx->bases.end()) return ctx->fail(ZK_ERR_ARG, "zk_msm: unknown bases handle %llu", (unsigned long long)handle);
     const BaseTable& bt = it->second;
-    if (!out || (!scalars && n)) return ctx->fail(ZK_ERR_ARG, "zk_msm: null pointer");
+    if (nb == 0) return ZK_OK;
+    if (!out || !scalars) return ctx->fail(ZK_ERR_ARG, "zk_msm: null pointer");
     if (n > bt.n) return ctx->fail(ZK_ERR_ARG, "zk_msm: n = %zu exceeds registered table size %zu", n, bt.n);
-    XYZZ res = xyzz_identity();
+    if (nb > 4096) return ctx->fail(ZK_ERR_LIMIT, "zk_msm_batch: more than 4096 columns");
+    std::vector<XYZZ> res(nb, xyzz_identity());
     if (n > 0) {
-        const void* d_scal = scalars;
-        if (!on_device) {
-            ZK_HIP(ctx->ws_scalars.ensure(n * 32));
-            ZK_HIP(hipMemcpyAsync(ctx->ws_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-            d_scal = ctx->ws_scalars.p;
+        std::vector<const void*> ptrs(nb);
+        for (size_t i = 0; i < nb; i++) {
+            if (!scalars[i]) return ctx->fail(ZK_ERR_ARG, "zk_msm: null scalar column %zu", i);
+            ptrs[i] = scalars[i];
         }
-        int rc = msm_core(ctx, bt, d_scal, n, &res);
+        if (!on_device) {
+            ZK_HIP(ctx->ws_scalars.ensure(nb * n * 32));
+            for (size_t i = 0; i < nb; i++) {
+                void* d = (char*)ctx->ws_scalars.p + i * n * 32;
+                ZK_HIP(hipMemcpyAsync(d, scalars[i], n * 32, hipMemcpyHostToDevice, ctx->stream));
+                ptrs[i] = d;
+            }
+        }
+        int rc = msm_core(ctx, bt, ptrs.data(), (uint32_t)nb, n, res.data());
         if (rc) return rc;
     }
-    if (partial) memcpy(out, &res, 128);
-    else xyzz_to_jacobian_host(res, out);
+    if (partial) memcpy(out, res.data(), nb * 128);
+    else if (nb == 1) xyzz_to_jacobian_host(res[0], out);
+    else xyzz_batch_to_jacobian_host(res, out);
     return ZK_OK;
+}
+int msm_run(zk_ctx* ctx, uint64_t handle, const void* scalars, size_t n, bool on_device, void* out, int partial) {
+    if (!scalars && n) return ctx->fail(ZK_ERR_ARG, "zk_msm: null pointer");
+    const void* one[1] = {scalars ? scalars : (const void*)ctx};
+    return msm_run_batch(ctx, handle, one, 1, n, on_device, out, partial);
 }
 
 int g1_sum_xyzz_host(const void* xyzz, size_t count, void* out_jac) {

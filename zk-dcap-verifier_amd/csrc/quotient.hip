@@ -54,6 +54,8 @@ struct QuotProgram {
 #define ZK_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #endif
 
+constexpr uint32_t QUOT_NREG = 6;   // first slots of the allocator are registers, the rest LDS
+
 struct QuotArgs {
     const uint4* code;
     uint32_t n_instr;
@@ -74,6 +76,7 @@ ZK_KERNEL void quotient_kernel(QuotArgs q) {
     const uint32_t idx = blockIdx.x * T + tid;
     const uint32_t mask = (1u << q.size_log) - 1u;
     u256 acc = Fr::zero(), xpow = Fr::one();
+    u256 rg0 = Fr::zero(), rg1 = rg0, rg2 = rg0, rg3 = rg0, rg4 = rg0, rg5 = rg0;   // slots 0..QUOT_NREG-1 live in VGPRs
     if (q.uses_xpow) {  // extended_omega^idx
         xpow = load_u256(q.tw_lo, idx & ((1u << q.lo_bits) - 1u));
         const uint32_t h = idx >> q.lo_bits;
@@ -83,7 +86,13 @@ ZK_KERNEL void quotient_kernel(QuotArgs q) {
         const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
         switch (kind) {
             case K_SLOT: {
-                uint4 l = smem[(2 * pay) * T + tid], h = smem[(2 * pay + 1) * T + tid];
+                switch (pay) {
+                    case 0: return rg0; case 1: return rg1; case 2: return rg2;
+                    case 3: return rg3; case 4: return rg4; case 5: return rg5;
+                    default: break;
+                }
+                const uint32_t ls = pay - QUOT_NREG;
+                uint4 l = smem[(2 * ls) * T + tid], h = smem[(2 * ls + 1) * T + tid];
                 u256 o;
                 o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w;
                 return o;
@@ -116,8 +125,15 @@ ZK_KERNEL void quotient_kernel(QuotArgs q) {
             acc = r;
         } else {
             const uint32_t slot = w0 >> 16;
-            smem[(2 * slot) * T + tid] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-            smem[(2 * slot + 1) * T + tid] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+            switch (slot) {
+                case 0: rg0 = r; break; case 1: rg1 = r; break; case 2: rg2 = r; break;
+                case 3: rg3 = r; break; case 4: rg4 = r; break; case 5: rg5 = r; break;
+                default: {
+                    const uint32_t ls = slot - QUOT_NREG;
+                    smem[(2 * ls) * T + tid] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+                    smem[(2 * ls + 1) * T + tid] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+                }
+            }
         }
     }
     store_u256(q.out, idx, acc);
@@ -248,51 +264,120 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
 
     Builder B(P);
     // ---- graphs -------------------------------------------------------------------------------
+    // Demand-driven emission: a calculation is emitted right before its first use (depth-first from
+    // the graph's result), so e.g. the gate polynomials of halo2's final Horner(previous, gates, y)
+    // are produced one at a time instead of all being live at once.  Unreachable calculations vanish.
     auto run_graph = [&](const Graph& g, uint32_t cbase, bool prev_is_acc, int* result_vreg) -> int {
-        std::vector<int> cur(g.num_intermediates, -1);   // intermediate -> current vreg
-        auto opnd = [&](const VSrc& s, bool* ok) -> Builder::Opnd {
+        const size_t nc = g.calcs.size();
+        *result_vreg = -1;
+        if (nc == 0) return ZK_OK;
+        // resolve Intermediate(t) operands to the calculation that last wrote t before the reader
+        std::vector<int> writer(g.num_intermediates, -1);
+        std::vector<std::vector<int>> dep(nc);       // per calc: producing calc index of each operand (or -1)
+        auto operands_of = [&](const Calc& k) {
+            std::vector<const VSrc*> o;
+            o.push_back(&k.s0);
+            if (k.op == OP_ADD || k.op == OP_SUB || k.op == OP_MUL || k.op == OP_HORNER) o.push_back(&k.s1);
+            for (auto& pp : k.parts) o.push_back(&pp);
+            return o;
+        };
+        for (size_t i = 0; i < nc; i++) {
+            for (const VSrc* o : operands_of(g.calcs[i])) {
+                int d = -1;
+                {   // validate every operand, including those of calculations that end up unreachable
+                    const bool rot_ok = o->b < g.rotations.size();
+                    bool good = true;
+                    switch (o->kind) {
+                        case VS_CONST: good = o->a < g.constants.size(); break;
+                        case VS_INTER: break;
+                        case VS_FIXED: good = o->a < P.n_fixed && rot_ok; break;
+                        case VS_ADVICE: good = o->a < P.n_advice && rot_ok; break;
+                        case VS_INSTANCE: good = o->a < P.n_instance && rot_ok; break;
+                        case VS_CHALLENGE: good = o->a < P.n_challenges; break;
+                        default: good = o->kind <= VS_PREV; break;
+                    }
+                    if (!good) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: operand out of range in calculation %zu", i);
+                }
+                if (o->kind == VS_INTER) {
+                    if (o->a >= writer.size() || writer[o->a] < 0) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: intermediate read before it is written");
+                    d = writer[o->a];
+                }
+                dep[i].push_back(d);
+            }
+            writer[g.calcs[i].target] = (int)i;
+        }
+        std::vector<int> vreg(nc, -1);
+        bool ok = true;
+        auto leaf = [&](const VSrc& s) -> Builder::Opnd {
             switch (s.kind) {
-                case VS_CONST: if (s.a >= g.constants.size()) *ok = false; return B.cst(cbase + s.a);
-                case VS_INTER: if (s.a >= cur.size() || cur[s.a] < 0) { *ok = false; return B.cst(P.c_zero); } return B.slot(cur[s.a]);
-                case VS_FIXED: if (s.a >= P.n_fixed || s.b >= g.rotations.size()) { *ok = false; return B.cst(P.c_zero); } return B.col(P.col_fixed + s.a, g.rotations[s.b]);
-                case VS_ADVICE: if (s.a >= P.n_advice || s.b >= g.rotations.size()) { *ok = false; return B.cst(P.c_zero); } return B.col(P.col_advice + s.a, g.rotations[s.b]);
-                case VS_INSTANCE: if (s.a >= P.n_instance || s.b >= g.rotations.size()) { *ok = false; return B.cst(P.c_zero); } return B.col(P.col_instance + s.a, g.rotations[s.b]);
-                case VS_CHALLENGE: if (s.a >= P.n_challenges) *ok = false; return B.cst(P.c_chal + s.a);
+                case VS_CONST: if (s.a >= g.constants.size()) ok = false; return B.cst(cbase + s.a);
+                case VS_FIXED: if (s.a >= P.n_fixed || s.b >= g.rotations.size()) { ok = false; return B.cst(P.c_zero); } return B.col(P.col_fixed + s.a, g.rotations[s.b]);
+                case VS_ADVICE: if (s.a >= P.n_advice || s.b >= g.rotations.size()) { ok = false; return B.cst(P.c_zero); } return B.col(P.col_advice + s.a, g.rotations[s.b]);
+                case VS_INSTANCE: if (s.a >= P.n_instance || s.b >= g.rotations.size()) { ok = false; return B.cst(P.c_zero); } return B.col(P.col_instance + s.a, g.rotations[s.b]);
+                case VS_CHALLENGE: if (s.a >= P.n_challenges) ok = false; return B.cst(P.c_chal + s.a);
                 case VS_BETA: return B.cst(P.c_beta);
                 case VS_GAMMA: return B.cst(P.c_gamma);
                 case VS_THETA: return B.cst(P.c_theta);
                 case VS_Y: return B.cst(P.c_y);
                 case VS_PREV: return prev_is_acc ? B.acc() : B.cst(P.c_zero);
-                default: *ok = false; return B.cst(P.c_zero);
+                default: ok = false; return B.cst(P.c_zero);
             }
         };
-        int last = -1;
-        for (auto& k : g.calcs) {
-            bool ok = true;
-            Builder::Opnd a = opnd(k.s0, &ok);
-            int v = -1;
-            switch (k.op) {
-                case OP_ADD: v = B.tmp(M_ADD, {a, opnd(k.s1, &ok)}); break;
-                case OP_SUB: v = B.tmp(M_SUB, {a, opnd(k.s1, &ok)}); break;
-                case OP_MUL: v = B.tmp(M_MUL, {a, opnd(k.s1, &ok)}); break;
-                case OP_SQUARE: v = B.tmp(M_SQR, {a}); break;
-                case OP_DOUBLE: v = B.tmp(M_DBL, {a}); break;
-                case OP_NEGATE: v = B.tmp(M_NEG, {a}); break;
-                case OP_STORE: v = B.tmp(M_MOV, {a}); break;
-                case OP_HORNER: {
-                    Builder::Opnd factor = opnd(k.s1, &ok);
-                    if (k.parts.empty()) { v = B.tmp(M_MOV, {a}); break; }
-                    Builder::Opnd curv = a;
-                    for (auto& p : k.parts) { v = B.tmp(M_MULADD, {curv, factor, opnd(p, &ok)}); curv = B.slot(v); }
-                    break;
+        // explicit stack (graphs can be deep): frame = (calc, next operand to make available)
+        struct Frame { int calc; size_t next; };
+        std::vector<Frame> st;
+        st.push_back(Frame{(int)nc - 1, 0});
+        // Horner needs interleaving (part_i must be emitted right before its step), so it keeps a
+        // running value across operand visits.
+        std::vector<int> horner_cur(nc, -1);
+        while (!st.empty()) {
+            Frame& f = st.back();
+            const int ci = f.calc;
+            const Calc& k = g.calcs[ci];
+            if (vreg[ci] >= 0) { st.pop_back(); continue; }
+            const std::vector<int>& d = dep[ci];
+            auto opnd_at = [&](size_t oi) -> Builder::Opnd {
+                const VSrc& sv = oi == 0 ? k.s0 : (oi == 1 && (k.op == OP_ADD || k.op == OP_SUB || k.op == OP_MUL || k.op == OP_HORNER)) ? k.s1
+                                                : k.parts[oi - 2];
+                return d[oi] >= 0 ? B.slot(vreg[d[oi]]) : leaf(sv);
+            };
+            if (k.op != OP_HORNER) {
+                if (f.next < d.size()) {               // make operand f.next available
+                    const size_t oi = f.next++;
+                    if (d[oi] >= 0 && vreg[d[oi]] < 0) st.push_back(Frame{d[oi], 0});
+                    continue;
                 }
-                default: ok = false;
+                int v = -1;
+                switch (k.op) {
+                    case OP_ADD: v = B.tmp(M_ADD, {opnd_at(0), opnd_at(1)}); break;
+                    case OP_SUB: v = B.tmp(M_SUB, {opnd_at(0), opnd_at(1)}); break;
+                    case OP_MUL: v = B.tmp(M_MUL, {opnd_at(0), opnd_at(1)}); break;
+                    case OP_SQUARE: v = B.tmp(M_SQR, {opnd_at(0)}); break;
+                    case OP_DOUBLE: v = B.tmp(M_DBL, {opnd_at(0)}); break;
+                    case OP_NEGATE: v = B.tmp(M_NEG, {opnd_at(0)}); break;
+                    default: v = B.tmp(M_MOV, {opnd_at(0)}); break;
+                }
+                vreg[ci] = v;
+                st.pop_back();
+            } else {
+                // operands: 0 = start, 1 = factor, 2.. = parts.  Steps happen as soon as part i is ready.
+                if (f.next < d.size()) {
+                    const size_t oi = f.next;
+                    if (d[oi] >= 0 && vreg[d[oi]] < 0) { st.push_back(Frame{d[oi], 0}); continue; }
+                    f.next++;
+                    if (oi >= 2) {
+                        Builder::Opnd curv = horner_cur[ci] >= 0 ? B.slot(horner_cur[ci]) : opnd_at(0);
+                        horner_cur[ci] = B.tmp(M_MULADD, {curv, opnd_at(1), opnd_at(oi)});
+                    }
+                    continue;
+                }
+                vreg[ci] = horner_cur[ci] >= 0 ? horner_cur[ci] : B.tmp(M_MOV, {opnd_at(0)});
+                st.pop_back();
             }
             if (!ok) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: operand out of range in a calculation");
-            cur[k.target] = v;
-            last = v;
         }
-        *result_vreg = last;
+        if (!ok) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: operand out of range in a calculation");
+        *result_vreg = vreg[nc - 1];
         return ZK_OK;
     };
     int res = -1;
@@ -439,7 +524,7 @@ int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* p
     QuotProgram* P = new QuotProgram();
     int rc = compile_program(ctx, words.data(), words.size(), *P);
     if (rc) { delete P; return rc; }
-    if ((size_t)P->n_slots * 64 * 32 > 160 * 1024) {
+    if ((size_t)(P->n_slots > QUOT_NREG ? P->n_slots - QUOT_NREG : 0) * 64 * 32 > 160 * 1024) {
         delete P;
         return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %u live intermediates; this build keeps at most 80 in LDS", P->n_slots);
     }
@@ -467,6 +552,14 @@ static void free_program(QuotProgram* P) {
     if (P->d_cols) (void)hipFree(P->d_cols);
     if (P->d_rot) (void)hipFree(P->d_rot);
     delete P;
+}
+int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns) {
+    auto it = ctx->programs.find(prog);
+    if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_info: unknown program");
+    if (n_instr) *n_instr = (uint32_t)it->second->code.size();
+    if (n_slots) *n_slots = it->second->n_slots;
+    if (n_columns) *n_columns = it->second->n_cols;
+    return ZK_OK;
 }
 int quotient_program_release(zk_ctx* ctx, uint64_t prog) {
     auto it = ctx->programs.find(prog);
@@ -549,9 +642,10 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a) {
     }
     uint32_t T = (uint32_t)ctx->tune.quot_threads;
     if (T > size) T = (uint32_t)size;
-    while (T > 64 && (size_t)P.n_slots * T * 32 > 64 * 1024) T >>= 1;
+    const uint32_t lds_slots = P.n_slots > QUOT_NREG ? P.n_slots - QUOT_NREG : 0;
+    while (T > 64 && (size_t)lds_slots * T * 32 > 32 * 1024) T >>= 1;
     if (T < 1) T = 1;
-    const size_t lds = (size_t)P.n_slots * T * 32;
+    const size_t lds = (size_t)lds_slots * T * 32;
     if (lds > 160 * 1024) return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %zu bytes of LDS", lds);
     EvTimer tq(ctx, "quotient");
     ZK_LAUNCH(quotient_kernel, (uint32_t)(size / T), T, lds, st, q);

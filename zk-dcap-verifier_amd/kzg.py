@@ -12,7 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 from ._lib import Backend, default_backend
-from .arithmetic import BasesHandle, best_multiexp
+from .arithmetic import BasesHandle, best_multiexp, best_multiexp_batch
 
 
 class ParamsKZG:
@@ -34,6 +34,12 @@ class ParamsKZG:
         poly = np.asarray(poly, dtype=np.uint64).reshape(-1, 4)
         assert poly.shape[0] == self.n
         return best_multiexp(poly, self.g_lagrange)
+
+    def commit_lagrange_batch(self, polys) -> np.ndarray:
+        return best_multiexp_batch(polys, self.g_lagrange)
+
+    def commit_batch(self, polys) -> np.ndarray:
+        return best_multiexp_batch(polys, self.g)
 
     def release(self):
         self.g.release()

@@ -38,7 +38,7 @@ def main():
                           "gen_s": round(t_gen, 3), "register_s": round(t_reg, 3),
                           "kernels_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in lab.items() if v[0] is not None}}), flush=True)
         if lg == 19:
-            for key, vals in (("msm_target_threads", [1 << 17, 1 << 18, 1 << 20]), ("msm_block", [64, 256]), ("msm_merge_fanin", [4, 16])):
+            for key, vals in (("msm_block", [64, 256]), ("msm_merge_fanin", [4, 16]), ("msm_tree_fanin", [2, 8])):
                 old = be.tune_get(key)
                 for v in vals:
                     be.tune(**{key: v})
@@ -59,6 +59,18 @@ def main():
                 be.timing(False)
                 print(json.dumps({"msm_batch": nb, "ms_total": round(dt * 1e3, 3), "ms_per_msm": round(dt * 1e3 / nb, 3),
                                   "kernels_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in lab.items() if v[0] is not None}}), flush=True)
+            for mc in (16, 32, 64, 128, 256, 512):
+                be.tune(msm_max_chunk=mc)
+                be.msm_batch(h, cols[:16], n)
+                be.timing(True)
+                t = time.time()
+                for _ in range(3): be.msm_batch(h, cols[:16], n)
+                dt = (time.time() - t) / 3
+                lab = {k: be.timing_get(k) for k in ("msm_sort", "msm_accumulate", "msm_reduce")}
+                be.timing(False)
+                print(json.dumps({"batch16_max_chunk": mc, "ms_per_msm": round(dt * 1e3 / 16, 3),
+                                  "kernels_ms_per_msm": {k: round(v[0] / max(v[1], 1) / 16, 3) for k, v in lab.items() if v[0] is not None}}), flush=True)
+            be.tune(msm_max_chunk=512)
             for c_ in cols: c_.free()
         be.bases_release(h); dk.free(); dp.free(); ds.free()
     for lg in [int(x) for x in os.environ.get("NTT_LOGS", "16,19,21,22").split(",")]:

@@ -19,7 +19,7 @@ struct Tune {
     int msm_sort_threads = 1024;
     int msm_target_threads = 1 << 19;  // sub-bucket count the accumulate launch aims for
     int msm_min_chunk = 16;      // min pairs per accumulate thread
-    int msm_max_chunk = 512;
+    int msm_max_chunk = 32;        // fixed-size sub-buckets keep all 64 lanes of a wave equally loaded (profiles/r01)
     int msm_merge_fanin = 8;
     int msm_tree_fanin = 4;
     int msm_block = 128;         // threads per workgroup of the curve-arithmetic kernels

@@ -4,10 +4,9 @@
 // [u32;8] little endian on this target), so buffers cross the FFI with zero conversion
 // (halo2curves 0.3.1 @ bdb2e66, Cargo.lock:1329-1344).
 //
-// CDNA4 has no 64x64 multiplier in the VALU; the widest integer multiply is
-// v_mad_u64_u32 (32x32+64 -> 64).  mont_mul below is a CIOS Montgomery product built on
-// that instruction; both moduli are < 2^254 so the running value never exceeds 8 limbs + 1 bit
-// and a single conditional subtraction finishes the reduction.
+// CDNA4 has no 64x64 multiplier in the VALU; the widest integer multiply is v_mad_u64_u32
+// (32x32+64 -> 64, measured at ~1/3 of the full VALU rate on MI355X, profiles/r01).  Field::mul is a
+// product-scanning Montgomery multiplication built directly on that instruction and its carry-out.
 #pragma once
 #include "rt.h"
 #include <stdint.h>
@@ -33,6 +32,8 @@ struct FrParams {
     static constexpr uint64_t R2[4] = BN254_FR_R2;
     static constexpr uint32_t INV = BN254_FR_INV32;
 };
+
+#include "field_mac.inc"
 
 template <class FP>
 struct Field {
@@ -115,9 +116,23 @@ struct Field {
     }
     static ZK_HD u256 dbl(const u256& a) { return add(a, a); }
 
-    // Montgomery product a*b*R^-1 mod p.  CIOS over 32-bit limbs; every inner step is one
-    // 32x32+64 multiply-add (v_mad_u64_u32) plus the propagation of a 32-bit carry.
+    // Montgomery product a*b*R^-1 mod p: finely integrated product scanning (Comba columns).  Column k
+    // gathers every a_i*b_j and m_i*p_j with i + j = k in a 96-bit accumulator (64-bit register pair +
+    // overflow counter): each of the 128 partial products costs one v_mad_u64_u32 (carry-out to VCC)
+    // and one v_addc_co_u32 into the counter — see field_mac.inc — and the modulus limbs sit in SGPRs.
+    // The quotient digit m_k is formed when column k is complete.  Both moduli are < 2^254, so the
+    // 16-limb total divided by 2^256 is < 2p and fits 8 limbs; one conditional subtraction finishes.
     static ZK_HD u256 mul(const u256& a, const u256& b) {
+        uint64_t acc = 0;
+        uint32_t cnt = 0;
+        uint32_t m[8];
+        u256 r;
+#include "field_mul_body.inc"
+        r.v[7] = (uint32_t)acc;
+        return reduce_once(r);
+    }
+    // the plain-C coarsely integrated operand scanning form (kept for the microbenchmark comparison)
+    static ZK_HD u256 mul_cios(const u256& a, const u256& b) {
         uint32_t t[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) t[i] = 0;
@@ -130,7 +145,7 @@ struct Field {
                 t[j] = (uint32_t)s;
                 c = s >> 32;
             }
-            uint32_t t8 = t[8] + (uint32_t)c;  // < 2^32: total stays < 2p*2^32-ish, see header
+            uint32_t t8 = t[8] + (uint32_t)c;
             uint32_t m = t[0] * FP::INV;
             c = ((uint64_t)m * p(0) + t[0]) >> 32;
 #pragma unroll
@@ -146,7 +161,7 @@ struct Field {
         u256 o;
 #pragma unroll
         for (int i = 0; i < 8; i++) o.v[i] = t[i];
-        return reduce_once(o);  // t[8] == 0 here because p < 2^254 (result < 2p < 2^255)
+        return reduce_once(o);
     }
     static ZK_HD u256 sqr(const u256& a) { return mul(a, a); }
 

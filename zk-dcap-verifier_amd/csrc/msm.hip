@@ -64,7 +64,7 @@ ZK_HD uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // ------------------------------------------------------------------------------------------------
 // launch plan shared by the kernels of one (batched) MSM call.  blockIdx.y = column of the batch.
 // ------------------------------------------------------------------------------------------------
-constexpr int MSM_MAX_LEVELS = 8;
+constexpr int MSM_MAX_LEVELS = 12;
 struct MsmPlan {
     uint32_t n, n_table, B, L, M, R, nb;   // R = merge levels above level 0
     int c, W;

@@ -1,0 +1,41 @@
+"""Worker for tests/test_multi_rank.py: the N>1 MSM path of bench.py (base table sharded by index range,
+128-byte XYZZ partials all-gathered, every rank sums) on the gloo backend with the kernel emulator."""
+import os
+import sys
+
+import numpy as np
+
+
+def run(rank: int, world: int, port: int, n: int, out_dir: str):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import oracle as orc
+    import pyref
+    import parity_cases as pc
+    import zk_dcap_verifier_amd as z
+    from conftest import EMU_SO
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    be = z.Backend(0, lib_path=EMU_SO)
+    be.tune(msm_sort_threads=32, msm_sort_wgs=2, msm_block=32, msm_target_threads=64, msm_min_chunk=2)
+    sc, bases = pc.msm_inputs(orc, pyref, n, 1234)           # same seed on every rank = the global problem
+    lo, hi = rank * n // world, (rank + 1) * n // world       # this rank's shard of bases and scalars
+    h = be.bases_register(np.ascontiguousarray(bases[lo:hi]))
+    ds = be.to_device(np.ascontiguousarray(sc[lo:hi]))
+    part = be.msm_partial(h, ds, hi - lo)
+    mine = torch.from_numpy(part.view(np.int64).copy())
+    gathered = [torch.zeros(16, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    total = be.g1_sum_xyzz(torch.stack(gathered).numpy().view(np.uint64))
+    want = orc.g1_to_affine(orc.best_multiexp(sc, bases))[0]
+    ok = bool((total[:8] == want).all())
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+    be.close()

@@ -1,0 +1,25 @@
+"""N>1 path on CPU: two gloo ranks, base table sharded by index range, partial points all-gathered and
+summed on every rank (what bench.py --gpus N does over RCCL).  Checked against the oracle's full MSM."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import torch.multiprocessing as mp
+
+import multi_rank_worker
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_msm_two_ranks_gloo(built):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(multi_rank_worker.run, args=(2, _free_port(), 150, d), nprocs=2, join=True)
+        for r in range(2):
+            assert np.load(os.path.join(d, f"rank{r}.npy"))[0] == 1

@@ -30,7 +30,7 @@ def test_ntt_other_plans(gpu, orc, pyref, tile, radix):
         for log_n in (4, 10, 14, 16):
             pc.check_ntt(gpu, orc, pyref, log_n, seed=log_n)
     finally:
-        gpu.tune(ntt_tile_log=11, ntt_max_radix_log=8)
+        gpu.tune(ntt_tile_log=10, ntt_max_radix_log=8)
 
 
 @pytest.mark.parametrize("j,k", [(4, 10), (5, 12), (3, 9), (9, 8), (2, 11)])

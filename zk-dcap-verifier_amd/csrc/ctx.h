@@ -23,8 +23,8 @@ struct Tune {
     int msm_merge_fanin = 8;
     int msm_tree_fanin = 4;
     int msm_block = 128;         // threads per workgroup of the curve-arithmetic kernels
-    int ntt_tile_log = 11;       // log2(elements) of the LDS tile of one NTT workgroup
-    int ntt_threads = 256;
+    int ntt_tile_log = 10;       // log2(elements) of the LDS tile of one NTT workgroup (sweep: profiles/r01/run6_ntt_plan_sweep.txt)
+    int ntt_threads = 512;
     int ntt_max_radix_log = 8;
     int vec_block = 256;
     int quot_threads = 128;

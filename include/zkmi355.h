@@ -51,10 +51,12 @@ const char* zk_last_error(zk_ctx* ctx);
 /* runtime tunables, e.g. "msm_c", "ntt_tile_log" (see DESIGN.md); unknown key -> ZK_ERR_ARG */
 int zk_tune_set(zk_ctx* ctx, const char* key, int value);
 int zk_tune_get(zk_ctx* ctx, const char* key, int* value);
-/* per-kernel HIP-event timing of the most recent call (enable with zk_timing_enable(ctx, 1));
- * zk_timing_get returns milliseconds for a kernel label such as "msm_accumulate", or < 0. */
+/* per-kernel HIP-event timing, accumulated since zk_timing_enable(ctx, 1) (which also resets it).
+ * zk_timing_get returns milliseconds for a kernel label ("msm_sort", "msm_accumulate", "msm_reduce",
+ * "quotient"), the launch count for "<label>#n", the counters "msm_pairs" (point additions fed to the
+ * accumulate kernel) and "msm_columns"; < 0 if unknown. */
 int zk_timing_enable(zk_ctx* ctx, int on);
-float zk_timing_get(zk_ctx* ctx, const char* label);
+double zk_timing_get(zk_ctx* ctx, const char* label);
 
 /* ---- device memory helpers (so callers need no HIP of their own) -------------------------- */
 int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** dptr);
@@ -105,6 +107,11 @@ int zk_coeff_to_extended_dev(zk_ctx* ctx, const void* coeff_dev, uint32_t k, uin
 int zk_extended_to_coeff_dev(zk_ctx* ctx, void* a_ext_dev, uint32_t k, uint32_t extended_k);
 /* a[i] *= t_evaluations[i mod 2^(extended_k-k)] (1/(X^n - 1) on the coset)                      */
 int zk_divide_by_vanishing_poly_dev(zk_ctx* ctx, void* a_ext_dev, uint32_t k, uint32_t extended_k);
+/* batched forms: `count` columns per call (HOST arrays of DEVICE pointers) — one launch per pass for the
+ * whole phase, e.g. the advice-column loop of create_proof / evaluate_h                                */
+int zk_ntt_batch_dev(zk_ctx* ctx, void* const* cols_dev, size_t count, uint32_t log_n, const void* omega);
+int zk_lagrange_to_coeff_batch_dev(zk_ctx* ctx, void* const* cols_dev, size_t count, uint32_t k);
+int zk_coeff_to_extended_batch_dev(zk_ctx* ctx, const void* const* coeffs_dev, void* const* outs_dev, size_t count, uint32_t k, uint32_t extended_k);
 int zk_lagrange_to_coeff(zk_ctx* ctx, void* a_host, uint32_t k);
 int zk_coeff_to_extended(zk_ctx* ctx, const void* coeff_host, uint32_t k, uint32_t extended_k, void* out_host);
 int zk_extended_to_coeff(zk_ctx* ctx, void* a_ext_host, uint32_t k, uint32_t extended_k);

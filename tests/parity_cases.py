@@ -125,6 +125,28 @@ def check_ntt(be, orc, pyref, log_n, seed=41):
     assert (b == orc.fr_mul(a, np.repeat(nm, n, axis=0))).all()
 
 
+def check_domain_batch(be, orc, pyref, j, k, count, seed=55):
+    """zk_lagrange_to_coeff_batch_dev / zk_coeff_to_extended_batch_dev / zk_ntt_batch_dev vs the oracle per column."""
+    od = orc.Domain(j, k)
+    n, en = 1 << k, 1 << od.extended_k
+    cols = [rand_fr(orc, pyref, n, seed + i) for i in range(count)]
+    dcols = [be.to_device(c) for c in cols]
+    be.lagrange_to_coeff_batch_dev(dcols, k)
+    coeffs = [od.lagrange_to_coeff(c) for c in cols]
+    for d, want in zip(dcols, coeffs):
+        assert (d.download((n, 4)) == want).all()
+    outs = [be.alloc(en * 32) for _ in range(count)]
+    be.coeff_to_extended_batch_dev(dcols, outs, k, od.extended_k)
+    for o, c in zip(outs, coeffs):
+        assert (o.download((en, 4)) == od.coeff_to_extended(c)).all()
+    w = od.extended_omega
+    be.ntt_batch_dev(outs, od.extended_k, w)
+    for o, c in zip(outs, coeffs):
+        assert (o.download((en, 4)) == orc.best_fft(od.coeff_to_extended(c), w, od.extended_k)).all()
+    for d in dcols + outs:
+        d.free()
+
+
 def check_domain(be, orc, pyref, j, k, seed=51):
     d = z.domain.EvaluationDomain(j, k, backend=be)
     od = orc.Domain(j, k)

@@ -24,9 +24,23 @@ def test_ntt_other_plans(emu, orc, pyref, tile, radix):
         emu.tune(ntt_tile_log=6, ntt_max_radix_log=4)
 
 
+def test_ntt_two_level_twiddle_path(emu, orc, pyref):
+    emu.tune(ntt_full_twiddle_max_log=0)          # the path used above 2^24: twiddles from the two-level tables
+    try:
+        for log_n in (5, 9, 12):
+            pc.check_ntt(emu, orc, pyref, log_n, seed=100 + log_n)
+    finally:
+        emu.tune(ntt_full_twiddle_max_log=24)
+
+
 @pytest.mark.parametrize("j,k", [(4, 5), (5, 6), (3, 4), (9, 3), (2, 4)])
 def test_domain(emu, orc, pyref, j, k):
     pc.check_domain(emu, orc, pyref, j, k)
+
+
+def test_domain_batch(emu, orc, pyref):
+    pc.check_domain_batch(emu, orc, pyref, 4, 5, 3)
+    pc.check_domain_batch(emu, orc, pyref, 3, 2, 2)          # single-pass transforms, batched
 
 
 @pytest.mark.parametrize("n,c", [(1, 0), (2, 0), (5, 0), (33, 0), (200, 5), (300, 7), (700, 0)])

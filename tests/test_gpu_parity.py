@@ -33,9 +33,23 @@ def test_ntt_other_plans(gpu, orc, pyref, tile, radix):
         gpu.tune(ntt_tile_log=10, ntt_max_radix_log=8)
 
 
+def test_ntt_two_level_twiddle_path(gpu, orc, pyref):
+    gpu.tune(ntt_full_twiddle_max_log=0)
+    try:
+        for log_n in (9, 14, 17):
+            pc.check_ntt(gpu, orc, pyref, log_n, seed=100 + log_n)
+    finally:
+        gpu.tune(ntt_full_twiddle_max_log=24)
+
+
 @pytest.mark.parametrize("j,k", [(4, 10), (5, 12), (3, 9), (9, 8), (2, 11)])
 def test_domain_ops(gpu, orc, pyref, j, k):
     pc.check_domain(gpu, orc, pyref, j, k)
+
+
+@pytest.mark.parametrize("j,k,count", [(5, 12, 9), (4, 6, 3), (3, 14, 4)])
+def test_domain_batch(gpu, orc, pyref, j, k, count):
+    pc.check_domain_batch(gpu, orc, pyref, j, k, count)
 
 
 @pytest.mark.parametrize("n", [1, 2, 7, 100, 1000, 4096, 20000])

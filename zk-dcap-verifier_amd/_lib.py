@@ -43,7 +43,7 @@ def _load(path: str):
     lib = C.CDLL(path)
     lib.zk_last_error.restype = C.c_char_p
     lib.zk_version.restype = C.c_char_p
-    lib.zk_timing_get.restype = C.c_float
+    lib.zk_timing_get.restype = C.c_double
     return lib
 
 
@@ -137,6 +137,10 @@ class Backend:
         n = self.lib.zk_timing_get(self.ctx, (label + "#n").encode())
         return (ms, int(n)) if ms >= 0 else (None, 0)
 
+    def stat_get(self, label: str) -> float:
+        v = self.lib.zk_timing_get(self.ctx, label.encode())
+        return v if v >= 0 else 0.0
+
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
@@ -223,6 +227,20 @@ class Backend:
 
     def lagrange_to_coeff_dev(self, a_dev, k): self._ck(self.lib.zk_lagrange_to_coeff_dev(self.ctx, C.c_void_p(_dptr(a_dev)), C.c_uint32(k)))
     def coeff_to_lagrange_dev(self, a_dev, k): self._ck(self.lib.zk_coeff_to_lagrange_dev(self.ctx, C.c_void_p(_dptr(a_dev)), C.c_uint32(k)))
+
+    def _ptr_array(self, bufs):
+        return (C.c_void_p * max(1, len(bufs)))(*[_dptr(b) for b in bufs])
+
+    def ntt_batch_dev(self, cols, log_n: int, omega):
+        w = self._fe(omega)
+        self._ck(self.lib.zk_ntt_batch_dev(self.ctx, self._ptr_array(cols), C.c_size_t(len(cols)), C.c_uint32(log_n), w.ctypes.data_as(C.c_void_p)))
+
+    def lagrange_to_coeff_batch_dev(self, cols, k):
+        self._ck(self.lib.zk_lagrange_to_coeff_batch_dev(self.ctx, self._ptr_array(cols), C.c_size_t(len(cols)), C.c_uint32(k)))
+
+    def coeff_to_extended_batch_dev(self, coeffs, outs, k, ek):
+        assert len(coeffs) == len(outs)
+        self._ck(self.lib.zk_coeff_to_extended_batch_dev(self.ctx, self._ptr_array(coeffs), self._ptr_array(outs), C.c_size_t(len(outs)), C.c_uint32(k), C.c_uint32(ek)))
 
     def coeff_to_extended_dev(self, coeff_dev, k, ek, out_dev):
         self._ck(self.lib.zk_coeff_to_extended_dev(self.ctx, C.c_void_p(_dptr(coeff_dev)), C.c_uint32(k), C.c_uint32(ek), C.c_void_p(_dptr(out_dev))))

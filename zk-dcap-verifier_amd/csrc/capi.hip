@@ -8,6 +8,9 @@ int ntt_set_lds_attr();
 int quotient_set_lds_attr();
 int domain_lagrange_to_coeff(zk_ctx* ctx, void* d_a, uint32_t k);
 int domain_coeff_to_lagrange(zk_ctx* ctx, void* d_a, uint32_t k);
+int domain_lagrange_to_coeff_batch(zk_ctx* ctx, void* const* cols, size_t count, uint32_t k);
+int domain_coeff_to_extended_batch(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek);
+int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, size_t count, uint32_t log_n, const u256& omega, const NttFuse* fuse);
 int domain_coeff_to_extended(zk_ctx* ctx, const void* d_coeff, uint32_t k, uint32_t ek, void* d_out);
 int domain_extended_to_coeff(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek);
 int domain_divide_by_vanishing(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek);
@@ -74,10 +77,10 @@ const char* zk_last_error(zk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null c
 static int* tune_slot(zk_ctx* ctx, const char* key) {
     zk::Tune& t = ctx->tune;
     struct { const char* k; int* v; } tab[] = {
-        {"msm_c", &t.msm_c}, {"msm_sort_wgs", &t.msm_sort_wgs}, {"msm_sort_threads", &t.msm_sort_threads},
+        {"msm_c", &t.msm_c}, {"msm_sort_wgs", &t.msm_sort_wgs}, {"msm_sort_threads", &t.msm_sort_threads}, {"msm_sort_batch_wgs", &t.msm_sort_batch_wgs},
         {"msm_target_threads", &t.msm_target_threads}, {"msm_min_chunk", &t.msm_min_chunk}, {"msm_max_chunk", &t.msm_max_chunk},
         {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block},
-        {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log},
+        {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log},
         {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}};
     for (auto& e : tab) if (!strcmp(e.k, key)) return e.v;
     return nullptr;
@@ -98,11 +101,11 @@ int zk_tune_get(zk_ctx* ctx, const char* key, int* value) {
     return ZK_OK;
 }
 int zk_timing_enable(zk_ctx* ctx, int on) { NEED_CTX; LOCK; ctx->timing = on != 0; ctx->last_ms.clear(); return ZK_OK; }
-float zk_timing_get(zk_ctx* ctx, const char* label) {
-    if (!ctx || !label) return -1.f;
+double zk_timing_get(zk_ctx* ctx, const char* label) {
+    if (!ctx || !label) return -1.0;
     LOCK;
     auto it = ctx->last_ms.find(label);
-    return it == ctx->last_ms.end() ? -1.f : it->second;
+    return it == ctx->last_ms.end() ? -1.0 : it->second;
 }
 
 #define ENTER NEED_CTX; LOCK; ZK_HIP(hipSetDevice(ctx->device))
@@ -158,6 +161,17 @@ int zk_ntt(zk_ctx* ctx, void* a, uint32_t log_n, const void* omega) {
     int rc = with_host_buffer(ctx, a, bytes, bytes, bytes, &d); if (rc) return rc;
     rc = ntt_dev(ctx, d, log_n, load_host_fr(omega), nullptr); if (rc) return rc;
     return finish_host(ctx, a, d, bytes);
+}
+int zk_ntt_batch_dev(zk_ctx* ctx, void* const* cols, size_t count, uint32_t log_n, const void* omega) {
+    ENTER; if (!omega) return ctx->fail(ZK_ERR_ARG, "zk_ntt_batch_dev: null omega");
+    int rc = ntt_dev_batch(ctx, cols, nullptr, count, log_n, load_host_fr(omega), nullptr); if (rc) return rc;
+    ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
+}
+int zk_lagrange_to_coeff_batch_dev(zk_ctx* ctx, void* const* cols, size_t count, uint32_t k) {
+    ENTER; int rc = domain_lagrange_to_coeff_batch(ctx, cols, count, k); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
+}
+int zk_coeff_to_extended_batch_dev(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek) {
+    ENTER; int rc = domain_coeff_to_extended_batch(ctx, coeffs, outs, count, k, ek); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
 }
 int zk_lagrange_to_coeff_dev(zk_ctx* ctx, void* a, uint32_t k) { ENTER; int rc = domain_lagrange_to_coeff(ctx, a, k); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
 int zk_coeff_to_lagrange_dev(zk_ctx* ctx, void* a, uint32_t k) { ENTER; int rc = domain_coeff_to_lagrange(ctx, a, k); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }

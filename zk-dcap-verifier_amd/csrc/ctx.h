@@ -17,6 +17,7 @@ struct Tune {
     int msm_c = 0;               // 0 = pick from n
     int msm_sort_wgs = 256;      // workgroups of the counting-sort kernels (one per CU)
     int msm_sort_threads = 1024;
+    int msm_sort_batch_wgs = 2048;   // total sort workgroups aimed for by a batched call
     int msm_target_threads = 1 << 19;  // sub-bucket count the accumulate launch aims for
     int msm_min_chunk = 16;      // min pairs per accumulate thread
     int msm_max_chunk = 32;        // fixed-size sub-buckets keep all 64 lanes of a wave equally loaded (profiles/r01)
@@ -26,6 +27,7 @@ struct Tune {
     int ntt_tile_log = 10;       // log2(elements) of the LDS tile of one NTT workgroup (sweep: profiles/r01/run6_ntt_plan_sweep.txt)
     int ntt_threads = 512;
     int ntt_max_radix_log = 8;
+    int ntt_full_twiddle_max_log = 24;   // up to this size inter-pass twiddles come from full HBM tables (32 B/element/pass)
     int vec_block = 256;
     int quot_threads = 128;
 };
@@ -58,6 +60,7 @@ struct TwiddleSet {           // per (omega, log_n)
     void* d_hi = nullptr;     // omega^(e << lo_bits)
     uint32_t lo_bits = 0;
     void* d_stage[3] = {nullptr, nullptr, nullptr};  // per pass: omega_R^k, k < R/2
+    void* d_full[3] = {nullptr, nullptr, nullptr};   // per non-final pass: inter-pass twiddles in store order
     uint32_t radix_log[3] = {0, 0, 0};
     int passes = 0;
 };
@@ -80,7 +83,7 @@ struct zk_ctx {
     zk::DevBuf ws_scalars, ws_sorted, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts;
     // last-call kernel timing (ms), filled when timing is enabled
     bool timing = false;
-    std::map<std::string, float> last_ms;
+    std::map<std::string, double> last_ms;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -112,7 +115,7 @@ struct EvTimer {
         if (!on) return;
         (void)hipEventSynchronize(b);
         float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
-        ctx->last_ms[label] += ms; ctx->last_ms[std::string(label) + "#n"] += 1.0f;
+        ctx->last_ms[label] += ms; ctx->last_ms[std::string(label) + "#n"] += 1.0;
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     }
 };

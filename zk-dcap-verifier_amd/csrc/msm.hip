@@ -512,7 +512,7 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
         uint64_t per = (uint64_t)tn.msm_sort_threads * 4;
         uint64_t want = (n + per - 1) / per;
         if (want < (uint64_t)wgs) wgs = (int)std::max<uint64_t>(want, 1);
-        if (nb > 1) wgs = std::max(1, std::min(wgs, (int)(2048 / nb) + 1));
+        if (nb > 1) wgs = std::max(1, std::min(wgs, (int)((tn.msm_sort_batch_wgs) / nb) + 1));
     }
     const size_t lds = (size_t)B * 4;
     EvTimer t_sort(ctx, "msm_sort");
@@ -553,7 +553,12 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     t_red.stop();
     std::vector<XYZZ> cls((size_t)nb * c);
     ZK_HIP(hipMemcpyAsync(cls.data(), p.cls[flip], (size_t)nb * c * 128, hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> npairs(ctx->timing ? nb : 0);
+    for (uint32_t col = 0; col < (uint32_t)npairs.size(); col++)   // off[B] = pairs of the column (zero digits are skipped)
+        ZK_HIP(hipMemcpyAsync(&npairs[col], plan_small(p, col) + p.o_off + B, 4, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
+    for (uint32_t v : npairs) ctx->last_ms["msm_pairs"] += (double)v;
+    if (ctx->timing) ctx->last_ms["msm_columns"] += (double)nb;
     t_sort.resolve(); t_acc.resolve(); t_red.resolve();
     for (uint32_t col = 0; col < nb; col++) {   // sum_t 2^t C_t, Horner from the top class
         const XYZZ* cc = &cls[(size_t)col * c];

@@ -12,12 +12,15 @@
 // C-element (C*32 B) contiguous runs.  The digit-reversed placement of the last pass replaces the
 // bit-reversal pass, so natural order is kept with 2-3 HBM round trips in total.
 #include "ctx.h"
+#include <vector>
 
 namespace zk {
 
 struct NttPassArgs {
     const void* src;
     void* dst;
+    const void* const* srcs;   // batch: device arrays of per-column pointers (blockIdx.y = column); null for one column
+    void* const* dsts;
     uint32_t log_n;
     uint32_t blk_log;   // log2 of the sub-transform this pass works inside
     uint32_t r;         // log2 radix of this pass
@@ -28,6 +31,7 @@ struct NttPassArgs {
     const void* tw_lo;      // omega^e, e < 2^lo_bits
     const void* tw_hi;      // omega^(h << lo_bits)
     uint32_t lo_bits;
+    const void* tw_full;    // non-final pass: twiddle of element (row, m) at [row * cols + m], or null
     // fused operations
     uint32_t n_valid;       // first pass only (0 = all)
     int pre_zeta;
@@ -100,6 +104,7 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
 // the same addresses; the output row j of column m is multiplied by omega_blk^(m*j).
 ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
     ZK_DYN_SHARED(uint4, smem);
+    if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
     const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
     uint4* lo = smem;
     uint4* hi = smem + tile;
@@ -123,10 +128,14 @@ ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
         u256 v = lds_get(lo, hi, e);
         const uint32_t ex = ((m0 + col) * row) << sh;  // < 2^log_n
         if (ex) {
-            u256 tw = load_u256(a.tw_lo, ex & lomask);
-            const uint32_t h = ex >> a.lo_bits;
-            if (h) tw = Fr::mul(tw, load_u256(a.tw_hi, h));
-            v = Fr::mul(v, tw);
+            if (a.tw_full) {   // one coalesced 32-byte read in exactly the order this pass stores
+                v = Fr::mul(v, load_u256(a.tw_full, ((size_t)row << cols_log) + m0 + col));
+            } else {
+                u256 tw = load_u256(a.tw_lo, ex & lomask);
+                const uint32_t h = ex >> a.lo_bits;
+                if (h) tw = Fr::mul(tw, load_u256(a.tw_hi, h));
+                v = Fr::mul(v, tw);
+            }
         }
         store_u256(a.dst, base + ((size_t)row << cols_log) + col, v);
     }
@@ -136,6 +145,7 @@ ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
 // row goes to out[j1 + Q * (jm + P * row)] — the digit reversal that restores natural order.
 ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
     ZK_DYN_SHARED(uint4, smem);
+    if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
     const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
     uint4* lo = smem;
     uint4* hi = smem + tile;
@@ -166,6 +176,18 @@ ZK_KERNEL void fr_pow_table_kernel(u256 base, uint32_t count, void* out) {
         if ((k >> b) & 1) acc = Fr::mul(acc, base);
     }
     store_u256(out, k, acc);
+}
+
+// full inter-pass twiddle table of a non-final pass: out[row * cols + m] = omega^((m * row) << sh)
+ZK_KERNEL void ntt_full_twiddle_kernel(const void* tw_lo, const void* tw_hi, uint32_t lo_bits, uint32_t cols_log, uint32_t r, uint32_t sh, void* out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << (cols_log + r))) return;
+    const uint32_t m = (uint32_t)(i & (((size_t)1 << cols_log) - 1)), row = (uint32_t)(i >> cols_log);
+    const uint32_t ex = (m * row) << sh;
+    u256 tw = load_u256(tw_lo, ex & ((1u << lo_bits) - 1));
+    const uint32_t h = ex >> lo_bits;
+    if (h) tw = Fr::mul(tw, load_u256(tw_hi, h));
+    store_u256(out, i, tw);
 }
 
 // element-wise helpers ---------------------------------------------------------------------------
@@ -222,7 +244,7 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleS
     plan_passes(log_n, ctx->tune, rl, &passes);
     for (auto& t : ctx->twiddles)
         if (t.log_n == log_n && Fr::eq(t.omega, omega) && t.passes == passes && t.radix_log[0] == rl[0] && t.radix_log[1] == rl[1] &&
-            t.radix_log[2] == rl[2]) { *out = &t; return ZK_OK; }
+            t.radix_log[2] == rl[2] && (t.d_full[0] != nullptr) == (passes > 1 && (int)log_n <= ctx->tune.ntt_full_twiddle_max_log)) { *out = &t; return ZK_OK; }
     TwiddleSet ts;
     ts.log_n = log_n; ts.omega = omega; ts.passes = passes;
     for (int i = 0; i < 3; i++) ts.radix_log[i] = rl[i];
@@ -241,6 +263,18 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleS
         ZK_LAUNCH(fr_pow_table_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, fr_pow2k_host(omega, log_n - rl[i]), half, ts.d_stage[i]);
         ZK_CHECK_LAUNCH();
     }
+    if ((int)log_n <= ctx->tune.ntt_full_twiddle_max_log) {
+        uint32_t blk_log = log_n;
+        for (int i = 0; i + 1 < passes; i++) {
+            const uint32_t cols_log = blk_log - rl[i];
+            const size_t cnt = (size_t)1 << blk_log;
+            ZK_HIP(hipMalloc(&ts.d_full[i], cnt * 32));
+            ZK_LAUNCH(ntt_full_twiddle_kernel, (uint32_t)((cnt + blk - 1) / blk), blk, 0, ctx->stream, (const void*)ts.d_lo, (const void*)ts.d_hi, ts.lo_bits,
+                      cols_log, rl[i], log_n - blk_log, ts.d_full[i]);
+            ZK_CHECK_LAUNCH();
+            blk_log -= rl[i];
+        }
+    }
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->twiddles.push_back(ts);
     *out = &ctx->twiddles.back();
@@ -251,7 +285,7 @@ void release_twiddles(zk_ctx* ctx) {
     for (auto& t : ctx->twiddles) {
         if (t.d_lo) (void)hipFree(t.d_lo);
         if (t.d_hi) (void)hipFree(t.d_hi);
-        for (int i = 0; i < 3; i++) if (t.d_stage[i]) (void)hipFree(t.d_stage[i]);
+        for (int i = 0; i < 3; i++) { if (t.d_stage[i]) (void)hipFree(t.d_stage[i]); if (t.d_full[i]) (void)hipFree(t.d_full[i]); }
     }
     ctx->twiddles.clear();
 }
@@ -264,19 +298,24 @@ int ntt_set_lds_attr() {
     return 0;
 }
 
-// In-place (on d_a) natural-order NTT of 2^log_n elements; fuse may redirect the input.
-int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const NttFuse* fuse) {
-    if (!d_a) return ctx->fail(ZK_ERR_ARG, "zk_ntt: null pointer");
+// In-place natural-order NTT of `count` columns of 2^log_n elements (h_cols: host array of device pointers).
+// h_srcs (optional, fused forms): read column i from h_srcs[i] instead of h_cols[i].
+int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, size_t count, uint32_t log_n, const u256& omega, const NttFuse* fuse) {
+    if (!h_cols || count == 0) return count == 0 ? ZK_OK : ctx->fail(ZK_ERR_ARG, "zk_ntt: null pointer");
     if (log_n > 27) return ctx->fail(ZK_ERR_LIMIT, "zk_ntt: log_n = %u > 27", log_n);
+    if (count > 65535) return ctx->fail(ZK_ERR_LIMIT, "zk_ntt batch: more than 65535 columns");
+    for (size_t i = 0; i < count; i++) if (!h_cols[i] || (h_srcs && !h_srcs[i])) return ctx->fail(ZK_ERR_ARG, "zk_ntt: null column pointer");
     const size_t N = (size_t)1 << log_n;
     NttFuse nf;
     if (fuse) nf = *fuse;
-    const void* src0 = nf.src ? nf.src : d_a;
     if (log_n == 0) {
-        if (src0 != d_a) ZK_HIP(hipMemcpyAsync(d_a, src0, 32, hipMemcpyDeviceToDevice, ctx->stream));
-        if (nf.post_scale) {
-            ZK_LAUNCH(fr_vec_kernel, 1, 64, 0, ctx->stream, 3, (const void*)d_a, (const void*)d_a, d_a, (size_t)1, nf.scale);
-            ZK_CHECK_LAUNCH();
+        for (size_t i = 0; i < count; i++) {
+            const void* s0 = h_srcs ? h_srcs[i] : h_cols[i];
+            if (s0 != h_cols[i]) ZK_HIP(hipMemcpyAsync(h_cols[i], s0, 32, hipMemcpyDeviceToDevice, ctx->stream));
+            if (nf.post_scale) {
+                ZK_LAUNCH(fr_vec_kernel, 1, 64, 0, ctx->stream, 3, (const void*)h_cols[i], (const void*)h_cols[i], h_cols[i], (size_t)1, nf.scale);
+                ZK_CHECK_LAUNCH();
+            }
         }
         return ZK_OK;
     }
@@ -285,20 +324,44 @@ int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const Ntt
     if (rc) return rc;
     const Tune& tn = ctx->tune;
     const uint32_t tl = (uint32_t)tn.ntt_tile_log;
-    ZK_HIP(ctx->ws_ntt.ensure(N * 32));
-    void* tmp = ctx->ws_ntt.p;
+    for (int p = 0; p < ts->passes; p++) if (ts->radix_log[p] > tl) return ctx->fail(ZK_ERR_ARG, "zk_ntt: radix 2^%u exceeds the LDS tile 2^%u", ts->radix_log[p], tl);
+    ZK_HIP(ctx->ws_ntt.ensure(count * N * 32 + 3 * count * sizeof(void*) + 64));
+    char* tmp_base = (char*)ctx->ws_ntt.p;
+    // device pointer tables: [src0 | tmp | dst]
+    const bool batch = count > 1;
+    const void** d_src0 = nullptr; void** d_tmp = nullptr; void** d_dst = nullptr;
+    if (batch) {
+        std::vector<const void*> tab(3 * count);
+        for (size_t i = 0; i < count; i++) {
+            tab[i] = h_srcs ? h_srcs[i] : h_cols[i];
+            tab[count + i] = tmp_base + i * N * 32;
+            tab[2 * count + i] = h_cols[i];
+        }
+        char* dtab = tmp_base + ((count * N * 32 + 15) & ~(size_t)15);
+        ZK_HIP(hipMemcpyAsync(dtab, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));   // tab is a stack object
+        d_src0 = (const void**)dtab; d_tmp = (void**)dtab + count; d_dst = (void**)dtab + 2 * count;
+    }
+    const void* src0 = h_srcs ? h_srcs[0] : h_cols[0];
+    void* d_a = h_cols[0];
+    void* tmp = tmp_base;
     const int P = ts->passes;
-    // data flow: pass 0 reads src0; intermediate passes live in tmp; the final pass writes d_a.
+    // data flow: pass 0 reads src0; intermediate passes live in tmp; the final pass writes the column.
     uint32_t blk_log = log_n;
     for (int p = 0; p < P; p++) {
         NttPassArgs a;
         memset(&a, 0, sizeof a);
         const bool first = p == 0, last = p == P - 1;
+        bool via_tmp = false;
         a.src = first ? src0 : tmp;
         a.dst = last ? d_a : tmp;
-        if (first && last && src0 == d_a) a.dst = tmp;  // single pass cannot scatter in place
+        if (first && last && !h_srcs) { a.dst = tmp; via_tmp = true; }   // a single pass cannot scatter in place
+        if (batch) {
+            a.srcs = first ? (const void* const*)d_src0 : (const void* const*)d_tmp;
+            a.dsts = (last && !via_tmp) ? (void* const*)d_dst : (void* const*)d_tmp;
+        }
         a.log_n = log_n; a.blk_log = blk_log; a.r = ts->radix_log[p];
-        a.stage_tw = ts->d_stage[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits;
+        a.stage_tw = ts->d_stage[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits; a.tw_full = last ? nullptr : ts->d_full[p];
         if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; }
         if (last) { a.post_scale = nf.post_scale; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
         const uint32_t room = tl > a.r ? tl - a.r : 0;
@@ -307,7 +370,7 @@ int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const Ntt
             a.c_log = room < cols_log ? room : cols_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
             const size_t lds = ((size_t)32 << (a.r + a.c_log));
-            ZK_LAUNCH(ntt_strided_pass_kernel, grid, tn.ntt_threads, lds, ctx->stream, a);
+            ZK_LAUNCH(ntt_strided_pass_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();
         } else {
             // o = j1 * Pm + jm with j1 the digit of pass 0 (Q = R_0) and jm the digit of pass 1 (if 3 passes)
@@ -316,13 +379,21 @@ int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const Ntt
             a.c_log = room < a.q_log ? room : a.q_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
             const size_t lds = ((size_t)32 << (a.r + a.c_log));
-            ZK_LAUNCH(ntt_final_pass_kernel, grid, tn.ntt_threads, lds, ctx->stream, a);
+            ZK_LAUNCH(ntt_final_pass_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();
-            if (a.dst != d_a) ZK_HIP(hipMemcpyAsync(d_a, a.dst, N * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            if (via_tmp)
+                for (size_t i = 0; i < count; i++)
+                    ZK_HIP(hipMemcpyAsync(h_cols[i], tmp_base + i * N * 32, N * 32, hipMemcpyDeviceToDevice, ctx->stream));
         }
         blk_log -= a.r;
     }
     return ZK_OK;
+}
+int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const NttFuse* fuse) {
+    if (!d_a) return ctx->fail(ZK_ERR_ARG, "zk_ntt: null pointer");
+    void* cols[1] = {d_a};
+    const void* srcs[1] = {fuse && fuse->src ? fuse->src : d_a};
+    return ntt_dev_batch(ctx, cols, (fuse && fuse->src) ? srcs : nullptr, 1, log_n, omega, fuse);
 }
 
 // ---- EvaluationDomain constants (host, Fr arithmetic of field.cuh compiled for the CPU) ---------
@@ -347,6 +418,18 @@ int domain_lagrange_to_coeff(zk_ctx* ctx, void* d_a, uint32_t k) {
     NttFuse f;
     f.post_scale = 1; f.scale = fr_two_inv_pow(k);
     return ntt_dev(ctx, d_a, k, Fr::inv(domain_omega(k)), &f);
+}
+int domain_lagrange_to_coeff_batch(zk_ctx* ctx, void* const* cols, size_t count, uint32_t k) {
+    if (k > BN254_FR_S) return ctx->fail(ZK_ERR_ARG, "k = %u > S", k);
+    NttFuse f;
+    f.post_scale = 1; f.scale = fr_two_inv_pow(k);
+    return ntt_dev_batch(ctx, cols, nullptr, count, k, Fr::inv(domain_omega(k)), &f);
+}
+int domain_coeff_to_extended_batch(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek) {
+    if (ek > BN254_FR_S || k > ek || !coeffs || !outs) return ctx->fail(ZK_ERR_ARG, "zk_coeff_to_extended: bad k/extended_k/pointer");
+    NttFuse f;
+    f.n_valid = 1u << k; f.pre_zeta = 1;
+    return ntt_dev_batch(ctx, outs, coeffs, count, ek, domain_omega(ek), &f);
 }
 int domain_coeff_to_lagrange(zk_ctx* ctx, void* d_a, uint32_t k) {
     if (k > BN254_FR_S) return ctx->fail(ZK_ERR_ARG, "k = %u > S", k);

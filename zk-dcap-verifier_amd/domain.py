@@ -62,6 +62,8 @@ class EvaluationDomain:
 
     # device-resident forms ---------------------------------------------------------------------
     def lagrange_to_coeff_dev(self, a_dev): self.backend.lagrange_to_coeff_dev(a_dev, self.k)
+    def lagrange_to_coeff_batch_dev(self, cols): self.backend.lagrange_to_coeff_batch_dev(cols, self.k)
+    def coeff_to_extended_batch_dev(self, coeffs, outs): self.backend.coeff_to_extended_batch_dev(coeffs, outs, self.k, self.extended_k)
     def coeff_to_extended_dev(self, coeff_dev, out_dev): self.backend.coeff_to_extended_dev(coeff_dev, self.k, self.extended_k, out_dev)
     def extended_to_coeff_dev(self, a_dev): self.backend.extended_to_coeff_dev(a_dev, self.k, self.extended_k)
     def divide_by_vanishing_poly_dev(self, a_dev): self.backend.divide_by_vanishing_poly_dev(a_dev, self.k, self.extended_k)

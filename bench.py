@@ -243,8 +243,12 @@ def main(argv=None):
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # RCCL over xGMI
+        else:                                                                             # CPU plumbing test only
+            dist.init_process_group("gloo")
+    tdev = "cuda" if torch.cuda.is_available() else "cpu"
     import zk_dcap_verifier_amd as z
     be = z.Backend(local)                      # raises if the HIP library / GPU is missing: no CPU path
     assert "gfx950" in be.version() or os.environ.get("ZK_BENCH_PLUMBING_TEST") == "1"
@@ -257,7 +261,8 @@ def main(argv=None):
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         wl.step()
@@ -275,7 +280,7 @@ def main(argv=None):
     be_stats = {"msm_columns": be.stat_get("msm_columns"), "msm_pairs": be.stat_get("msm_pairs")}
     be.timing(False)
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
@@ -339,7 +344,7 @@ def main(argv=None):
     if world > 1 and not args.no_extras:
         # MSM with the base table sharded over the ranks: partial XYZZ points all-gathered over RCCL/xGMI
         try:
-            logn = 24
+            logn = int(os.environ.get("ZK_BENCH_SHARDED_LOG_N", "24"))
             n_loc = (1 << logn) // world
             ks = be.to_device(rand_fr(n_loc, 31 + rank))
             pts = be.alloc(n_loc * 64)
@@ -347,11 +352,11 @@ def main(argv=None):
             h = be.bases_register((pts, n_loc))
             pts.free()
             ks.upload(rand_fr(n_loc, 77 + rank))
-            gather = [torch.zeros(16, dtype=torch.int64, device="cuda") for _ in range(world)]
+            gather = [torch.zeros(16, dtype=torch.int64, device=tdev) for _ in range(world)]
 
             def sharded():
                 part = be.msm_partial(h, ks, n_loc)
-                mine = torch.from_numpy(part.view(np.int64)).cuda()
+                mine = torch.from_numpy(part.view(np.int64).copy()).to(tdev)
                 dist.all_gather(gather, mine)
                 parts = torch.stack(gather).cpu().numpy().view(np.uint64)
                 return be.g1_sum_xyzz(parts)
@@ -362,7 +367,7 @@ def main(argv=None):
                 sharded()
             barrier()
             ds = (time.time() - t) / 3
-            extra["msm_sharded_2^24"] = {"ranks": world, "ms": round(ds * 1e3, 3), "Mscalar_per_s": round((1 << logn) / ds / 1e6, 2)}
+            extra[f"msm_sharded_2^{logn}"] = {"ranks": world, "ms": round(ds * 1e3, 3), "Mscalar_per_s": round((1 << logn) / ds / 1e6, 2)}
             be.bases_release(h)
             ks.free()
         except Exception as e:

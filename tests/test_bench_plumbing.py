@@ -33,3 +33,39 @@ def test_bench_emits_contract_json(built, capsys, monkeypatch):
     assert line["unit"] == "proofs/hour" and line["n_gpus"] == 1 and "workload" in line["config"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in line["roofline"]
+
+
+def _bench_rank(rank, world, port, out_dir):
+    import io
+    import contextlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      ZK_BENCH_PLUMBING_TEST="1", ZK_BENCH_SHARDED_LOG_N="7")
+    sys.path.insert(0, ROOT)
+    import zk_dcap_verifier_amd as z
+    import bench
+    z._lib.LIB_PATH = EMU_SO
+    real_init = z.Backend.__init__
+
+    def small_init(self, device=0, lib_path=None):
+        real_init(self, device, lib_path)
+        self.tune(msm_sort_threads=32, msm_sort_wgs=2, msm_block=32, ntt_threads=32, ntt_tile_log=6, ntt_max_radix_log=4,
+                  msm_target_threads=64, msm_min_chunk=2, vec_block=32, quot_threads=32)
+    z.Backend.__init__ = small_init
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "0", "--k", "4", "--advice", "2", "--fixed", "2", "--lookups", "1",
+                    "--perm-columns", "2", "--degree", "4"])
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(buf.getvalue())
+
+
+def test_bench_two_ranks_gloo(built, tmp_path):
+    """The N > 1 launch path of bench.py (barrier, max-over-ranks timing, sharded MSM + all_gather) with two
+    gloo ranks on the emulator; rank 0 alone prints the JSON line."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_bench_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out0 = open(tmp_path / "rank0.txt").read().strip().splitlines()
+    line = json.loads(out0[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "msm_sharded_2^7" in line["extra"], line["extra"]
+    assert open(tmp_path / "rank1.txt").read().strip() == ""

@@ -22,7 +22,7 @@ struct Tune {
     int msm_min_chunk = 16;      // min pairs per accumulate thread
     int msm_max_chunk = 32;        // fixed-size sub-buckets keep all 64 lanes of a wave equally loaded (profiles/r01)
     int msm_merge_fanin = 8;
-    int msm_tree_fanin = 4;
+    int msm_tree_fanin = 2;
     int msm_block = 128;         // threads per workgroup of the curve-arithmetic kernels
     int ntt_tile_log = 10;       // log2(elements) of the LDS tile of one NTT workgroup (sweep: profiles/r01/run6_ntt_plan_sweep.txt)
     int ntt_threads = 512;

@@ -124,6 +124,21 @@ int zk_fr_scale_dev(zk_ctx* ctx, const void* a, const void* scalar_host, void* o
 /* Fq flavour of mul (used by the parity tests of the curve field) */
 int zk_fq_mul_dev(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n);
 
+/* ---- grand products (SURVEY 8f "next 1") ------------------------------------------------------ *
+ * halo2_proofs src/plonk/permutation/prover.rs Argument::commit — the row loops of ONE column set:
+ *   z[0] = z_init;  z[i+1] = z[i] * prod_j (v_j[i] + delta^(j0+j) beta omega^i + gamma) / prod_j (v_j[i] + beta sigma_j[i] + gamma)
+ *   rows [n - blinding_factors, n) <- blinding (HOST, the caller's Fr::random draws);  *last_z_out = z[n - blinding_factors - 1]
+ * values / sigmas: HOST arrays of `count` DEVICE columns (Lagrange basis, n = 2^k rows); delta_start = DELTA^(j0) with j0 the index of
+ * the set's first column in cs.permutation.columns; beta, gamma, delta_start, z_init, last_z_out: HOST 32 B.  z_dev: DEVICE n x 32 B. */
+int zk_permutation_product_dev(zk_ctx* ctx, const void* const* values, const void* const* sigmas, size_t count, uint32_t k, const void* beta,
+                               const void* gamma, const void* delta_start, const void* z_init, const void* blinding, uint32_t blinding_factors,
+                               void* z_dev, void* last_z_out);
+/* halo2_proofs src/plonk/lookup/prover.rs Permuted::commit_product:
+ *   z[0] = 1;  z[i+1] = z[i] * (cin[i] + beta)(ctab[i] + gamma) / ((pin[i] + beta)(ptab[i] + gamma));  last rows <- blinding */
+int zk_lookup_product_dev(zk_ctx* ctx, const void* compressed_input, const void* compressed_table, const void* permuted_input,
+                          const void* permuted_table, uint32_t k, const void* beta, const void* gamma, const void* blinding,
+                          uint32_t blinding_factors, void* z_dev);
+
 /* ---- quotient: replaces plonk::evaluation::Evaluator::evaluate_h ---------------------------- *
  * halo2_proofs src/plonk/evaluation.rs.  The compiled GraphEvaluator of a proving key is uploaded
  * once as a "ZKQ1" blob (layout in DESIGN.md / INTEGRATION.md), then run per proof on

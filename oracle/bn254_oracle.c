@@ -441,4 +441,50 @@ void orc_eval_polynomial(const fe *poly, size_t n, const fe *x, fe *out) {
     *out = acc;
 }
 
+/* ------------------------------------------------ grand products */
+/* halo2_proofs src/plonk/permutation/prover.rs Argument::commit, the body of ONE column set:
+ * modified_values = prod_j (beta*sigma_j + gamma + v_j); batch_invert; *= prod_j (deltaomega_j*beta + gamma + v_j)
+ * with deltaomega_j = delta^(j0+j) * omega^row; z[0] = last_z, z[row] = z[row-1]*modified[row-1];
+ * z[n-blinding..] = randomness (drawn by the caller here).  delta_start = delta^(j0) (Montgomery). */
+void orc_permutation_product(const fe *const *values, const fe *const *sigmas, size_t count, uint32_t k, const fe *beta, const fe *gamma,
+                             const fe *delta_start, const fe *last_z, const fe *blinding, uint32_t blinding_factors, fe *z, fe *last_z_out) {
+    size_t n = (size_t)1 << k;
+    fe *mv = malloc(n * sizeof(fe)), *inv = malloc(n * sizeof(fe));
+    for (size_t i = 0; i < n; i++) mv[i] = FR.r;
+    for (size_t j = 0; j < count; j++)
+        for (size_t i = 0; i < n; i++) { fe t; f_mul(&FR, &t, beta, &sigmas[j][i]); f_add(&FR, &t, &t, gamma); f_add(&FR, &t, &t, &values[j][i]); f_mul(&FR, &mv[i], &mv[i], &t); }
+    /* batch_invert (zero stays zero) */
+    { fe acc = FR.r; for (size_t i = 0; i < n; i++) { inv[i] = acc; if (!fe_is_zero(&mv[i])) f_mul(&FR, &acc, &acc, &mv[i]); }
+      fe ai; f_inv(&FR, &ai, &acc);
+      for (size_t i = n; i-- > 0;) { if (fe_is_zero(&mv[i])) continue; fe t; f_mul(&FR, &t, &ai, &inv[i]); f_mul(&FR, &ai, &ai, &mv[i]); mv[i] = t; } }
+    fe omega; omega_for(&omega, k);
+    fe delta = { BN254_FR_DELTA_M }, deltaomega0 = *delta_start;
+    for (size_t j = 0; j < count; j++) {
+        fe dw = deltaomega0;
+        for (size_t i = 0; i < n; i++) { fe t; f_mul(&FR, &t, &dw, beta); f_add(&FR, &t, &t, gamma); f_add(&FR, &t, &t, &values[j][i]); f_mul(&FR, &mv[i], &mv[i], &t); f_mul(&FR, &dw, &dw, &omega); }
+        f_mul(&FR, &deltaomega0, &deltaomega0, &delta);
+    }
+    z[0] = *last_z;
+    for (size_t row = 1; row < n; row++) f_mul(&FR, &z[row], &z[row - 1], &mv[row - 1]);
+    for (uint32_t b = 0; b < blinding_factors; b++) z[n - blinding_factors + b] = blinding[b];
+    if (last_z_out) *last_z_out = z[n - (blinding_factors + 1)];
+    free(mv); free(inv);
+}
+/* halo2_proofs src/plonk/lookup/prover.rs Permuted::commit_product */
+void orc_lookup_product(const fe *cin, const fe *ctab, const fe *pin, const fe *ptab, uint32_t k, const fe *beta, const fe *gamma,
+                        const fe *blinding, uint32_t blinding_factors, fe *z) {
+    size_t n = (size_t)1 << k;
+    fe *lp = malloc(n * sizeof(fe)), *pre = malloc(n * sizeof(fe));
+    for (size_t i = 0; i < n; i++) { fe a, b; f_add(&FR, &a, beta, &pin[i]); f_add(&FR, &b, gamma, &ptab[i]); f_mul(&FR, &lp[i], &a, &b); }
+    { fe acc = FR.r; for (size_t i = 0; i < n; i++) { pre[i] = acc; if (!fe_is_zero(&lp[i])) f_mul(&FR, &acc, &acc, &lp[i]); }
+      fe ai; f_inv(&FR, &ai, &acc);
+      for (size_t i = n; i-- > 0;) { if (fe_is_zero(&lp[i])) continue; fe t; f_mul(&FR, &t, &ai, &pre[i]); f_mul(&FR, &ai, &ai, &lp[i]); lp[i] = t; } }
+    for (size_t i = 0; i < n; i++) { fe a, b; f_add(&FR, &a, &cin[i], beta); f_add(&FR, &b, &ctab[i], gamma); f_mul(&FR, &lp[i], &lp[i], &a); f_mul(&FR, &lp[i], &lp[i], &b); }
+    fe state = FR.r;
+    size_t keep = n - blinding_factors;
+    for (size_t i = 0; i < keep; i++) { if (i > 0) f_mul(&FR, &state, &state, &lp[i - 1]); z[i] = state; }   /* once(1).chain(lp).scan */
+    for (uint32_t b = 0; b < blinding_factors; b++) z[keep + b] = blinding[b];
+    free(lp); free(pre);
+}
+
 #include "evaluate_h_oracle.inc"

@@ -244,3 +244,27 @@ def evaluate_h(blob: bytes, fixed, advice, instance, l0, l_last, l_active_row, p
     if rc:
         raise ValueError("bad program blob")
     return values
+
+
+def permutation_product(values, sigmas, k, beta, gamma, delta_start, last_z, blinding):
+    """One column set of permutation::Argument::commit -> (z (n,4), last_z (4,))."""
+    keep = []
+    def pa(cols):
+        arr, c = _ptr_array(cols); keep.append(c); return arr
+    n = 1 << k
+    z = np.empty((n, 4), dtype=np.uint64); last = np.empty(4, dtype=np.uint64)
+    bl = np.ascontiguousarray(np.asarray(blinding, dtype=np.uint64).reshape(-1, 4))
+    sc = [_fe(np.asarray(v).reshape(4)) for v in (beta, gamma, delta_start, last_z)]
+    lib().orc_permutation_product(pa(values), pa(sigmas), C.c_size_t(len(values)), C.c_uint32(k), _p(sc[0]), _p(sc[1]), _p(sc[2]), _p(sc[3]),
+                                  _p(bl), C.c_uint32(bl.shape[0]), _p(z), _p(last))
+    return z, last
+
+
+def lookup_product(cin, ctab, pin, ptab, k, beta, gamma, blinding):
+    n = 1 << k
+    z = np.empty((n, 4), dtype=np.uint64)
+    bl = np.ascontiguousarray(np.asarray(blinding, dtype=np.uint64).reshape(-1, 4))
+    sc = [_fe(np.asarray(v).reshape(4)) for v in (beta, gamma)]
+    lib().orc_lookup_product(_p(_fe(cin)), _p(_fe(ctab)), _p(_fe(pin)), _p(_fe(ptab)), C.c_uint32(k), _p(sc[0]), _p(sc[1]), _p(bl),
+                             C.c_uint32(bl.shape[0]), _p(z))
+    return z

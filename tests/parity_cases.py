@@ -174,3 +174,37 @@ def check_fixed_base(be, orc, pyref, n, seed=61):
         assert (got[i] == want).all(), i
     ds.free()
     dout.free()
+
+
+def check_concurrent_callers(be, orc, pyref, n=200, threads=4):
+    """The C ABI promises thread safety (rayon workers may call commit concurrently): hammer one context
+    from several Python threads (ctypes releases the GIL) and check every result."""
+    import threading
+    sc, bases = msm_inputs(orc, pyref, n, 77)
+    h = z.arithmetic.BasesHandle(be, bases)
+    want_msm = orc.g1_to_affine(orc.best_multiexp(sc, bases))[0]
+    log_n = 6
+    a = rand_fr(orc, pyref, 1 << log_n, 78)
+    w = orc.fr_from_ints([pyref.omega(log_n)])[0]
+    want_ntt = orc.best_fft(a, w, log_n)
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(3):
+                if i % 2 == 0:
+                    got = z.arithmetic.best_multiexp(sc, h)
+                    assert (got[:8] == want_msm).all()
+                else:
+                    b = a.copy()
+                    z.arithmetic.best_fft(b, w, log_n, backend=be)
+                    assert (b == want_ntt).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    h.release()
+    assert not errors, errors

@@ -89,3 +89,7 @@ def test_error_paths(emu, orc, pyref):
     h.release()
     with pytest.raises(AssertionError):
         z.arithmetic.best_multiexp(sc[:3], bases)                   # halo2: assert_eq!(coeffs.len(), bases.len())
+
+
+def test_concurrent_callers(emu, orc, pyref):
+    pc.check_concurrent_callers(emu, orc, pyref, n=60, threads=3)

@@ -128,3 +128,7 @@ def test_ntt_roundtrip_2p20_and_spot_values(gpu, orc, pyref):
     back = d.download((n, 4))
     assert (back == orc.fr_mul(a, np.repeat(orc.fr_from_ints([n]), n, axis=0))).all()
     d.free()
+
+
+def test_concurrent_callers(gpu, orc, pyref):
+    pc.check_concurrent_callers(gpu, orc, pyref, n=5000, threads=6)

@@ -264,6 +264,24 @@ class Backend:
         s = self._fe(scalar)
         self._ck(self.lib.zk_fr_scale_dev(self.ctx, C.c_void_p(_dptr(a)), s.ctypes.data_as(C.c_void_p), C.c_void_p(_dptr(out)), C.c_size_t(n)))
 
+    # -- grand products ------------------------------------------------------------------------
+    def permutation_product_dev(self, values, sigmas, k, beta, gamma, delta_start, z_init, blinding, z_dev) -> np.ndarray:
+        bl = np.ascontiguousarray(np.asarray(blinding, dtype=np.uint64).reshape(-1, 4))
+        sc = [self._fe(v) for v in (beta, gamma, delta_start, z_init)]
+        last = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.zk_permutation_product_dev(self.ctx, self._ptr_array(values), self._ptr_array(sigmas), C.c_size_t(len(values)), C.c_uint32(k),
+                                                     sc[0].ctypes.data_as(C.c_void_p), sc[1].ctypes.data_as(C.c_void_p), sc[2].ctypes.data_as(C.c_void_p),
+                                                     sc[3].ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p), C.c_uint32(bl.shape[0]),
+                                                     C.c_void_p(_dptr(z_dev)), last.ctypes.data_as(C.c_void_p)))
+        return last
+
+    def lookup_product_dev(self, cin, ctab, pin, ptab, k, beta, gamma, blinding, z_dev):
+        bl = np.ascontiguousarray(np.asarray(blinding, dtype=np.uint64).reshape(-1, 4))
+        sc = [self._fe(v) for v in (beta, gamma)]
+        self._ck(self.lib.zk_lookup_product_dev(self.ctx, C.c_void_p(_dptr(cin)), C.c_void_p(_dptr(ctab)), C.c_void_p(_dptr(pin)), C.c_void_p(_dptr(ptab)),
+                                                C.c_uint32(k), sc[0].ctypes.data_as(C.c_void_p), sc[1].ctypes.data_as(C.c_void_p),
+                                                bl.ctypes.data_as(C.c_void_p), C.c_uint32(bl.shape[0]), C.c_void_p(_dptr(z_dev))))
+
     # -- quotient -------------------------------------------------------------------------------
     def quotient_program_load(self, blob: bytes) -> int:
         h = C.c_uint64()

@@ -15,6 +15,10 @@ int domain_coeff_to_extended(zk_ctx* ctx, const void* d_coeff, uint32_t k, uint3
 int domain_extended_to_coeff(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek);
 int domain_divide_by_vanishing(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek);
 int fr_vec_op(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n, const u256* scalar);
+int permutation_product(zk_ctx* ctx, const void* const* values, const void* const* sigmas, size_t count, uint32_t k, const void* beta, const void* gamma,
+                        const void* delta_start, const void* z_init, const void* blinding, uint32_t bf, void* d_z, void* h_last_z);
+int lookup_product(zk_ctx* ctx, const void* cin, const void* ctab, const void* pin, const void* ptab, uint32_t k, const void* beta, const void* gamma,
+                   const void* blinding, uint32_t bf, void* d_z);
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
@@ -213,6 +217,17 @@ int zk_fr_scale_dev(zk_ctx* ctx, const void* a, const void* s, void* o, size_t n
     u256 sc = load_host_fr(s); return vec_sync(ctx, fr_vec_op(ctx, 3, a, nullptr, o, n, &sc));
 }
 int zk_fq_mul_dev(zk_ctx* ctx, const void* a, const void* b, void* o, size_t n) { ENTER; return vec_sync(ctx, fr_vec_op(ctx, 4, a, b, o, n, nullptr)); }
+
+// ---- grand products -----------------------------------------------------------------------------
+int zk_permutation_product_dev(zk_ctx* ctx, const void* const* values, const void* const* sigmas, size_t count, uint32_t k, const void* beta,
+                               const void* gamma, const void* delta_start, const void* z_init, const void* blinding, uint32_t blinding_factors,
+                               void* z_dev, void* last_z_out) {
+    ENTER; return permutation_product(ctx, values, sigmas, count, k, beta, gamma, delta_start, z_init, blinding, blinding_factors, z_dev, last_z_out);
+}
+int zk_lookup_product_dev(zk_ctx* ctx, const void* cin, const void* ctab, const void* pin, const void* ptab, uint32_t k, const void* beta,
+                          const void* gamma, const void* blinding, uint32_t blinding_factors, void* z_dev) {
+    ENTER; return lookup_product(ctx, cin, ctab, pin, ptab, k, beta, gamma, blinding, blinding_factors, z_dev);
+}
 
 // ---- quotient -----------------------------------------------------------------------------------
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog) { ENTER; return quotient_program_load(ctx, blob, len, prog); }

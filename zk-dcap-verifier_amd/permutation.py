@@ -1,0 +1,46 @@
+"""halo2_proofs::plonk::{permutation, lookup}::prover grand products, MI355X edition (SURVEY.md §8f "next 1").
+
+Mirrors (halo2_proofs 0.2.0 @ zkwebauthn c254c75) src/plonk/permutation/prover.rs `Argument::commit` and
+src/plonk/lookup/prover.rs `Permuted::commit_product`, reached from the reference through create_proof
+(circuits/src/sgx_dcap_verifier.rs:814-822).  Columns stay in HBM: the returned z buffers go straight into
+`commit_lagrange` (zk_msm) and `lagrange_to_coeff`."""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import Backend, default_backend
+
+DELTA = 0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2   # Fr::DELTA = 7^(2^28)
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def _mont(x: int) -> np.ndarray:
+    v = (x << 256) % R_MOD
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def permutation_commit(columns, sigmas, k: int, cs_degree: int, beta, gamma, blinding_rows, backend: Backend | None = None):
+    """All column sets of the permutation argument.
+
+    columns / sigmas: device buffers (Lagrange basis) in cs.permutation.columns order; blinding_rows[s]: the
+    `blinding_factors` random rows of set s (the caller's RNG draws, so proofs stay reproducible under a seeded RNG).
+    Returns the list of z device buffers, one per set (chunks of cs_degree - 2 columns)."""
+    be = backend or default_backend()
+    chunk = cs_degree - 2
+    n = 1 << k
+    zs = []
+    last_z = _mont(1)
+    for s, lo in enumerate(range(0, len(columns), chunk)):
+        z = be.alloc(n * 32)
+        last_z = be.permutation_product_dev(columns[lo:lo + chunk], sigmas[lo:lo + chunk], k, beta, gamma, _mont(pow(DELTA, lo, R_MOD)), last_z,
+                                            blinding_rows[s], z)
+        zs.append(z)
+    return zs
+
+
+def lookup_commit_product(compressed_input, compressed_table, permuted_input, permuted_table, k: int, beta, gamma, blinding_rows,
+                          backend: Backend | None = None):
+    be = backend or default_backend()
+    z = be.alloc((1 << k) * 32)
+    be.lookup_product_dev(compressed_input, compressed_table, permuted_input, permuted_table, k, beta, gamma, blinding_rows, z)
+    return z

@@ -139,6 +139,13 @@ int zk_lookup_product_dev(zk_ctx* ctx, const void* compressed_input, const void*
                           const void* permuted_table, uint32_t k, const void* beta, const void* gamma, const void* blinding,
                           uint32_t blinding_factors, void* z_dev);
 
+/* ---- evaluation phase (SURVEY 8f "next 2") ----------------------------------------------------- *
+ * halo2_proofs src/arithmetic.rs eval_polynomial(poly, point): out[q] = polys[q](points[q]) for `count` queries of n coefficients
+ * each (a polynomial queried at several rotations appears several times).  polys: HOST array of DEVICE pointers; points, out: HOST. */
+int zk_eval_polynomial_batch_dev(zk_ctx* ctx, const void* const* polys_dev, size_t count, size_t n, const void* points, void* out);
+/* halo2_proofs src/arithmetic.rs kate_division(a, b): q(X) = (a(X) - a(b)) / (X - b); a: n coefficients, q: n - 1 (DEVICE); b: HOST 32 B */
+int zk_kate_division_dev(zk_ctx* ctx, const void* a_dev, size_t n, const void* b, void* q_dev);
+
 /* ---- quotient: replaces plonk::evaluation::Evaluator::evaluate_h ---------------------------- *
  * halo2_proofs src/plonk/evaluation.rs.  The compiled GraphEvaluator of a proving key is uploaded
  * once as a "ZKQ1" blob (layout in DESIGN.md / INTEGRATION.md), then run per proof on

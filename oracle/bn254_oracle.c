@@ -441,6 +441,17 @@ void orc_eval_polynomial(const fe *poly, size_t n, const fe *x, fe *out) {
     *out = acc;
 }
 
+/* halo2_proofs src/arithmetic.rs kate_division(a, b): quotient of a(X) by (X - b); q has n-1 coefficients */
+void orc_kate_division(const fe *a, size_t n, const fe *b, fe *q) {
+    fe nb; f_neg(&FR, &nb, b);
+    fe tmp; memset(&tmp, 0, sizeof tmp);
+    for (size_t i = n - 1; i >= 1; i--) {
+        fe lead; f_sub(&FR, &lead, &a[i], &tmp);
+        q[i - 1] = lead;
+        f_mul(&FR, &tmp, &lead, &nb);
+    }
+}
+
 /* ------------------------------------------------ grand products */
 /* halo2_proofs src/plonk/permutation/prover.rs Argument::commit, the body of ONE column set:
  * modified_values = prod_j (beta*sigma_j + gamma + v_j); batch_invert; *= prod_j (deltaomega_j*beta + gamma + v_j)

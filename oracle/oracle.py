@@ -268,3 +268,10 @@ def lookup_product(cin, ctab, pin, ptab, k, beta, gamma, blinding):
     lib().orc_lookup_product(_p(_fe(cin)), _p(_fe(ctab)), _p(_fe(pin)), _p(_fe(ptab)), C.c_uint32(k), _p(sc[0]), _p(sc[1]), _p(bl),
                              C.c_uint32(bl.shape[0]), _p(z))
     return z
+
+
+def kate_division(a, b_mont) -> np.ndarray:
+    a = _fe(a); b = _fe(np.asarray(b_mont).reshape(4))
+    q = np.empty((a.shape[0] - 1, 4), dtype=np.uint64)
+    lib().orc_kate_division(_p(a), C.c_size_t(a.shape[0]), _p(b), _p(q))
+    return q

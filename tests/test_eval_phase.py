@@ -1,0 +1,54 @@
+"""Evaluation phase: eval_polynomial and kate_division — oracle vs definition, product vs oracle."""
+import random
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+import zk_dcap_verifier_amd as z
+
+
+def test_oracle_kate_division_and_eval_match_definition(orc, pyref):
+    p, rnd = pyref, random.Random(8)
+    n, R = 37, p.R
+    a = [rnd.randrange(R) for _ in range(n)]
+    b = rnd.randrange(R)
+    M = orc.fr_from_ints
+    q = orc.fr_to_ints(orc.kate_division(M(a), M([b])[0]))
+    # (X - b) * q(X) + a(b) == a(X)
+    ab = p.poly_eval(a, b)
+    assert orc.fr_to_ints(orc.eval_polynomial(M(a), M([b])[0]).reshape(1, 4))[0] == ab
+    prod = [0] * n
+    for i, c in enumerate(q):
+        prod[i + 1] = (prod[i + 1] + c) % R
+        prod[i] = (prod[i] - b * c) % R
+    prod[0] = (prod[0] + ab) % R
+    assert prod == a
+
+
+def _check(be, orc, pyref, n, count, seed):
+    polys = [pc.rand_fr(orc, pyref, n, seed + i) for i in range(count)]
+    pts = pc.rand_fr(orc, pyref, count, seed + 100)
+    pts[0] = 0
+    if count > 1:
+        pts[1] = orc.fr_from_ints([1])[0]
+    d = [be.to_device(c) for c in polys]
+    got = be.eval_polynomial_batch_dev(d, n, pts)
+    for i in range(count):
+        assert (got[i] == orc.eval_polynomial(polys[i], pts[i])).all(), i
+    for dd in d:
+        dd.free()
+    if n >= 2:
+        assert (z.arithmetic.kate_division(polys[0], pts[-1], backend=be) == orc.kate_division(polys[0], pts[-1])).all()
+    assert (z.arithmetic.eval_polynomial(polys[0], pts[-1], backend=be) == orc.eval_polynomial(polys[0], pts[-1])).all()
+
+
+@pytest.mark.parametrize("n,count", [(1, 1), (2, 2), (100, 3), (4096, 2), (10000, 3)])
+def test_emulated_eval_phase(emu, orc, pyref, n, count):
+    _check(emu, orc, pyref, n, count, seed=n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,count", [(1, 1), (3, 2), (1 << 12, 5), (100003, 7), (1 << 19, 4)])
+def test_gpu_eval_phase(gpu, orc, pyref, n, count):
+    _check(gpu, orc, pyref, n, count, seed=n)

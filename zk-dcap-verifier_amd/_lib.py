@@ -282,6 +282,19 @@ class Backend:
                                                 C.c_uint32(k), sc[0].ctypes.data_as(C.c_void_p), sc[1].ctypes.data_as(C.c_void_p),
                                                 bl.ctypes.data_as(C.c_void_p), C.c_uint32(bl.shape[0]), C.c_void_p(_dptr(z_dev))))
 
+    # -- evaluation phase -----------------------------------------------------------------------
+    def eval_polynomial_batch_dev(self, polys, n: int, points) -> np.ndarray:
+        pts = np.ascontiguousarray(np.asarray(points, dtype=np.uint64).reshape(-1, 4))
+        assert pts.shape[0] == len(polys)
+        out = np.zeros((len(polys), 4), dtype=np.uint64)
+        self._ck(self.lib.zk_eval_polynomial_batch_dev(self.ctx, self._ptr_array(polys), C.c_size_t(len(polys)), C.c_size_t(n),
+                                                       pts.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def kate_division_dev(self, a_dev, n: int, b, q_dev):
+        bb = self._fe(b)
+        self._ck(self.lib.zk_kate_division_dev(self.ctx, C.c_void_p(_dptr(a_dev)), C.c_size_t(n), bb.ctypes.data_as(C.c_void_p), C.c_void_p(_dptr(q_dev))))
+
     # -- quotient -------------------------------------------------------------------------------
     def quotient_program_load(self, blob: bytes) -> int:
         h = C.c_uint64()

@@ -69,3 +69,26 @@ def best_multiexp_batch(columns, bases: BasesHandle) -> np.ndarray:
     independent, so the shim hands the whole phase to the GPU at once and the latency-bound bucket
     reduction is paid once per phase instead of once per column."""
     return bases.backend.msm_batch(bases.handle, list(columns))
+
+
+def eval_polynomial(poly: np.ndarray, point, backend: Backend | None = None) -> np.ndarray:
+    """halo2_proofs::arithmetic::eval_polynomial(poly, point) -> Fr (host array in, 4 limbs out)."""
+    be = backend or default_backend()
+    poly = np.ascontiguousarray(poly, dtype=np.uint64).reshape(-1, 4)
+    d = be.to_device(poly)
+    out = be.eval_polynomial_batch_dev([d], poly.shape[0], [point])[0]
+    d.free()
+    return out
+
+
+def kate_division(a: np.ndarray, b, backend: Backend | None = None) -> np.ndarray:
+    """halo2_proofs::arithmetic::kate_division(a, b): quotient of a(X) by (X - b), len(a) - 1 coefficients."""
+    be = backend or default_backend()
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    n = a.shape[0]
+    d, q = be.to_device(a), be.alloc(max(n - 1, 1) * 32)
+    be.kate_division_dev(d, n, b, q)
+    out = q.download((n - 1, 4))
+    d.free()
+    q.free()
+    return out

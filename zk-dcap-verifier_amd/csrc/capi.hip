@@ -19,6 +19,8 @@ int permutation_product(zk_ctx* ctx, const void* const* values, const void* cons
                         const void* delta_start, const void* z_init, const void* blinding, uint32_t bf, void* d_z, void* h_last_z);
 int lookup_product(zk_ctx* ctx, const void* cin, const void* ctab, const void* pin, const void* ptab, uint32_t k, const void* beta, const void* gamma,
                    const void* blinding, uint32_t bf, void* d_z);
+int eval_polynomial_batch(zk_ctx* ctx, const void* const* polys, size_t count, size_t n, const void* points, void* out);
+int kate_division(zk_ctx* ctx, const void* d_a, size_t n, const void* b_host, void* d_q);
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
@@ -228,6 +230,12 @@ int zk_lookup_product_dev(zk_ctx* ctx, const void* cin, const void* ctab, const 
                           const void* gamma, const void* blinding, uint32_t blinding_factors, void* z_dev) {
     ENTER; return lookup_product(ctx, cin, ctab, pin, ptab, k, beta, gamma, blinding, blinding_factors, z_dev);
 }
+
+// ---- evaluation phase ---------------------------------------------------------------------------
+int zk_eval_polynomial_batch_dev(zk_ctx* ctx, const void* const* polys, size_t count, size_t n, const void* points, void* out) {
+    ENTER; return eval_polynomial_batch(ctx, polys, count, n, points, out);
+}
+int zk_kate_division_dev(zk_ctx* ctx, const void* a_dev, size_t n, const void* b, void* q_dev) { ENTER; return kate_division(ctx, a_dev, n, b, q_dev); }
 
 // ---- quotient -----------------------------------------------------------------------------------
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog) { ENTER; return quotient_program_load(ctx, blob, len, prog); }

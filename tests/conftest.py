@@ -62,6 +62,9 @@ def emu(built):
 def gpu():
     """Backend on the real GPU through the product library — fails loudly if it is missing."""
     import zk_dcap_verifier_amd as z
+    if not os.path.exists(z.LIB_PATH):          # normally the built library travels with the tree
+        import __graft_entry__ as g
+        g.build(test_artifacts=False)
     be = z.Backend(0)
     assert "gfx950" in be.version() and "EMULATED" not in be.version()
     yield be

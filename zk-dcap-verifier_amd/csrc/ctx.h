@@ -25,7 +25,7 @@ struct Tune {
     int msm_tree_fanin = 2;
     int msm_block = 128;         // threads per workgroup of the curve-arithmetic kernels
     int ntt_tile_log = 10;       // log2(elements) of the LDS tile of one NTT workgroup (sweep: profiles/r01/run6_ntt_plan_sweep.txt)
-    int ntt_threads = 512;
+    int ntt_threads = 256;
     int ntt_max_radix_log = 8;
     int ntt_full_twiddle_max_log = 24;   // up to this size inter-pass twiddles come from full HBM tables (32 B/element/pass)
     int vec_block = 256;

@@ -81,12 +81,39 @@ ZK_HD u256 lds_get(const uint4* lo, const uint4* hi, uint32_t idx) {
     return o;
 }
 
-// all log R radix-2 DIT stages on the tile held in LDS (rows were stored bit-reversed)
+// all log R DIT stages on the tile held in LDS (rows were stored bit-reversed).  Two stages at a time are
+// done in registers (radix-4 step: 4 loads, 4 butterflies, 4 stores) so the tile makes half as many LDS
+// round trips and barriers as a radix-2 sweep; an odd last stage is a plain radix-2 step.
 __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r, uint32_t c_log, const void* stage_tw) {
     const uint32_t C = 1u << c_log;
-    const uint32_t nbf = (1u << (r - 1)) << c_log;  // butterflies per stage in the tile
-    for (uint32_t s = 0; s < r; s++) {
+    uint32_t s = 0;
+    for (; s + 1 < r; s += 2) {
+        const uint32_t h = 1u << s;
+        const uint32_t nq = (1u << (r - 2)) << c_log;  // quads per step in the tile
+        for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) {
+            const uint32_t col = q & (C - 1), bq = q >> c_log;
+            const uint32_t grp = bq >> s, pos = bq & (h - 1);
+            const uint32_t i0 = ((grp << (s + 2)) + pos) * C + col, step = h * C;
+            u256 x0 = lds_get(lo, hi, i0), x1 = lds_get(lo, hi, i0 + step), x2 = lds_get(lo, hi, i0 + 2 * step), x3 = lds_get(lo, hi, i0 + 3 * step);
+            if (pos) {
+                const u256 w1 = load_u256(stage_tw, (size_t)pos << (r - 1 - s));
+                x1 = Fr::mul(x1, w1);
+                x3 = Fr::mul(x3, w1);
+            }
+            const u256 t0 = Fr::add(x0, x1), t1 = Fr::sub(x0, x1);
+            u256 t2 = Fr::add(x2, x3), t3 = Fr::sub(x2, x3);
+            if (pos) t2 = Fr::mul(t2, load_u256(stage_tw, (size_t)pos << (r - 2 - s)));
+            t3 = Fr::mul(t3, load_u256(stage_tw, (size_t)(pos + h) << (r - 2 - s)));
+            lds_put(lo, hi, i0, Fr::add(t0, t2));
+            lds_put(lo, hi, i0 + step, Fr::add(t1, t3));
+            lds_put(lo, hi, i0 + 2 * step, Fr::sub(t0, t2));
+            lds_put(lo, hi, i0 + 3 * step, Fr::sub(t1, t3));
+        }
+        __syncthreads();
+    }
+    if (s < r) {
         const uint32_t half = 1u << s;
+        const uint32_t nbf = (1u << (r - 1)) << c_log;  // butterflies of the stage in the tile
         for (uint32_t q = threadIdx.x; q < nbf; q += blockDim.x) {
             const uint32_t col = q & (C - 1), bq = q >> c_log;
             const uint32_t grp = bq >> s, pos = bq & (half - 1);

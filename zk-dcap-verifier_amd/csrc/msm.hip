@@ -66,7 +66,7 @@ ZK_HD uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // ------------------------------------------------------------------------------------------------
 constexpr int MSM_MAX_LEVELS = 12;
 struct MsmPlan {
-    uint32_t n, n_table, B, L, M, R, nb;   // R = merge levels above level 0
+    uint32_t n, n_table, B, L, M, Mlog, R, nb;   // R = merge levels above level 0; M = 2^Mlog
     int c, W;
     const void* const* scalars;            // device array: nb column pointers
     const void* table;
@@ -116,46 +116,62 @@ ZK_KERNEL void msm_hist_kernel(MsmPlan p) {
 //   off[b] = first sorted slot of bucket b, suboff[r][b] = first level-r entry of bucket b
 //   info[0] = max level-0 entries of any bucket
 ZK_KERNEL void msm_scan_kernel(MsmPlan p) {
-    __shared__ uint32_t sc[(MSM_MAX_LEVELS + 2) * 1024];
+    constexpr uint32_t NVMAX = MSM_MAX_LEVELS + 2;
+    __shared__ uint32_t sc[NVMAX * 1024];
     __shared__ uint32_t smax;
     const uint32_t T = blockDim.x, tid = threadIdx.x, B = p.B, NV = p.R + 2;   // pairs + (R+1) levels
+    const uint32_t mlog = p.Mlog;                                              // M = 2^mlog
     uint32_t* sm = plan_small(p, blockIdx.x);
     const uint32_t* hist = sm;
     const uint32_t ipt = ceil_div(B, T);
     const uint32_t lo = tid * ipt < B ? tid * ipt : B;
     const uint32_t hi = lo + ipt < B ? lo + ipt : B;
-    uint32_t sum[MSM_MAX_LEVELS + 2];
-    for (uint32_t v = 0; v < NV; v++) sum[v] = 0;
+    uint32_t sum[NVMAX];
+#pragma unroll
+    for (uint32_t v = 0; v < NVMAX; v++) sum[v] = 0;
     uint32_t mx = 0;
     for (uint32_t b = lo; b < hi; b++) {
-        uint32_t cnt = hist[b];
+        const uint32_t cnt = hist[b];
         sum[0] += cnt;
         uint32_t e = ceil_div(cnt, p.L);
         mx = e > mx ? e : mx;
-        for (uint32_t r = 0; r <= p.R; r++) { sum[1 + r] += e; e = ceil_div(e, p.M); }
+#pragma unroll
+        for (uint32_t r = 0; r <= MSM_MAX_LEVELS; r++) {     // levels beyond R are never read
+            sum[1 + r] += e;
+            e = (e + (1u << mlog) - 1) >> mlog;
+        }
     }
-    for (uint32_t v = 0; v < NV; v++) sc[v * T + tid] = sum[v];
+#pragma unroll
+    for (uint32_t v = 0; v < NVMAX; v++) if (v < NV) sc[v * T + tid] = sum[v];
     if (tid == 0) smax = 0;
     __syncthreads();
     atomicMax(&smax, mx);
     for (uint32_t d = 1; d < T; d <<= 1) {
-        uint32_t add[MSM_MAX_LEVELS + 2];
-        for (uint32_t v = 0; v < NV; v++) add[v] = tid >= d ? sc[v * T + tid - d] : 0;
+        uint32_t add[NVMAX];
+#pragma unroll
+        for (uint32_t v = 0; v < NVMAX; v++) add[v] = (v < NV && tid >= d) ? sc[v * T + tid - d] : 0;
         __syncthreads();
-        for (uint32_t v = 0; v < NV; v++) sc[v * T + tid] += add[v];
+#pragma unroll
+        for (uint32_t v = 0; v < NVMAX; v++) if (v < NV) sc[v * T + tid] += add[v];
         __syncthreads();
     }
-    uint32_t ex[MSM_MAX_LEVELS + 2];
-    for (uint32_t v = 0; v < NV; v++) ex[v] = sc[v * T + tid] - sum[v];
+    uint32_t ex[NVMAX];
+#pragma unroll
+    for (uint32_t v = 0; v < NVMAX; v++) ex[v] = v < NV ? sc[v * T + tid] - sum[v] : 0;
     uint32_t* off = sm + p.o_off;
     uint32_t* cursor = sm + p.o_cursor;
     uint32_t* suboff = sm + p.o_suboff;
     for (uint32_t b = lo; b < hi; b++) {
-        uint32_t cnt = hist[b];
+        const uint32_t cnt = hist[b];
         off[b] = ex[0]; cursor[b] = ex[0];
         ex[0] += cnt;
         uint32_t e = ceil_div(cnt, p.L);
-        for (uint32_t r = 0; r <= p.R; r++) { suboff[(size_t)r * (B + 1) + b] = ex[1 + r]; ex[1 + r] += e; e = ceil_div(e, p.M); }
+#pragma unroll
+        for (uint32_t r = 0; r <= MSM_MAX_LEVELS; r++) {
+            if (r <= p.R) suboff[(size_t)r * (B + 1) + b] = ex[1 + r];
+            ex[1 + r] += e;
+            e = (e + (1u << mlog) - 1) >> mlog;
+        }
     }
     if (tid == T - 1) {
         off[B] = sc[0 * T + T - 1];
@@ -182,9 +198,14 @@ ZK_KERNEL void msm_scatter_kernel(MsmPlan p) {
     }
     __syncthreads();
     uint32_t* cursor = plan_small(p, col) + p.o_cursor;
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
-        uint32_t v = lh[b];
-        lh[b] = v ? atomicAdd(&cursor[b], v) : 0u;
+    for (uint32_t b0 = threadIdx.x; b0 < B; b0 += 8 * blockDim.x) {   // 8 reservations in flight per thread
+        uint32_t v[8], r[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t b = b0 + u * blockDim.x; v[u] = b < B ? lh[b] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) r[u] = v[u] ? atomicAdd(&cursor[b0 + u * blockDim.x], v[u]) : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t b = b0 + u * blockDim.x; if (b < B) lh[b] = r[u]; }
     }
     __syncthreads();
     uint32_t* sorted = p.sorted + (size_t)col * p.sorted_stride;
@@ -467,12 +488,14 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     const uint32_t B = 1u << (c - 1);
     const Tune& tn = ctx->tune;
     const uint64_t pairs_max = (uint64_t)n * W;
-    const uint32_t M = (uint32_t)std::max(2, tn.msm_merge_fanin), TM = (uint32_t)std::max(2, tn.msm_tree_fanin);
+    uint32_t Mlog = 1;
+    while ((2u << Mlog) <= (uint32_t)std::max(2, tn.msm_merge_fanin) && Mlog < 8) Mlog++;
+    const uint32_t M = 1u << Mlog, TM = (uint32_t)std::max(2, tn.msm_tree_fanin);   // merge fan-in rounded down to a power of two
     uint32_t L = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)nb * pairs_max / (uint64_t)tn.msm_target_threads, (uint64_t)tn.msm_min_chunk),
                                               (uint64_t)tn.msm_max_chunk);
     MsmPlan p;
     memset(&p, 0, sizeof p);
-    p.n = (uint32_t)n; p.n_table = (uint32_t)bt.n; p.B = B; p.L = L; p.M = M; p.nb = nb; p.c = c; p.W = W;
+    p.n = (uint32_t)n; p.n_table = (uint32_t)bt.n; p.B = B; p.L = L; p.M = M; p.Mlog = Mlog; p.nb = nb; p.c = c; p.W = W;
     // merge levels for the worst case (one bucket holds every pair)
     uint64_t cap[MSM_MAX_LEVELS + 1];
     cap[0] = pairs_max / L + B + 1;

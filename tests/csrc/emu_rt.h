@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 struct dim3 {
@@ -92,10 +93,13 @@ static void* emu_thread(void* arg) {
         }
     return nullptr;
 }
+inline std::mutex& emu_launch_mutex() { static std::mutex m; return m; }
 template <class F>
 static inline void emu_launch(dim3 grid, dim3 block, size_t smem_bytes, F f) {
     unsigned nt = block.x * block.y;
     if (nt == 0 || grid.x == 0 || grid.y == 0) return;
+    // `__shared__` is a process-wide static here, so kernels of different contexts must not overlap
+    std::lock_guard<std::mutex> serialise(emu_launch_mutex());
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, nullptr, nt);
     void* smem = nullptr;

@@ -176,6 +176,23 @@ int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
 int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args);
 
+/* proving-key level form — the shape of halo2's own call (polynomials in, polynomial out):
+ * zk_pk_load uploads what keygen_pk holds for the evaluator — fixed columns, permutation (sigma) columns, l0, l_last,
+ * l_active_row — either as coefficient-form polynomials of n = 2^k (form 0; expanded with coeff_to_extended on the
+ * device) or as the extended cosets pk already stores (form 1), all HOST pointers.
+ * zk_evaluate_h takes the proof's COEFFICIENT-form polynomials (HOST, n x 32 B each: advice, instance, permutation
+ * products z, and per lookup the product / permuted input / permuted table polynomials), expands them on the device,
+ * runs the program and returns on the HOST either the extended numerator (finish = 0: 2^extended_k x 32 B, what
+ * Evaluator::evaluate_h returns) or, with finish = 1, h(X) itself after divide_by_vanishing_poly and
+ * extended_to_coeff ((cs_degree - 1) * n coefficients, what vanishing::Argument::construct splits and commits). */
+int zk_pk_load(zk_ctx* ctx, uint64_t prog, const void* const* fixed, const void* const* sigma, const void* l0, const void* l_last,
+               const void* l_active_row, int form, uint64_t* pk);
+int zk_pk_release(zk_ctx* ctx, uint64_t pk);
+int zk_evaluate_h(zk_ctx* ctx, uint64_t pk, const void* const* advice_polys, const void* const* instance_polys,
+                  const void* const* perm_product_polys, const void* const* lookup_product_polys, const void* const* lookup_input_polys,
+                  const void* const* lookup_table_polys, const void* challenges, const void* beta, const void* gamma, const void* theta,
+                  const void* y, int finish, void* out);
+
 /* library / build identification */
 const char* zk_version(void);
 

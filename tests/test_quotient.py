@@ -122,3 +122,51 @@ def test_quotient_rejects_malformed_programs(emu, orc, pyref):
 def test_gpu_quotient_vs_oracle(gpu, orc, pyref, seed, shape):
     prog = qc.build_program(orc, pyref, seed=seed, gate_ops=60 if shape["k"] >= 10 else 24, **shape)
     qc.run_case(gpu, orc, pyref, pc, prog, seed=seed)
+
+
+def _pk_level_case(be, orc, pyref, seed, shape, form):
+    """zk_pk_load + zk_evaluate_h (coefficient polynomials in, h(X) out) against the oracle's composition
+    coeff_to_extended -> evaluate_h -> divide_by_vanishing_poly -> extended_to_coeff."""
+    import numpy as np
+    prog = qc.build_program(orc, pyref, seed=seed, **shape)
+    k, deg = shape["k"], shape["cs_degree"]
+    dom = orc.Domain(deg, k)
+    n, en = 1 << k, 1 << dom.extended_k
+    chunk = deg - 2
+    n_sets = (len(prog.perm_columns) + chunk - 1) // chunk if prog.perm_columns else 0
+    nl = len(prog.lookups)
+    P = lambda cnt, sd: [pc.rand_fr(orc, pyref, n, sd + 3 * i) for i in range(cnt)]
+    fixed, sigma, ls = P(prog.n_fixed, seed), P(len(prog.perm_columns), seed + 100), P(3, seed + 200)
+    advice, inst, zs = P(prog.n_advice, seed + 300), P(prog.n_instance, seed + 400), P(n_sets, seed + 500)
+    lz, la, lt = P(nl, seed + 600), P(nl, seed + 700), P(nl, seed + 800)
+    chal = pc.rand_fr(orc, pyref, max(prog.n_challenges, 1), seed + 900)[: prog.n_challenges]
+    beta, gamma, theta, y = pc.rand_fr(orc, pyref, 4, seed + 901)
+    ext = lambda cols: [dom.coeff_to_extended(c) for c in cols]
+    num = orc.evaluate_h(prog.to_blob(), ext(fixed), ext(advice), ext(inst), *ext(ls), ext(sigma), ext(zs), ext(lz), ext(la), ext(lt),
+                         chal, beta, gamma, theta, y, en)
+    want_h = dom.extended_to_coeff(dom.divide_by_vanishing_poly(num))
+    h = be.quotient_program_load(prog.to_blob())
+    if form == 0:
+        pk = be.pk_load(h, fixed, sigma, ls[0], ls[1], ls[2], form=0)
+    else:
+        pk = be.pk_load(h, ext(fixed), ext(sigma), *ext(ls), form=1)
+    kw = dict(advice=advice, instance=inst, perm_products=zs, lookup_product=lz, lookup_input=la, lookup_table=lt, challenges=chal,
+              beta=beta, gamma=gamma, theta=theta, y=y)
+    got_num = be.evaluate_h(pk, out_rows=en, finish=False, **kw)
+    assert (got_num == num).all()
+    got_h = be.evaluate_h(pk, out_rows=n * (deg - 1), finish=True, **kw)
+    assert (got_h == want_h).all()
+    be.pk_release(pk)
+    be.quotient_program_release(h)
+
+
+@pytest.mark.parametrize("form", [0, 1])
+def test_emulated_pk_level_evaluate_h(emu, orc, pyref, form):
+    _pk_level_case(emu, orc, pyref, 1, SHAPES[0][1], form)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,idx", [(0, 0), (1, 1), (0, 4)])
+def test_gpu_pk_level_evaluate_h(gpu, orc, pyref, form, idx):
+    shapes = SHAPES + [(5, dict(k=10, cs_degree=5, n_fixed=4, n_advice=6, n_instance=1, n_challenges=1, n_perm=7, n_lookups=3))]
+    _pk_level_case(gpu, orc, pyref, shapes[idx][0], shapes[idx][1], form)

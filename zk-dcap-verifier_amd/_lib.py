@@ -328,6 +328,38 @@ class Backend:
         self._ck(self.lib.zk_quotient_run_dev(self.ctx, C.c_uint64(prog), C.byref(a)))
 
 
+def _host_ptrs(cols):
+    cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in cols]
+    return (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data for c in cols]), cols
+
+
+def _pk_methods():
+    def pk_load(self, prog: int, fixed, sigma, l0, l_last, l_active_row, form: int = 0) -> int:
+        fa, k1 = _host_ptrs(fixed)
+        sa, k2 = _host_ptrs(sigma)
+        ls = [np.ascontiguousarray(c, dtype=np.uint64) for c in (l0, l_last, l_active_row)]
+        h = C.c_uint64()
+        self._ck(self.lib.zk_pk_load(self.ctx, C.c_uint64(prog), fa, sa, ls[0].ctypes.data_as(C.c_void_p), ls[1].ctypes.data_as(C.c_void_p),
+                                     ls[2].ctypes.data_as(C.c_void_p), C.c_int(form), C.byref(h)))
+        return h.value
+
+    def pk_release(self, pk: int):
+        self._ck(self.lib.zk_pk_release(self.ctx, C.c_uint64(pk)))
+
+    def evaluate_h(self, pk: int, *, advice, instance, perm_products, lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y,
+                   out_rows: int, finish: bool):
+        arrs = [_host_ptrs(g) for g in (advice, instance, perm_products, lookup_product, lookup_input, lookup_table)]
+        ch = np.ascontiguousarray(np.asarray(challenges, dtype=np.uint64).reshape(-1, 4)) if len(challenges) else np.zeros((1, 4), np.uint64)
+        sc = [self._fe(v) for v in (beta, gamma, theta, y)]
+        out = np.empty((out_rows, 4), dtype=np.uint64)
+        self._ck(self.lib.zk_evaluate_h(self.ctx, C.c_uint64(pk), *[a[0] for a in arrs], ch.ctypes.data_as(C.c_void_p),
+                                        *[v.ctypes.data_as(C.c_void_p) for v in sc], C.c_int(1 if finish else 0), out.ctypes.data_as(C.c_void_p)))
+        return out
+    Backend.pk_load, Backend.pk_release, Backend.evaluate_h = pk_load, pk_release, evaluate_h
+
+
+_pk_methods()
+
 _default = None
 _default_lock = threading.Lock()
 

@@ -21,6 +21,13 @@ int lookup_product(zk_ctx* ctx, const void* cin, const void* ctab, const void* p
                    const void* blinding, uint32_t bf, void* d_z);
 int eval_polynomial_batch(zk_ctx* ctx, const void* const* polys, size_t count, size_t n, const void* points, void* out);
 int kate_division(zk_ctx* ctx, const void* d_a, size_t n, const void* b_host, void* d_q);
+int pk_load(zk_ctx* ctx, uint64_t prog, const void* const* fixed, const void* const* sigma, const void* l0, const void* l_last, const void* l_active,
+            int form, uint64_t* handle);
+int pk_release(zk_ctx* ctx, uint64_t h);
+void release_pks(zk_ctx* ctx);
+int evaluate_h_host(zk_ctx* ctx, uint64_t pkh, const void* const* advice, const void* const* instance, const void* const* perm_products,
+                    const void* const* lk_product, const void* const* lk_input, const void* const* lk_table, const void* challenges,
+                    const void* beta, const void* gamma, const void* theta, const void* y, int finish, void* out);
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
@@ -68,6 +75,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
         for (auto& kv : ctx->bases) (void)hipFree(kv.second.d_table);
         ctx->bases.clear();
         release_twiddles(ctx);
+        release_pks(ctx);
         release_programs(ctx);
         release_gtab(ctx);
         zk::DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_sorted, &ctx->ws_small, &ctx->ws_sub0, &ctx->ws_sub1, &ctx->ws_cls0,
@@ -242,5 +250,14 @@ int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* ni, uint32_t* ns, uint32_t* nc) { ENTER; return quotient_program_info(ctx, prog, ni, ns, nc); }
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog) { ENTER; return quotient_program_release(ctx, prog); }
 int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args); }
+
+int zk_pk_load(zk_ctx* ctx, uint64_t prog, const void* const* fixed, const void* const* sigma, const void* l0, const void* l_last, const void* l_active,
+               int form, uint64_t* pk) { ENTER; return pk_load(ctx, prog, fixed, sigma, l0, l_last, l_active, form, pk); }
+int zk_pk_release(zk_ctx* ctx, uint64_t pk) { ENTER; return pk_release(ctx, pk); }
+int zk_evaluate_h(zk_ctx* ctx, uint64_t pk, const void* const* advice, const void* const* instance, const void* const* perm_products,
+                  const void* const* lookup_product, const void* const* lookup_input, const void* const* lookup_table, const void* challenges,
+                  const void* beta, const void* gamma, const void* theta, const void* y, int finish, void* out) {
+    ENTER; return evaluate_h_host(ctx, pk, advice, instance, perm_products, lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, finish, out);
+}
 
 }  // extern "C"

@@ -13,10 +13,14 @@
 // documented in INTEGRATION.md.
 #include "ctx.h"
 #include <algorithm>
+#include <mutex>
 
 namespace zk {
 
 int ntt_pow_tables(zk_ctx* ctx, uint32_t log_n, const u256& omega, const void** lo, const void** hi, uint32_t* lo_bits);
+int domain_coeff_to_extended_batch(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek);
+int domain_extended_to_coeff(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek);
+int domain_divide_by_vanishing(zk_ctx* ctx, void* d_a, uint32_t k, uint32_t ek);
 u256 domain_omega(uint32_t k);
 
 enum { VS_CONST = 0, VS_INTER, VS_FIXED, VS_ADVICE, VS_INSTANCE, VS_CHALLENGE, VS_BETA, VS_GAMMA, VS_THETA, VS_Y, VS_PREV };
@@ -653,6 +657,162 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a) {
     tq.stop();
     ZK_HIP(hipStreamSynchronize(st));
     tq.resolve();
+    return ZK_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// proving-key level entry points: the shape of halo2's own call (polynomials in, h(X) out)
+// ------------------------------------------------------------------------------------------------
+struct PkData {
+    uint64_t prog = 0;
+    std::vector<void*> fixed, sigma;           // extended cosets, device
+    void* l[3] = {nullptr, nullptr, nullptr};   // l0, l_last, l_active_row
+    // per-proof workspace (allocated once): staging for coefficient uploads + extended cosets of the proof's polys
+    std::vector<void*> dyn_ext;
+    void* stage = nullptr;
+    void* h_ext = nullptr;
+};
+static std::map<uint64_t, PkData*> g_pks;       // keyed by handle (handles are unique per process)
+static std::mutex g_pk_mu;
+
+static void pk_free(PkData* pk) {
+    for (void* p : pk->fixed) if (p) (void)hipFree(p);
+    for (void* p : pk->sigma) if (p) (void)hipFree(p);
+    for (void* p : pk->dyn_ext) if (p) (void)hipFree(p);
+    for (void* p : pk->l) if (p) (void)hipFree(p);
+    if (pk->stage) (void)hipFree(pk->stage);
+    if (pk->h_ext) (void)hipFree(pk->h_ext);
+    delete pk;
+}
+
+// host columns -> extended cosets on the device.  form 0: n coefficients each; form 1: 2^ek coset values each
+static int pk_upload_cols(zk_ctx* ctx, const QuotProgram& P, const void* const* cols, size_t count, int form, std::vector<void*>& out) {
+    const size_t nb = (size_t)32 << P.k, eb = (size_t)32 << P.ek;
+    out.assign(count, nullptr);
+    if (count == 0) return ZK_OK;
+    for (size_t i = 0; i < count; i++) {
+        if (!cols[i]) return ctx->fail(ZK_ERR_ARG, "zk_pk_load: null column %zu", i);
+        ZK_HIP(hipMalloc(&out[i], eb));
+    }
+    if (form == 1) {
+        for (size_t i = 0; i < count; i++) ZK_HIP(hipMemcpyAsync(out[i], cols[i], eb, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        return ZK_OK;
+    }
+    ZK_HIP(ctx->ws_scalars.ensure(count * nb));
+    std::vector<const void*> src(count);
+    for (size_t i = 0; i < count; i++) {
+        src[i] = (char*)ctx->ws_scalars.p + i * nb;
+        ZK_HIP(hipMemcpyAsync((void*)src[i], cols[i], nb, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int rc = domain_coeff_to_extended_batch(ctx, src.data(), out.data(), count, P.k, P.ek);
+    if (rc) return rc;
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+int pk_load(zk_ctx* ctx, uint64_t prog, const void* const* fixed, const void* const* sigma, const void* l0, const void* l_last, const void* l_active,
+            int form, uint64_t* handle) {
+    auto it = ctx->programs.find(prog);
+    if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_pk_load: unknown program %llu", (unsigned long long)prog);
+    const QuotProgram& P = *it->second;
+    if (!handle || !l0 || !l_last || !l_active || (P.n_fixed && !fixed) || (P.n_perm_cols && !sigma) || (form != 0 && form != 1))
+        return ctx->fail(ZK_ERR_ARG, "zk_pk_load: null / bad argument");
+    PkData* pk = new PkData();
+    pk->prog = prog;
+    int rc = pk_upload_cols(ctx, P, fixed, P.n_fixed, form, pk->fixed);
+    if (!rc) rc = pk_upload_cols(ctx, P, sigma, P.n_perm_cols, form, pk->sigma);
+    std::vector<void*> lv;
+    const void* ls[3] = {l0, l_last, l_active};
+    if (!rc) rc = pk_upload_cols(ctx, P, ls, 3, form, lv);
+    if (rc) { for (void* p : lv) if (p) (void)hipFree(p); pk_free(pk); return rc; }
+    for (int i = 0; i < 3; i++) pk->l[i] = lv[i];
+    const size_t ndyn = (size_t)P.n_advice + P.n_instance + P.n_sets + 3 * (size_t)P.n_lookups;
+    pk->dyn_ext.assign(ndyn, nullptr);
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < ndyn && e == hipSuccess; i++) e = hipMalloc(&pk->dyn_ext[i], (size_t)32 << P.ek);
+    if (e == hipSuccess) e = hipMalloc(&pk->stage, std::max<size_t>(ndyn, 1) * ((size_t)32 << P.k));
+    if (e == hipSuccess) e = hipMalloc(&pk->h_ext, (size_t)32 << P.ek);
+    if (e != hipSuccess) { pk_free(pk); return ctx->fail(ZK_ERR_HIP, "zk_pk_load: device allocation failed"); }
+    *handle = ctx->next_handle++;
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    g_pks[((uint64_t)(uintptr_t)ctx << 20) ^ *handle] = pk;
+    return ZK_OK;
+}
+static PkData* pk_find(zk_ctx* ctx, uint64_t h) {
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(((uint64_t)(uintptr_t)ctx << 20) ^ h);
+    return it == g_pks.end() ? nullptr : it->second;
+}
+int pk_release(zk_ctx* ctx, uint64_t h) {
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pks.find(((uint64_t)(uintptr_t)ctx << 20) ^ h);
+    if (it == g_pks.end()) return ctx->fail(ZK_ERR_ARG, "zk_pk_release: unknown handle");
+    pk_free(it->second);
+    g_pks.erase(it);
+    return ZK_OK;
+}
+void release_pks(zk_ctx* ctx) {   // called from zk_ctx_destroy: free what this context still owns
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    const uint64_t tag = (uint64_t)(uintptr_t)ctx << 20;
+    for (auto it = g_pks.begin(); it != g_pks.end();) {
+        if (((it->first ^ tag) >> 20) == 0) { pk_free(it->second); it = g_pks.erase(it); }
+        else ++it;
+    }
+}
+
+// Evaluator::evaluate_h (+ optionally the divide / extended_to_coeff of vanishing::Argument::construct):
+// host coefficient-form polynomials in, host result out.
+int evaluate_h_host(zk_ctx* ctx, uint64_t pkh, const void* const* advice, const void* const* instance, const void* const* perm_products,
+                    const void* const* lk_product, const void* const* lk_input, const void* const* lk_table, const void* challenges,
+                    const void* beta, const void* gamma, const void* theta, const void* y, int finish, void* out) {
+    PkData* pk = pk_find(ctx, pkh);
+    if (!pk) return ctx->fail(ZK_ERR_ARG, "zk_evaluate_h: unknown pk handle");
+    auto it = ctx->programs.find(pk->prog);
+    if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_evaluate_h: the pk's program was released");
+    const QuotProgram& P = *it->second;
+    if (!out) return ctx->fail(ZK_ERR_ARG, "zk_evaluate_h: null output");
+    const size_t nb = (size_t)32 << P.k;
+    // gather the proof's polynomials in the order of pk->dyn_ext: advice | instance | perm products | lookup z | a' | s'
+    struct Grp { const void* const* cols; size_t n; const char* what; };
+    const Grp groups[] = {{advice, P.n_advice, "advice"}, {instance, P.n_instance, "instance"}, {perm_products, P.n_sets, "permutation product"},
+                          {lk_product, P.n_lookups, "lookup product"}, {lk_input, P.n_lookups, "lookup permuted input"}, {lk_table, P.n_lookups, "lookup permuted table"}};
+    std::vector<const void*> src;
+    size_t idx = 0;
+    for (const Grp& g : groups) {
+        if (g.n && !g.cols) return ctx->fail(ZK_ERR_ARG, "zk_evaluate_h: missing %s polynomials", g.what);
+        for (size_t i = 0; i < g.n; i++, idx++) {
+            if (!g.cols[i]) return ctx->fail(ZK_ERR_ARG, "zk_evaluate_h: null %s polynomial %zu", g.what, i);
+            void* d = (char*)pk->stage + idx * nb;
+            ZK_HIP(hipMemcpyAsync(d, g.cols[i], nb, hipMemcpyHostToDevice, ctx->stream));
+            src.push_back(d);
+        }
+    }
+    if (!src.empty()) {
+        int rc = domain_coeff_to_extended_batch(ctx, src.data(), pk->dyn_ext.data(), src.size(), P.k, P.ek);
+        if (rc) return rc;
+    }
+    zk_quotient_args qa;
+    memset(&qa, 0, sizeof qa);
+    void* const* dyn = pk->dyn_ext.data();
+    qa.fixed = pk->fixed.data(); qa.advice = dyn; qa.instance = dyn + P.n_advice;
+    qa.l0 = pk->l[0]; qa.l_last = pk->l[1]; qa.l_active_row = pk->l[2];
+    qa.perm_cosets = pk->sigma.data(); qa.perm_products = dyn + P.n_advice + P.n_instance; qa.n_sets = P.n_sets;
+    qa.lookup_product = dyn + P.n_advice + P.n_instance + P.n_sets;
+    qa.lookup_input = qa.lookup_product + P.n_lookups; qa.lookup_table = qa.lookup_input + P.n_lookups;
+    qa.challenges = challenges; qa.beta = beta; qa.gamma = gamma; qa.theta = theta; qa.y = y; qa.out = pk->h_ext;
+    int rc = quotient_run(ctx, pk->prog, &qa);
+    if (rc) return rc;
+    size_t out_bytes = (size_t)32 << P.ek;
+    if (finish) {
+        rc = domain_divide_by_vanishing(ctx, pk->h_ext, P.k, P.ek);
+        if (!rc) rc = domain_extended_to_coeff(ctx, pk->h_ext, P.k, P.ek);
+        if (rc) return rc;
+        out_bytes = nb * (P.degree - 1);
+    }
+    ZK_HIP(hipMemcpyAsync(out, pk->h_ext, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
     return ZK_OK;
 }
 

@@ -126,7 +126,27 @@ class Evaluator:
                                       lookup_product=lookup_product, lookup_input=lookup_input, lookup_table=lookup_table,
                                       challenges=challenges, beta=beta, gamma=gamma, theta=theta, y=y, out=out)
 
+    # -- the shape of halo2's own call: polynomials in, polynomial out -----------------------------------
+    def load_pk(self, fixed, sigma, l0, l_last, l_active_row, extended: bool = False) -> int:
+        """Upload what keygen_pk keeps for the evaluator (host arrays): coefficient form, or the extended
+        cosets pk already stores (extended=True).  Returns a pk handle for evaluate_h_polys."""
+        self.pk = self.backend.pk_load(self.handle, fixed, sigma, l0, l_last, l_active_row, form=1 if extended else 0)
+        return self.pk
+
+    def evaluate_h_polys(self, *, advice, instance, perm_products, lookup_product, lookup_input, lookup_table, challenges, beta, gamma,
+                         theta, y, finish: bool = True):
+        """Evaluator::evaluate_h on host coefficient-form polynomials; finish=True also applies
+        divide_by_vanishing_poly + extended_to_coeff and returns the (cs_degree - 1) * n coefficients of h(X)."""
+        p = self.program
+        rows = (1 << p.k) * (p.cs_degree - 1) if finish else 1 << p.extended_k
+        return self.backend.evaluate_h(self.pk, advice=advice, instance=instance, perm_products=perm_products, lookup_product=lookup_product,
+                                       lookup_input=lookup_input, lookup_table=lookup_table, challenges=challenges, beta=beta, gamma=gamma,
+                                       theta=theta, y=y, out_rows=rows, finish=finish)
+
     def release(self):
+        if getattr(self, "pk", 0):
+            self.backend.pk_release(self.pk)
+            self.pk = 0
         if self.handle:
             self.backend.quotient_program_release(self.handle)
             self.handle = 0

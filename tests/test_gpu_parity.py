@@ -132,3 +132,42 @@ def test_ntt_roundtrip_2p20_and_spot_values(gpu, orc, pyref):
 
 def test_concurrent_callers(gpu, orc, pyref):
     pc.check_concurrent_callers(gpu, orc, pyref, n=5000, threads=6)
+
+
+def test_msm_linearity_and_ntt_roundtrip_at_bench_sizes(gpu, orc, pyref):
+    """BASELINE sizes the oracle cannot reach in seconds, through size-independent properties:
+    MSM(s1) + MSM(s2) = MSM(s1 + s2) at 2^22 (the 2^24 bench path differs only in n), and iNTT(NTT(a)) = n*a at 2^23."""
+    n = 1 << 22
+    ks = pc.rand_fr(orc, pyref, n, 91)
+    dk, dpts = gpu.to_device(ks), gpu.alloc(n * 64)
+    gpu.g1_fixed_base_mul(dk, n, dpts)
+    h = gpu.bases_register((dpts, n))
+    dpts.free()
+    s1, s2 = pc.rand_fr(orc, pyref, n, 92), pc.rand_fr(orc, pyref, n, 93)
+    d1, d2, d3 = gpu.to_device(s1), gpu.to_device(s2), gpu.alloc(n * 32)
+    gpu.fr_add_dev(d1, d2, d3, n)
+    p1, p2 = gpu.msm_partial(h, d1, n), gpu.msm_partial(h, d2, n)
+    both = gpu.g1_sum_xyzz(np.stack([p1, p2]))
+    direct = gpu.msm(h, d3, n)
+    assert (both == direct).all() and not (direct == 0).all()
+    # spot check against the oracle on a prefix (the table prefix semantics of commit())
+    m = 1 << 12
+    pref = gpu.msm(h, d1, m)
+    bases_prefix = np.empty((m, 8), dtype=np.uint64)
+    g = orc.g1_generator()
+    want = orc.g1_to_affine(orc.g1_mul(g, orc.fr_from_ints([sum(a * b for a, b in zip(orc.fr_to_ints(ks[:m]), orc.fr_to_ints(s1[:m]))) % pyref.R])[0]))[0]
+    assert (pref[:8] == want).all()
+    gpu.bases_release(h)
+    for d in (dk, d1, d2, d3):
+        d.free()
+    log_n = 23
+    nn = 1 << log_n
+    a = pc.rand_fr(orc, pyref, nn, 94)
+    d = gpu.to_device(a)
+    w = pyref.omega(log_n)
+    gpu.ntt_dev(d, log_n, orc.fr_from_ints([w])[0])
+    gpu.ntt_dev(d, log_n, orc.fr_from_ints([pow(w, -1, pyref.R)])[0])
+    back = d.download((nn, 4))
+    idx = np.random.default_rng(5).integers(0, nn, size=4096)
+    assert (back[idx] == orc.fr_mul(a[idx], np.repeat(orc.fr_from_ints([nn]), idx.size, axis=0))).all()
+    d.free()

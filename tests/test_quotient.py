@@ -170,3 +170,39 @@ def test_emulated_pk_level_evaluate_h(emu, orc, pyref, form):
 def test_gpu_pk_level_evaluate_h(gpu, orc, pyref, form, idx):
     shapes = SHAPES + [(5, dict(k=10, cs_degree=5, n_fixed=4, n_advice=6, n_instance=1, n_challenges=1, n_perm=7, n_lookups=3))]
     _pk_level_case(gpu, orc, pyref, shapes[idx][0], shapes[idx][1], form)
+
+
+def _theta_compression_case(be, orc, pyref, k, seed):
+    """compress_expressions of a lookup over Lagrange columns (rotations wrap mod n): product vs Python definition."""
+    import random
+    p, rnd = pyref, random.Random(seed)
+    n, R = 1 << k, p.R
+    adv = [[rnd.randrange(R) for _ in range(n)] for _ in range(2)]
+    fix = [[rnd.randrange(R) for _ in range(n)]]
+    theta = rnd.randrange(R)
+    g = ev.Graph()
+    r0, r1 = g.add_rotation(0), g.add_rotation(-1)
+    e0 = g.add_calculation(ev.MUL, ev.vs(ev.FIXED, 0, r0), ev.vs(ev.ADVICE, 0, r0))        # q * a
+    e1 = g.add_calculation(ev.MUL, ev.vs(ev.FIXED, 0, r0), ev.vs(ev.ADVICE, 1, r1))        # q * b(omega^-1 X)
+    g.add_calculation(ev.HORNER, e0, [e1, ev.vs(ev.ADVICE, 1, r0)], ev.vs(ev.THETA))        # ((e0*theta + e1)*theta + b)
+    prog = ev.expression_program(k, 1, 2, 0, 0, g)
+    M = orc.fr_from_ints
+    d_adv, d_fix = [be.to_device(M(c)) for c in adv], [be.to_device(M(c)) for c in fix]
+    out = be.alloc(n * 32)
+    e = ev.Evaluator(prog, backend=be)
+    one = M([1])[0]
+    e.evaluate_h(fixed=d_fix, advice=d_adv, instance=[], l0=d_fix[0], l_last=d_fix[0], l_active_row=d_fix[0], perm_cosets=[], perm_products=[],
+                 lookup_product=[], lookup_input=[], lookup_table=[], challenges=[], beta=one, gamma=one, theta=M([theta])[0], y=one, out=out)
+    got = orc.fr_to_ints(out.download((n, 4)))
+    want = [((fix[0][i] * adv[0][i] * theta + fix[0][i] * adv[1][(i - 1) % n]) * theta + adv[1][i]) % R for i in range(n)]
+    assert got == want
+    e.release()
+
+
+def test_emulated_theta_compression(emu, orc, pyref):
+    _theta_compression_case(emu, orc, pyref, 5, 3)
+
+
+@pytest.mark.gpu
+def test_gpu_theta_compression(gpu, orc, pyref):
+    _theta_compression_case(gpu, orc, pyref, 12, 4)

@@ -150,3 +150,13 @@ class Evaluator:
         if self.handle:
             self.backend.quotient_program_release(self.handle)
             self.handle = 0
+
+
+def expression_program(k: int, n_fixed: int, n_advice: int, n_instance: int, n_challenges: int, graph: Graph) -> Program:
+    """A Program that evaluates ONE expression graph over the n = 2^k rows of the (non-extended) domain — rotations wrap
+    modulo n, exactly like `Expression::evaluate` over Lagrange columns.  With the graph `Horner(e_0, [e_1 .. e_m-1], Theta)`
+    this is lookup::Argument::commit_permuted's `compress_expressions` (theta-compression of the input / table expressions,
+    halo2_proofs src/plonk/lookup/prover.rs; SURVEY 8f n4, first half).  Run it with Evaluator.evaluate_h on Lagrange columns:
+    l0 / l_last / l_active_row are unused and may be any column."""
+    return Program(k=k, extended_k=k, n_fixed=n_fixed, n_advice=n_advice, n_instance=n_instance, n_challenges=n_challenges,
+                   blinding_factors=0, cs_degree=3, perm_columns=[], custom_gates=graph, lookups=[])

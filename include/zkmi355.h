@@ -139,6 +139,13 @@ int zk_lookup_product_dev(zk_ctx* ctx, const void* compressed_input, const void*
                           const void* permuted_table, uint32_t k, const void* beta, const void* gamma, const void* blinding,
                           uint32_t blinding_factors, void* z_dev);
 
+/* halo2_proofs src/plonk/lookup/prover.rs permute_expression_pair (SURVEY 8f "next 4"): input / table = the theta-compressed
+ * expressions over the n = 2^k rows (DEVICE); the first n - (blinding_factors + 1) rows are permuted (A' sorted, S' aligned),
+ * the remaining rows take blind_input / blind_table (HOST, (blinding_factors + 1) x 32 B each — the caller's Fr::random draws).
+ * An input value absent from the table returns ZK_ERR_ARG (halo2: Error::ConstraintSystemFailure). */
+int zk_lookup_permute_dev(zk_ctx* ctx, const void* input, const void* table, uint32_t k, uint32_t blinding_factors, const void* blind_input,
+                          const void* blind_table, void* out_input, void* out_table);
+
 /* ---- evaluation phase (SURVEY 8f "next 2") ----------------------------------------------------- *
  * halo2_proofs src/arithmetic.rs eval_polynomial(poly, point): out[q] = polys[q](points[q]) for `count` queries of n coefficients
  * each (a polynomial queried at several rotations appears several times).  polys: HOST array of DEVICE pointers; points, out: HOST. */

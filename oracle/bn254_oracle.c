@@ -498,4 +498,41 @@ void orc_lookup_product(const fe *cin, const fe *ctab, const fe *pin, const fe *
     free(lp); free(pre);
 }
 
+/* halo2_proofs src/plonk/lookup/prover.rs permute_expression_pair.  Returns 0, or -1 for
+ * Error::ConstraintSystemFailure (an input value that is not in the table).  blind_*: blinding_factors + 1 rows each. */
+static int cmp_canon(const void *a, const void *b) {
+    const fe *x = a, *y = b;
+    for (int i = 3; i >= 0; i--) { if (x->l[i] < y->l[i]) return -1; if (x->l[i] > y->l[i]) return 1; }
+    return 0;
+}
+int orc_lookup_permute(const fe *input, const fe *table, uint32_t k, uint32_t blinding_factors, const fe *blind_in, const fe *blind_tab,
+                       fe *out_in, fe *out_tab) {
+    size_t n = (size_t)1 << k, usable = n - (blinding_factors + 1);
+    fe *pin = malloc(usable * sizeof(fe)), *tab = malloc(usable * sizeof(fe));
+    for (size_t i = 0; i < usable; i++) { f_from_mont(&FR, &pin[i], &input[i]); f_from_mont(&FR, &tab[i], &table[i]); }
+    qsort(pin, usable, sizeof(fe), cmp_canon);                 /* permuted_input_expression.sort() */
+    qsort(tab, usable, sizeof(fe), cmp_canon);                 /* BTreeMap<value, count> == sorted multiset */
+    char *taken = calloc(usable, 1);
+    size_t *repeated = malloc(usable * sizeof(size_t)), nrep = 0;
+    fe *ptab = calloc(usable, sizeof(fe));
+    size_t tpos = 0;
+    int rc = 0;
+    for (size_t row = 0; row < usable; row++) {
+        if (row == 0 || cmp_canon(&pin[row], &pin[row - 1]) != 0) {
+            while (tpos < usable && cmp_canon(&tab[tpos], &pin[row]) < 0) tpos++;
+            if (tpos >= usable || cmp_canon(&tab[tpos], &pin[row]) != 0) { rc = -1; break; }
+            taken[tpos++] = 1;                                   /* *count -= 1 */
+            ptab[row] = pin[row];
+        } else repeated[nrep++] = row;
+    }
+    if (!rc) {
+        for (size_t t = 0; t < usable; t++)                      /* leftover table values ascending, rows popped from the back */
+            if (!taken[t]) ptab[repeated[--nrep]] = tab[t];
+        for (size_t i = 0; i < usable; i++) { f_to_mont(&FR, &out_in[i], &pin[i]); f_to_mont(&FR, &out_tab[i], &ptab[i]); }
+        for (size_t i = 0; i < blinding_factors + 1; i++) { out_in[usable + i] = blind_in[i]; out_tab[usable + i] = blind_tab[i]; }
+    }
+    free(pin); free(tab); free(taken); free(repeated); free(ptab);
+    return rc;
+}
+
 #include "evaluate_h_oracle.inc"

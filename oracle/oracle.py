@@ -34,6 +34,7 @@ def lib():
         _lib.orc_domain_new.restype = C.c_int
         _lib.orc_evaluate_h.restype = C.c_int
         _lib.orc_g1_is_on_curve.restype = C.c_int
+        _lib.orc_lookup_permute.restype = C.c_int
     return _lib
 
 
@@ -275,3 +276,13 @@ def kate_division(a, b_mont) -> np.ndarray:
     q = np.empty((a.shape[0] - 1, 4), dtype=np.uint64)
     lib().orc_kate_division(_p(a), C.c_size_t(a.shape[0]), _p(b), _p(q))
     return q
+
+
+def lookup_permute(inp, table, k, blinding_factors, blind_in, blind_tab):
+    """permute_expression_pair -> (permuted_input, permuted_table); raises ValueError for ConstraintSystemFailure."""
+    n = 1 << k
+    oi, ot = np.empty((n, 4), dtype=np.uint64), np.empty((n, 4), dtype=np.uint64)
+    rc = lib().orc_lookup_permute(_p(_fe(inp)), _p(_fe(table)), C.c_uint32(k), C.c_uint32(blinding_factors), _p(_fe(blind_in)), _p(_fe(blind_tab)), _p(oi), _p(ot))
+    if rc:
+        raise ValueError("ConstraintSystemFailure: input value not in table")
+    return oi, ot

@@ -1,0 +1,96 @@
+"""permute_expression_pair: oracle restatement vs a direct Python transcription of the rule, product vs oracle."""
+import random
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+import zk_dcap_verifier_amd as z
+
+
+def _case(orc, pyref, k, seed, kind):
+    rnd = random.Random(seed)
+    n, bf, R = 1 << k, 5, pyref.R
+    u = n - bf - 1
+    if kind == "small":                      # table = small range, inputs drawn from it (typical range-check lookup)
+        tab_vals = [rnd.randrange(0, max(4, u // 3)) for _ in range(u)]
+        tab_vals[: max(4, u // 3)] = list(range(max(4, u // 3)))[: len(tab_vals[: max(4, u // 3)])]
+        inp_vals = [rnd.choice(tab_vals) for _ in range(u)]
+    elif kind == "wide":                     # full-width field elements: every radix pass matters
+        tab_vals = [rnd.randrange(R) for _ in range(u)]
+        inp_vals = [rnd.choice(tab_vals[: max(2, u // 2)]) for _ in range(u)]
+    elif kind == "identical":                # all inputs equal
+        tab_vals = [7] + [rnd.randrange(R) for _ in range(u - 1)]
+        inp_vals = [7] * u
+    else:                                    # permutation: input == table multiset, no repeats needed from leftovers
+        tab_vals = [rnd.randrange(R) for _ in range(u)]
+        inp_vals = list(tab_vals)
+        rnd.shuffle(inp_vals)
+    pad = [rnd.randrange(R) for _ in range(bf + 1)]
+    return inp_vals + pad, tab_vals + pad[::-1], bf
+
+
+def test_oracle_lookup_permute_matches_rule(orc, pyref):
+    for kind in ("small", "wide", "identical", "perm"):
+        inp, tab, bf = _case(orc, pyref, 6, 5, kind)
+        n = 64
+        u = n - bf - 1
+        M = orc.fr_from_ints
+        bi, bt = M(list(range(100, 100 + bf + 1))), M(list(range(200, 200 + bf + 1)))
+        oi, ot = orc.lookup_permute(M(inp), M(tab), 6, bf, bi, bt)
+        got_i, got_t = orc.fr_to_ints(oi), orc.fr_to_ints(ot)
+        pin = sorted(inp[:u])
+        left = sorted(tab[:u])
+        ptab, rep = [None] * u, []
+        for r in range(u):
+            if r == 0 or pin[r] != pin[r - 1]:
+                ptab[r] = pin[r]
+                left.remove(pin[r])
+            else:
+                rep.append(r)
+        for v in left:
+            ptab[rep.pop()] = v
+        assert got_i == pin + list(range(100, 100 + bf + 1)) and got_t == ptab + list(range(200, 200 + bf + 1)), kind
+    with pytest.raises(ValueError):
+        bad = inp[:]
+        bad[3] = 1 << 200
+        orc.lookup_permute(M(bad), M(tab), 6, bf, bi, bt)
+
+
+def _check(be, orc, pyref, k, kind, seed):
+    inp, tab, bf = _case(orc, pyref, k, seed, kind)
+    n = 1 << k
+    M = orc.fr_from_ints
+    bi, bt = pc.rand_fr(orc, pyref, bf + 1, seed + 1), pc.rand_fr(orc, pyref, bf + 1, seed + 2)
+    A, T = M(inp), M(tab)
+    want_i, want_t = orc.lookup_permute(A, T, k, bf, bi, bt)
+    da, dt = be.to_device(A), be.to_device(T)
+    oa, ot = z.permutation.permute_expression_pair(da, dt, k, bf, bi, bt, backend=be)
+    assert (oa.download((n, 4)) == want_i).all() and (ot.download((n, 4)) == want_t).all(), kind
+    for d in (da, dt, oa, ot):
+        d.free()
+
+
+@pytest.mark.parametrize("kind", ["small", "wide"])
+def test_emulated_lookup_permute(emu, orc, pyref, kind):
+    emu.tune(vec_block=64)
+    try:
+        _check(emu, orc, pyref, 5, kind, seed=3)      # (the emulator spawns a thread per work-item: keep it tiny)
+    finally:
+        emu.tune(vec_block=32)
+
+
+def test_lookup_permute_rejects_value_outside_table(emu, orc, pyref):
+    inp, tab, bf = _case(orc, pyref, 5, 1, "small")
+    inp[2] = 1 << 100
+    M = orc.fr_from_ints
+    da, dt = emu.to_device(M(inp)), emu.to_device(M(tab))
+    b = pc.rand_fr(orc, pyref, bf + 1, 9)
+    with pytest.raises(z.ZkError):
+        z.permutation.permute_expression_pair(da, dt, 5, bf, b, b, backend=emu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,kind", [(7, "small"), (12, "wide"), (16, "small"), (14, "identical"), (15, "perm")])
+def test_gpu_lookup_permute(gpu, orc, pyref, k, kind):
+    _check(gpu, orc, pyref, k, kind, seed=k)

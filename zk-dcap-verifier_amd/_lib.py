@@ -282,6 +282,13 @@ class Backend:
                                                 C.c_uint32(k), sc[0].ctypes.data_as(C.c_void_p), sc[1].ctypes.data_as(C.c_void_p),
                                                 bl.ctypes.data_as(C.c_void_p), C.c_uint32(bl.shape[0]), C.c_void_p(_dptr(z_dev))))
 
+    def lookup_permute_dev(self, inp, table, k: int, blinding_factors: int, blind_input, blind_table, out_input, out_table):
+        bi = np.ascontiguousarray(np.asarray(blind_input, dtype=np.uint64).reshape(blinding_factors + 1, 4))
+        bt = np.ascontiguousarray(np.asarray(blind_table, dtype=np.uint64).reshape(blinding_factors + 1, 4))
+        self._ck(self.lib.zk_lookup_permute_dev(self.ctx, C.c_void_p(_dptr(inp)), C.c_void_p(_dptr(table)), C.c_uint32(k), C.c_uint32(blinding_factors),
+                                                bi.ctypes.data_as(C.c_void_p), bt.ctypes.data_as(C.c_void_p), C.c_void_p(_dptr(out_input)),
+                                                C.c_void_p(_dptr(out_table))))
+
     # -- evaluation phase -----------------------------------------------------------------------
     def eval_polynomial_batch_dev(self, polys, n: int, points) -> np.ndarray:
         pts = np.ascontiguousarray(np.asarray(points, dtype=np.uint64).reshape(-1, 4))

@@ -28,6 +28,8 @@ void release_pks(zk_ctx* ctx);
 int evaluate_h_host(zk_ctx* ctx, uint64_t pkh, const void* const* advice, const void* const* instance, const void* const* perm_products,
                     const void* const* lk_product, const void* const* lk_input, const void* const* lk_table, const void* challenges,
                     const void* beta, const void* gamma, const void* theta, const void* y, int finish, void* out);
+int lookup_permute(zk_ctx* ctx, const void* d_input, const void* d_table, uint32_t k, uint32_t blinding_factors, const void* h_blind_input,
+                   const void* h_blind_table, void* d_out_input, void* d_out_table);
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
@@ -237,6 +239,11 @@ int zk_permutation_product_dev(zk_ctx* ctx, const void* const* values, const voi
 int zk_lookup_product_dev(zk_ctx* ctx, const void* cin, const void* ctab, const void* pin, const void* ptab, uint32_t k, const void* beta,
                           const void* gamma, const void* blinding, uint32_t blinding_factors, void* z_dev) {
     ENTER; return lookup_product(ctx, cin, ctab, pin, ptab, k, beta, gamma, blinding, blinding_factors, z_dev);
+}
+
+int zk_lookup_permute_dev(zk_ctx* ctx, const void* input, const void* table, uint32_t k, uint32_t blinding_factors, const void* blind_input,
+                          const void* blind_table, void* out_input, void* out_table) {
+    ENTER; return lookup_permute(ctx, input, table, k, blinding_factors, blind_input, blind_table, out_input, out_table);
 }
 
 // ---- evaluation phase ---------------------------------------------------------------------------

@@ -44,3 +44,13 @@ def lookup_commit_product(compressed_input, compressed_table, permuted_input, pe
     z = be.alloc((1 << k) * 32)
     be.lookup_product_dev(compressed_input, compressed_table, permuted_input, permuted_table, k, beta, gamma, blinding_rows, z)
     return z
+
+
+def permute_expression_pair(compressed_input, compressed_table, k: int, blinding_factors: int, blind_input, blind_table, backend: Backend | None = None):
+    """lookup::Argument::commit_permuted's permute_expression_pair on device columns -> (permuted_input, permuted_table) buffers.
+    Raises ZkError if an input value is not in the table (halo2: Error::ConstraintSystemFailure)."""
+    be = backend or default_backend()
+    n = 1 << k
+    a, s = be.alloc(n * 32), be.alloc(n * 32)
+    be.lookup_permute_dev(compressed_input, compressed_table, k, blinding_factors, blind_input, blind_table, a, s)
+    return a, s

@@ -19,11 +19,16 @@ namespace zk {
 constexpr uint32_t LP_RUN = 64;     // consecutive items ranked by one thread (stability)
 constexpr uint32_t LP_T = 256;
 
-ZK_KERNEL void lp_canon_kernel(const void* x, uint32_t u, void* canon, uint32_t* idx) {
+// canonical keys + identity permutation; ormask[0..8) collects the OR of all keys so that the sort only visits the
+// digits some key actually uses (witness values are mostly far below 254 bits)
+ZK_KERNEL void lp_canon_kernel(const void* x, uint32_t u, void* canon, uint32_t* idx, uint32_t* ormask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= u) return;
-    store_u256(canon, i, Fr::from_mont(load_u256(x, i)));
+    const u256 c = Fr::from_mont(load_u256(x, i));
+    store_u256(canon, i, c);
     idx[i] = i;
+#pragma unroll
+    for (int w = 0; w < 8; w++) if (c.v[w] & ~ormask[w]) atomicOr(&ormask[w], c.v[w]);
 }
 ZK_HD uint32_t lp_digit(const void* canon, uint32_t row, uint32_t d) {  // d-th 4-bit digit, d = 0 least significant
     const uint32_t w = reinterpret_cast<const uint32_t*>(canon)[(size_t)row * 8 + (d >> 3)];
@@ -142,12 +147,12 @@ static uint32_t lp_scan_threads(uint32_t m) {   // single-workgroup scan: enough
     while (t < 1024 && t * 8 < m) t <<= 1;
     return t;
 }
-static int lp_sort(zk_ctx* ctx, const void* canon, uint32_t u, uint32_t* idx_a, uint32_t* idx_b, uint32_t* counts, uint32_t* flag, uint32_t** result) {
+static int lp_sort(zk_ctx* ctx, const void* canon, uint32_t u, uint32_t ndigits, uint32_t* idx_a, uint32_t* idx_b, uint32_t* counts, uint32_t* flag, uint32_t** result) {
     const uint32_t nruns = (u + LP_RUN - 1) / LP_RUN;
     const uint32_t grid = (nruns + LP_T - 1) / LP_T;
     uint32_t* in = idx_a;
     uint32_t* out = idx_b;
-    for (uint32_t d = 0; d < 64; d++) {
+    for (uint32_t d = 0; d < ndigits; d++) {
         ZK_LAUNCH(lp_hist_kernel, grid, LP_T, 0, ctx->stream, canon, (const uint32_t*)in, u, d, nruns, counts);
         ZK_CHECK_LAUNCH();
         ZK_LAUNCH(lp_scan_kernel, 1, lp_scan_threads(16 * nruns), 0, ctx->stream, counts, 16 * nruns, nruns, u, flag, (uint32_t*)nullptr);
@@ -190,14 +195,20 @@ int lookup_permute(zk_ctx* ctx, const void* d_input, const void* d_table, uint32
     ZK_HIP(hipMemsetAsync(scal, 0, 64, st));
     ZK_HIP(hipMemcpyAsync(d_blind_in, h_blind_input, (size_t)nb * 32, hipMemcpyHostToDevice, st));
     ZK_HIP(hipMemcpyAsync(d_blind_tab, h_blind_table, (size_t)nb * 32, hipMemcpyHostToDevice, st));
-    ZK_LAUNCH(lp_canon_kernel, g, blk, 0, st, d_input, u, canon_in, in_a);
+    ZK_LAUNCH(lp_canon_kernel, g, blk, 0, st, d_input, u, canon_in, in_a, scal + 4);
     ZK_CHECK_LAUNCH();
-    ZK_LAUNCH(lp_canon_kernel, g, blk, 0, st, d_table, u, canon_tab, tab_a);
+    ZK_LAUNCH(lp_canon_kernel, g, blk, 0, st, d_table, u, canon_tab, tab_a, scal + 4);
     ZK_CHECK_LAUNCH();
+    uint32_t om[8];
+    ZK_HIP(hipMemcpyAsync(om, scal + 4, 32, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    uint32_t ndigits = 1;                                   // number of 4-bit digits any key uses
+    for (int wd = 7; wd >= 0; wd--)
+        if (om[wd]) { uint32_t top = 31; while (!((om[wd] >> top) & 1)) top--; ndigits = (uint32_t)wd * 8 + top / 4 + 1; break; }
     uint32_t *in_sorted, *tab_sorted;
-    int rc = lp_sort(ctx, canon_in, u, in_a, in_b, counts, scal, &in_sorted);
+    int rc = lp_sort(ctx, canon_in, u, ndigits, in_a, in_b, counts, scal, &in_sorted);
     if (rc) return rc;
-    rc = lp_sort(ctx, canon_tab, u, tab_a, tab_b, counts, scal, &tab_sorted);
+    rc = lp_sort(ctx, canon_tab, u, ndigits, tab_a, tab_b, counts, scal, &tab_sorted);
     if (rc) return rc;
     ZK_LAUNCH(lp_fill_kernel, g, blk, 0, st, unconsumed, u, 1u);
     ZK_CHECK_LAUNCH();

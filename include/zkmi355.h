@@ -179,7 +179,7 @@ typedef struct zk_quotient_args {
 } zk_quotient_args;
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog);
-/* size of the compiled micro-program: instructions, live-value slots (first 6 are registers, rest LDS), columns */
+/* size of the compiled micro-program: instructions, live-value slots (first 3 are registers, rest LDS), columns */
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
 int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args);
 

@@ -27,7 +27,7 @@ enum { VS_CONST = 0, VS_INTER, VS_FIXED, VS_ADVICE, VS_INSTANCE, VS_CHALLENGE, V
 enum { OP_ADD = 0, OP_SUB, OP_MUL, OP_SQUARE, OP_DOUBLE, OP_NEGATE, OP_HORNER, OP_STORE };
 // micro-ops
 enum { M_ADD = 0, M_SUB, M_MUL, M_SQR, M_DBL, M_NEG, M_MOV, M_MULADD };
-enum { K_SLOT = 0, K_CONST, K_COL, K_ACC, K_XPOW };
+enum { K_SLOT = 0, K_CONST, K_COL, K_ACC, K_XPOW, K_NONE = 7 };
 
 struct QuotProgram {
     uint32_t k = 0, ek = 0, n_fixed = 0, n_advice = 0, n_instance = 0, n_challenges = 0, blinding = 0, degree = 0;
@@ -58,7 +58,7 @@ struct QuotProgram {
 #define ZK_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #endif
 
-constexpr uint32_t QUOT_NREG = 6;   // first slots of the allocator are registers, the rest LDS
+constexpr uint32_t QUOT_NREG = 3;   // first slots of the allocator are registers, the rest LDS
 
 struct QuotArgs {
     const uint4* code;
@@ -74,25 +74,37 @@ struct QuotArgs {
     void* out;
 };
 
+// One row per thread.  The loop is software-pipelined by one instruction: while instruction pc executes, the column /
+// constant operands of instruction pc + 1 are already in flight (the kernel is otherwise bound by the latency of ~850
+// dependent 32-byte loads per row, not by arithmetic: profiles/r01).  Slot, accumulator and X-power operands are read at
+// execute time because the previous instruction may just have written them.
 ZK_KERNEL void quotient_kernel(QuotArgs q) {
     ZK_DYN_SHARED(uint4, smem);
     const uint32_t T = blockDim.x, tid = threadIdx.x;
     const uint32_t idx = blockIdx.x * T + tid;
     const uint32_t mask = (1u << q.size_log) - 1u;
     u256 acc = Fr::zero(), xpow = Fr::one();
-    u256 rg0 = Fr::zero(), rg1 = rg0, rg2 = rg0, rg3 = rg0, rg4 = rg0, rg5 = rg0;   // slots 0..QUOT_NREG-1 live in VGPRs
+    u256 rg0 = Fr::zero(), rg1 = rg0, rg2 = rg0;   // slots 0..QUOT_NREG-1 live in VGPRs
     if (q.uses_xpow) {  // extended_omega^idx
         xpow = load_u256(q.tw_lo, idx & ((1u << q.lo_bits) - 1u));
         const uint32_t h = idx >> q.lo_bits;
         if (h) xpow = Fr::mul(xpow, load_u256(q.tw_hi, h));
     }
-    auto fetch = [&](uint32_t src) -> u256 {
+    auto prefetch = [&](uint32_t src) -> u256 {        // memory operands only; everything else is resolved later
+        const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
+        if (kind == K_COL) {
+            const uint32_t row = (idx + q.rot_off[pay & 0xffu]) & mask;
+            return load_u256(q.cols[pay >> 8], row);
+        }
+        if (kind == K_CONST) return load_u256(q.consts, pay);
+        return Fr::zero();
+    };
+    auto resolve = [&](uint32_t src, const u256& pre) -> u256 {
         const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
         switch (kind) {
             case K_SLOT: {
                 switch (pay) {
                     case 0: return rg0; case 1: return rg1; case 2: return rg2;
-                    case 3: return rg3; case 4: return rg4; case 5: return rg5;
                     default: break;
                 }
                 const uint32_t ls = pay - QUOT_NREG;
@@ -101,28 +113,33 @@ ZK_KERNEL void quotient_kernel(QuotArgs q) {
                 o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w;
                 return o;
             }
-            case K_CONST: return load_u256(q.consts, pay);
-            case K_COL: {
-                const uint32_t row = (idx + q.rot_off[pay & 0xffu]) & mask;
-                return load_u256(q.cols[pay >> 8], row);
-            }
             case K_ACC: return acc;
-            default: return xpow;
+            case K_XPOW: return xpow;
+            default: return pre;       // K_COL / K_CONST (already loaded) or K_NONE
         }
     };
+    uint4 ins = q.n_instr ? q.code[0] : make_uint4(M_MOV | (1u << 8), K_NONE << 28, K_NONE << 28, K_NONE << 28);
+    u256 pa = prefetch(ZK_UNIFORM(ins.y)), pb = prefetch(ZK_UNIFORM(ins.z)), pc_ = prefetch(ZK_UNIFORM(ins.w));
     for (uint32_t pc = 0; pc < q.n_instr; pc++) {
-        const uint4 ins = q.code[pc];
         const uint32_t w0 = ZK_UNIFORM(ins.x), sa = ZK_UNIFORM(ins.y), sb = ZK_UNIFORM(ins.z), sc = ZK_UNIFORM(ins.w);
+        // put the next instruction's loads in flight before this one's arithmetic
+        uint4 nxt = ins;
+        u256 na = pa, nb = pb, nc = pc_;
+        if (pc + 1 < q.n_instr) {
+            nxt = q.code[pc + 1];
+            na = prefetch(ZK_UNIFORM(nxt.y)); nb = prefetch(ZK_UNIFORM(nxt.z)); nc = prefetch(ZK_UNIFORM(nxt.w));
+        }
         const uint32_t op = w0 & 0xffu;
-        u256 a = fetch(sa), r;
+        const u256 a = resolve(sa, pa);
+        u256 r;
         switch (op) {
-            case M_ADD: r = Fr::add(a, fetch(sb)); break;
-            case M_SUB: r = Fr::sub(a, fetch(sb)); break;
-            case M_MUL: r = Fr::mul(a, fetch(sb)); break;
+            case M_ADD: r = Fr::add(a, resolve(sb, pb)); break;
+            case M_SUB: r = Fr::sub(a, resolve(sb, pb)); break;
+            case M_MUL: r = Fr::mul(a, resolve(sb, pb)); break;
             case M_SQR: r = Fr::sqr(a); break;
             case M_DBL: r = Fr::dbl(a); break;
             case M_NEG: r = Fr::neg(a); break;
-            case M_MULADD: r = Fr::add(Fr::mul(a, fetch(sb)), fetch(sc)); break;
+            case M_MULADD: r = Fr::add(Fr::mul(a, resolve(sb, pb)), resolve(sc, pc_)); break;
             default: r = a; break;
         }
         if ((w0 >> 8) & 0xffu) {
@@ -131,7 +148,6 @@ ZK_KERNEL void quotient_kernel(QuotArgs q) {
             const uint32_t slot = w0 >> 16;
             switch (slot) {
                 case 0: rg0 = r; break; case 1: rg1 = r; break; case 2: rg2 = r; break;
-                case 3: rg3 = r; break; case 4: rg4 = r; break; case 5: rg5 = r; break;
                 default: {
                     const uint32_t ls = slot - QUOT_NREG;
                     smem[(2 * ls) * T + tid] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
@@ -139,6 +155,7 @@ ZK_KERNEL void quotient_kernel(QuotArgs q) {
                 }
             }
         }
+        ins = nxt; pa = na; pb = nb; pc_ = nc;
     }
     store_u256(q.out, idx, acc);
 }
@@ -213,7 +230,7 @@ struct Builder {
     int emit(uint32_t op, int dst, std::initializer_list<Opnd> ops) {
         VIns v; v.op = op; v.dst = dst; v.nsrc = 0;
         for (auto& o : ops) { v.src[v.nsrc] = o.word; v.vsrc[v.nsrc] = o.vreg; v.nsrc++; }
-        for (int i = v.nsrc; i < 3; i++) { v.src[i] = enc(K_CONST, P.c_zero); v.vsrc[i] = -1; }
+        for (int i = v.nsrc; i < 3; i++) { v.src[i] = enc(K_NONE, 0); v.vsrc[i] = -1; }   // unused operand: nothing is fetched
         ins.push_back(v);
         return dst;
     }

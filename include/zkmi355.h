@@ -93,6 +93,10 @@ int zk_g1_sum_xyzz(const void* xyzz_host, size_t count, void* out_jacobian);
  * gen_srs (sgx_dcap_verifier.rs:799); also used to build synthetic SRS-shaped tables. */
 int zk_g1_fixed_base_mul_dev(zk_ctx* ctx, const void* scalars_dev, size_t n, void* out_affine_dev);
 
+/* best_fft over G = G1 (the "EC-FFT" of ParamsKZG::setup's g_to_lagrange): out[j] = [scale] sum_i [omega^(i j)] in[i], affine in
+ * and out (DEVICE, 2^log_n x 64 B); omega, scale: HOST 32 B Montgomery, scale may be NULL.  One-time setup work. */
+int zk_g1_ntt_dev(zk_ctx* ctx, const void* g1_affine_in_dev, uint32_t log_n, const void* omega, const void* scale, void* g1_affine_out_dev);
+
 /* ---- NTT: replaces arithmetic::best_fft (G = Fr) and the EvaluationDomain wrappers --------- *
  * halo2_proofs src/arithmetic.rs best_fft(a, omega, log_n): in place, natural order in and out,
  * out[j] = sum_i a[i] * omega^(i*j).  omega: 32 B Montgomery.                                   */

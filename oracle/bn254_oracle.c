@@ -441,6 +441,34 @@ void orc_eval_polynomial(const fe *poly, size_t n, const fe *x, fe *out) {
     *out = acc;
 }
 
+/* best_fft over the group G1 (the instance ParamsKZG::setup uses for g_to_lagrange): bit-reverse + iterative butterflies with
+ * group_scale = scalar multiplication; then an optional scaling of every output (the n^-1 of the inverse transform) */
+void orc_g1_fft(const g1a *in, uint32_t log_n, const fe *omega_mont, const fe *scale_mont_or_null, g1a *out) {
+    size_t n = (size_t)1 << log_n;
+    g1j *a = malloc(n * sizeof(g1j));
+    for (size_t k = 0; k < n; k++) j_from_affine(&a[bitreverse(k, log_n)], &in[k]);
+    fe *tw = malloc((n / 2 + 1) * sizeof(fe)); fe w = FR.r;
+    for (size_t i = 0; i < n / 2; i++) { f_from_mont(&FR, &tw[i], &w); f_mul(&FR, &w, &w, omega_mont); }   /* canonical twiddles */
+    size_t chunk = 2, twiddle_chunk = n / 2;
+    for (uint32_t s = 0; s < log_n; s++) {
+        for (size_t base = 0; base < n; base += chunk)
+            for (size_t i = 0; i < chunk / 2; i++) {
+                g1j t = a[base + chunk / 2 + i];
+                if (i) { g1a ta; j_to_affine(&ta, &t); j_mul(&t, &ta, &tw[i * twiddle_chunk]); }
+                g1j nt = t; f_neg(&FQ, &nt.y, &t.y);
+                g1j x = a[base + i];
+                j_add(&a[base + i], &x, &t);
+                j_add(&a[base + chunk / 2 + i], &x, &nt);
+            }
+        chunk *= 2; twiddle_chunk /= 2;
+    }
+    for (size_t k = 0; k < n; k++) {
+        if (scale_mont_or_null) { g1a t; j_to_affine(&t, &a[k]); fe sc; f_from_mont(&FR, &sc, scale_mont_or_null); j_mul(&a[k], &t, &sc); }
+        j_to_affine(&out[k], &a[k]);
+    }
+    free(a); free(tw);
+}
+
 /* halo2_proofs src/arithmetic.rs kate_division(a, b): quotient of a(X) by (X - b); q has n-1 coefficients */
 void orc_kate_division(const fe *a, size_t n, const fe *b, fe *q) {
     fe nb; f_neg(&FR, &nb, b);

@@ -286,3 +286,12 @@ def lookup_permute(inp, table, k, blinding_factors, blind_in, blind_tab):
     if rc:
         raise ValueError("ConstraintSystemFailure: input value not in table")
     return oi, ot
+
+
+def g1_fft(points_affine, log_n: int, omega_mont, scale_mont=None) -> np.ndarray:
+    pts = np.ascontiguousarray(points_affine, dtype=np.uint64).reshape(1 << log_n, 8)
+    w = _fe(np.asarray(omega_mont).reshape(4))
+    out = np.empty_like(pts)
+    sc = _fe(np.asarray(scale_mont).reshape(4)) if scale_mont is not None else None
+    lib().orc_g1_fft(_p(pts), C.c_uint32(log_n), _p(w), _p(sc) if sc is not None else None, _p(out))
+    return out

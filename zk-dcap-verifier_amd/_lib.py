@@ -210,6 +210,12 @@ class Backend:
     def g1_fixed_base_mul(self, scalars_dev, n: int, out_dev):
         self._ck(self.lib.zk_g1_fixed_base_mul_dev(self.ctx, C.c_void_p(_dptr(scalars_dev)), C.c_size_t(n), C.c_void_p(_dptr(out_dev))))
 
+    def g1_ntt_dev(self, in_dev, log_n: int, omega, scale, out_dev):
+        w = self._fe(omega)
+        sc = self._fe(scale) if scale is not None else None
+        self._ck(self.lib.zk_g1_ntt_dev(self.ctx, C.c_void_p(_dptr(in_dev)), C.c_uint32(log_n), w.ctypes.data_as(C.c_void_p),
+                                        sc.ctypes.data_as(C.c_void_p) if sc is not None else None, C.c_void_p(_dptr(out_dev))))
+
     # -- NTT / domain ---------------------------------------------------------------------------
     @staticmethod
     def _fe(x) -> np.ndarray:

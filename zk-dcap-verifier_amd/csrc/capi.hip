@@ -30,6 +30,7 @@ int evaluate_h_host(zk_ctx* ctx, uint64_t pkh, const void* const* advice, const 
                     const void* beta, const void* gamma, const void* theta, const void* y, int finish, void* out);
 int lookup_permute(zk_ctx* ctx, const void* d_input, const void* d_table, uint32_t k, uint32_t blinding_factors, const void* h_blind_input,
                    const void* h_blind_table, void* d_out_input, void* d_out_table);
+int g1_ntt(zk_ctx* ctx, const void* d_affine_in, uint32_t log_n, const void* omega_host, const void* scale_host, void* d_affine_out);
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
@@ -149,6 +150,8 @@ int zk_msm_batch_dev(zk_ctx* ctx, uint64_t b, const void* const* s, size_t count
 int zk_msm_partial_dev(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { ENTER; return msm_run(ctx, b, s, n, true, out, 1); }
 int zk_g1_sum_xyzz(const void* xyzz, size_t count, void* out) { if (!xyzz || !out) return ZK_ERR_ARG; return g1_sum_xyzz_host(xyzz, count, out); }
 int zk_g1_fixed_base_mul_dev(zk_ctx* ctx, const void* s, size_t n, void* out) { ENTER; return g1_fixed_base_mul(ctx, s, n, out); }
+
+int zk_g1_ntt_dev(zk_ctx* ctx, const void* in, uint32_t log_n, const void* omega, const void* scale, void* out) { ENTER; return g1_ntt(ctx, in, log_n, omega, scale, out); }
 
 // ---- NTT / domain -------------------------------------------------------------------------------
 static int with_host_buffer(zk_ctx* ctx, void* host_in_out, size_t in_bytes, size_t buf_bytes, size_t out_bytes, void** dbuf) {

@@ -25,6 +25,31 @@ class ParamsKZG:
         self.g = BasesHandle(self.backend, g)
         self.g_lagrange = BasesHandle(self.backend, g_lagrange)
 
+    @classmethod
+    def setup(cls, k: int, tau, backend: Backend | None = None) -> "ParamsKZG":
+        """ParamsKZG::setup(k, rng) with the toxic waste `tau` given explicitly (TESTS / synthetic SRS only):
+        g[i] = [tau^i] G  (n fixed-base multiplications), g_lagrange = EC-iFFT of g (g_to_lagrange) — both on the GPU."""
+        be = backend or default_backend()
+        n = 1 << k
+        R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+        mont = lambda x: np.array([((x << 256) % R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        powers = np.empty((n, 4), dtype=np.uint64)
+        cur = 1
+        for i in range(n):
+            powers[i] = mont(cur)
+            cur = cur * int(tau) % R
+        ds, dg, dl = be.to_device(powers), be.alloc(n * 64), be.alloc(n * 64)
+        be.g1_fixed_base_mul(ds, n, dg)
+        omega_inv = pow(pow(7, (R - 1) >> k, R), R - 2, R)
+        be.g1_ntt_dev(dg, k, mont(omega_inv), mont(pow(n, R - 2, R)), dl)
+        self = cls.__new__(cls)
+        self.backend, self.k, self.n = be, k, n
+        self.g_host, self.g_lagrange_host = dg.download((n, 8)), dl.download((n, 8))
+        self.g, self.g_lagrange = BasesHandle(be, (dg, n)), BasesHandle(be, (dl, n))
+        for d in (ds, dg, dl):
+            d.free()
+        return self
+
     def commit(self, poly: np.ndarray) -> np.ndarray:
         poly = np.asarray(poly, dtype=np.uint64).reshape(-1, 4)
         assert poly.shape[0] <= self.n

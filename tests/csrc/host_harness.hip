@@ -11,6 +11,7 @@ void hh_fr_neg(const u256* a, u256* o, size_t n) { for (size_t i = 0; i < n; i++
 void hh_fr_inv(const u256* a, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fr::inv(a[i]); }
 void hh_fr_from_mont(const u256* a, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fr::from_mont(a[i]); }
 void hh_fq_mul(const u256* a, const u256* b, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fq::mul(a[i], b[i]); }
+void hh_fq_mul2_sub(const u256* a, const u256* b, const u256* c, const u256* d, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fq::mul2_sub(a[i], b[i], c[i], d[i]); }
 void hh_fq_add(const u256* a, const u256* b, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fq::add(a[i], b[i]); }
 void hh_fq_sub(const u256* a, const u256* b, u256* o, size_t n) { for (size_t i = 0; i < n; i++) o[i] = Fq::sub(a[i], b[i]); }
 // acc (XYZZ) += sign * p for a list of affine points; acc starts at identity

@@ -41,6 +41,18 @@ def test_field_limb_ops(hh, orc, pyref):
     assert (out == orc.fr_sub(np.zeros_like(A), A)).all()
 
 
+def test_fused_two_product_reduction(hh, orc, pyref):
+    rnd = random.Random(9)
+    P_ = pyref.P
+    edge = [0, 1, P_ - 1, P_ - 2, P_ >> 1]
+    vals = [[rnd.randrange(P_) for _ in range(500)] + edge for _ in range(4)]
+    vals[1] = vals[1][:500] + edge[::-1]
+    A, B, C_, D = (orc.ints_to_limbs(v) for v in vals)
+    out = np.empty_like(A)
+    hh.hh_fq_mul2_sub(P(A), P(B), P(C_), P(D), P(out), C.c_size_t(len(A)))
+    assert (out == orc.fq_sub(orc.fq_mul(A, B), orc.fq_mul(C_, D))).all()
+
+
 def xyzz_to_affine(orc, pyref, x):
     X, Y, ZZ, ZZZ = orc.fq_to_ints(np.asarray(x).reshape(4, 4))
     if ZZ == 0:

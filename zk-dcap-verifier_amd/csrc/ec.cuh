@@ -3,7 +3,7 @@
 // Bases cross the FFI as halo2curves G1Affine {x, y} (Montgomery Fq, identity = (0,0));
 // accumulators live in extended Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2,
 // identity = ZZ == 0) because the mixed addition is the cheapest complete-enough formula
-// without inversions: 8M + 2S (EFD madd-2008-s), vs 7M + 4S for Jacobian madd-2007-bl that
+// without inversions: 8M + 2S (EFD madd-2008-s; the two products of Y3 share one Montgomery reduction), vs 7M + 4S for Jacobian madd-2007-bl that
 // halo2curves uses on the CPU.  Results are canonical after normalisation, so the choice of
 // coordinates is invisible to the caller (SURVEY.md App. C.1 "GPU freedom").
 #pragma once
@@ -42,7 +42,7 @@ ZK_HD XYZZ xyzz_mdbl(const u256& x1, const u256& y1) {
     u256 X2 = Fq::sqr(x1);
     u256 M = Fq::add(Fq::dbl(X2), X2);
     o.x = Fq::sub(Fq::sqr(M), Fq::dbl(S));
-    o.y = Fq::sub(Fq::mul(M, Fq::sub(S, o.x)), Fq::mul(W, y1));
+    o.y = Fq::mul2_sub(M, Fq::sub(S, o.x), W, y1);           // M*(S - X3) - W*Y1, one reduction
     o.zz = V;
     o.zzz = W;
     return o;
@@ -58,7 +58,7 @@ ZK_HD XYZZ xyzz_dbl(const XYZZ& p) {
     u256 X2 = Fq::sqr(p.x);
     u256 M = Fq::add(Fq::dbl(X2), X2);
     o.x = Fq::sub(Fq::sqr(M), Fq::dbl(S));
-    o.y = Fq::sub(Fq::mul(M, Fq::sub(S, o.x)), Fq::mul(W, p.y));
+    o.y = Fq::mul2_sub(M, Fq::sub(S, o.x), W, p.y);
     o.zz = Fq::mul(V, p.zz);
     o.zzz = Fq::mul(W, p.zzz);
     return o;
@@ -82,7 +82,7 @@ ZK_HD void xyzz_madd(XYZZ& acc, const u256& x2, const u256& y2) {
     u256 PPP = Fq::mul(P, PP);
     u256 Q = Fq::mul(acc.x, PP);
     u256 X3 = Fq::sub(Fq::sub(Fq::sqr(R), PPP), Fq::dbl(Q));
-    u256 Y3 = Fq::sub(Fq::mul(R, Fq::sub(Q, X3)), Fq::mul(acc.y, PPP));
+    u256 Y3 = Fq::mul2_sub(R, Fq::sub(Q, X3), acc.y, PPP);   // R*(Q - X3) - Y1*PPP, one reduction
     acc.x = X3;
     acc.y = Y3;
     acc.zz = Fq::mul(acc.zz, PP);
@@ -112,7 +112,7 @@ ZK_HD void xyzz_add(XYZZ& acc, const XYZZ& q) {
     u256 PPP = Fq::mul(P, PP);
     u256 Q = Fq::mul(U1, PP);
     u256 X3 = Fq::sub(Fq::sub(Fq::sqr(R), PPP), Fq::dbl(Q));
-    u256 Y3 = Fq::sub(Fq::mul(R, Fq::sub(Q, X3)), Fq::mul(S1, PPP));
+    u256 Y3 = Fq::mul2_sub(R, Fq::sub(Q, X3), S1, PPP);
     acc.x = X3;
     acc.y = Y3;
     acc.zz = Fq::mul(Fq::mul(acc.zz, q.zz), PP);

@@ -131,6 +131,20 @@ struct Field {
         r.v[7] = (uint32_t)acc;
         return reduce_once(r);
     }
+    // (a*b + c*d) * R^-1 mod p with ONE reduction: both products feed the same columns.  a*b + c*d < 2p^2 and p < 2^254,
+    // so (a*b + c*d + m*p) / 2^256 < p/2 + p < 2p: still 8 limbs and one conditional subtraction.
+    static ZK_HD u256 mul2_add(const u256& a, const u256& b, const u256& c, const u256& d) {
+        uint64_t acc = 0;
+        uint32_t cnt = 0;
+        uint32_t m[8];
+        u256 r;
+#include "field_mul2_body.inc"
+        r.v[7] = (uint32_t)acc;
+        return reduce_once(r);
+    }
+    // a*b - c*d (as a*b + c*(p - d))
+    static ZK_HD u256 mul2_sub(const u256& a, const u256& b, const u256& c, const u256& d) { return mul2_add(a, b, c, neg(d)); }
+
     // the plain-C coarsely integrated operand scanning form (kept for the microbenchmark comparison)
     static ZK_HD u256 mul_cios(const u256& a, const u256& b) {
         uint32_t t[9];

@@ -239,17 +239,21 @@ def main(argv=None):
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("ZK_BENCH_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if torch.cuda.is_available():
+        # RCCL over xGMI on a multi-GPU node; gloo only for the CPU plumbing test / a single-GPU dry run of the N > 1 path
+        backend = os.environ.get("ZK_BENCH_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # RCCL over xGMI
-        else:                                                                             # CPU plumbing test only
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
             dist.init_process_group("gloo")
-    tdev = "cuda" if torch.cuda.is_available() else "cpu"
+    else:
+        backend = "none"
+    tdev = "cuda" if backend == "nccl" else "cpu"
     import zk_dcap_verifier_amd as z
     be = z.Backend(local)                      # raises if the HIP library / GPU is missing: no CPU path
     assert "gfx950" in be.version() or os.environ.get("ZK_BENCH_PLUMBING_TEST") == "1"

@@ -124,3 +124,22 @@ def test_reference_proof_bin_decodes_on_this_curve(orc, pyref):
         pt = orc.g1_affine_from_ints([(x, ys[0])])[0]
         assert orc.g1_is_on_curve(pt)
     assert all(w < pyref.R for w in words[13:45])
+
+
+def test_committed_kats_fixture(orc, pyref):
+    """tests/golden/kats.json (tools/gen_golden.py): the committed vectors against the C oracle."""
+    import json
+    k = json.load(open(os.path.join(HERE, "golden", "kats.json")))
+    assert int(k["fq_modulus"], 16) == pyref.P and int(k["fr_modulus"], 16) == pyref.R
+    assert orc.limbs_to_ints(orc.fr_from_ints([1]))[0] == int(k["fr_R"], 16)
+    assert orc.limbs_to_ints(orc.fq_from_ints([1]))[0] == int(k["fq_R"], 16)
+    g = orc.g1_generator()
+    for case in k["msm"]:
+        bases = np.concatenate([orc.g1_to_affine(orc.g1_mul(g, orc.fr_from_ints([d])[0])) for d in case["base_dlogs"]])
+        res = orc.g1_to_affine(orc.best_multiexp(orc.fr_from_ints(case["scalars"]), bases))
+        want = [int(c, 16) for c in k["g1_multiples"][str(case["result_dlog"])]]
+        assert orc.g1_affine_to_ints(res) == [tuple(want)]
+    for case in k["ntt"]:
+        w = orc.fr_from_ints([int(k["omega"][str(case["log_n"])], 16)])[0]
+        got = orc.fr_to_ints(orc.best_fft(orc.fr_from_ints(case["input"]), w, case["log_n"]))
+        assert got == [int(v, 16) for v in case["output"]]

@@ -206,3 +206,23 @@ def test_emulated_theta_compression(emu, orc, pyref):
 @pytest.mark.gpu
 def test_gpu_theta_compression(gpu, orc, pyref):
     _theta_compression_case(gpu, orc, pyref, 12, 4)
+
+
+def _bench_program_case(be, orc, pyref, k):
+    """The sgx-shaped program that bench.py times (24 degree-3 gates, 16 permutation columns in 6 sets, 11 lookups), at small k."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    import zk_dcap_verifier_amd as z
+    prog = bench.sgx_shaped_program(z, k, k + 2, 25, 18, 11, 16, 5)
+    qc.run_case(be, orc, pyref, pc, prog, seed=77)
+
+
+def test_emulated_bench_program(emu, orc, pyref):
+    _bench_program_case(emu, orc, pyref, 3)
+
+
+@pytest.mark.gpu
+def test_gpu_bench_program(gpu, orc, pyref):
+    _bench_program_case(gpu, orc, pyref, 9)

@@ -136,9 +136,11 @@ ZK_KERNEL void msm_scan_kernel(MsmPlan p) {
         uint32_t e = ceil_div(cnt, p.L);
         mx = e > mx ? e : mx;
 #pragma unroll
-        for (uint32_t r = 0; r <= MSM_MAX_LEVELS; r++) {     // levels beyond R are never read
-            sum[1 + r] += e;
-            e = (e + (1u << mlog) - 1) >> mlog;
+        for (uint32_t r = 0; r <= MSM_MAX_LEVELS; r++) {     // (uniform guard: levels beyond R are never read)
+            if (r <= p.R) {
+                sum[1 + r] += e;
+                e = (e + (1u << mlog) - 1) >> mlog;
+            }
         }
     }
 #pragma unroll
@@ -168,9 +170,11 @@ ZK_KERNEL void msm_scan_kernel(MsmPlan p) {
         uint32_t e = ceil_div(cnt, p.L);
 #pragma unroll
         for (uint32_t r = 0; r <= MSM_MAX_LEVELS; r++) {
-            if (r <= p.R) suboff[(size_t)r * (B + 1) + b] = ex[1 + r];
-            ex[1 + r] += e;
-            e = (e + (1u << mlog) - 1) >> mlog;
+            if (r <= p.R) {
+                suboff[(size_t)r * (B + 1) + b] = ex[1 + r];
+                ex[1 + r] += e;
+                e = (e + (1u << mlog) - 1) >> mlog;
+            }
         }
     }
     if (tid == T - 1) {

@@ -202,24 +202,46 @@ def cpu_baseline(cfg, threads):
                       "C restatement of halo2 CPU algorithms (pthreads), not the Rust binary"}
 
 
-def msm_microbench(be, log_n, seed, reps=3):
+def _ints(a):
+    """(n, 4) uint64 limbs -> list of Python ints (the raw 256-bit values)."""
+    b = np.ascontiguousarray(a, dtype="<u8").tobytes()
+    return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+
+def msm_microbench(be, log_n, seed, reps=3, verify=False):
+    """SURVEY 8d cfg 3: bases P_i = [k_i]G built on the GPU, uniform scalars.  verify: the closed form
+    MSM(s, P) = [sum_i s_i k_i mod r] G, checked against the (independent) fixed-base path of the library."""
     n = 1 << log_n
-    ks = be.to_device(rand_fr(n, seed))
+    kh = rand_fr(n, seed)
+    ks = be.to_device(kh)
     pts = be.alloc(n * 64)
     be.g1_fixed_base_mul(ks, n, pts)
     t = time.time(); h = be.bases_register((pts, n)); t_reg = time.time() - t
     pts.free()
     sc = rand_fr(n, seed + 1)
     ks.upload(sc)
-    be.msm(h, ks, n)
+    res = be.msm(h, ks, n)
     t = time.time()
     for _ in range(reps):
         be.msm(h, ks, n)
     dt = (time.time() - t) / reps
+    out = {"log_n": log_n, "ms": round(dt * 1e3, 3), "Mscalar_per_s": round(n / dt / 1e6, 2), "hbm_frac_algorithmic": round(96 * n / dt / 1e9 / HBM_PEAK_GBS, 5),
+           "table_expand_s": round(t_reg, 3)}
+    if verify:
+        # the limb arrays are Montgomery forms: value = limbs * R^-1; sum_i s_i k_i = (sum_i S_i K_i) * R^-2, and the
+        # fixed-base kernel takes a Montgomery scalar, so feed it (sum S_i K_i) * R^-1
+        rinv = pow(1 << 256, -1, R_MOD)
+        tot = sum(a * b for a, b in zip(_ints(kh), _ints(sc))) % R_MOD * rinv % R_MOD
+        one = be.to_device(np.array([[(tot >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]], dtype=np.uint64))
+        o = be.alloc(64)
+        be.g1_fixed_base_mul(one, 1, o)
+        want = o.download((8,))
+        out["closed_form_check"] = bool((res[:8] == want).all())
+        one.free()
+        o.free()
     be.bases_release(h)
     ks.free()
-    return {"log_n": log_n, "ms": round(dt * 1e3, 3), "Mscalar_per_s": round(n / dt / 1e6, 2), "hbm_frac_algorithmic": round(96 * n / dt / 1e9 / HBM_PEAK_GBS, 5),
-            "table_expand_s": round(t_reg, 3)}
+    return out
 
 
 def main(argv=None):
@@ -356,7 +378,7 @@ def main(argv=None):
             except Exception as e:  # the baseline is a report, never a dependency of the measurement
                 cpu = {"error": str(e)}
             try:
-                extra["msm_2^20"] = msm_microbench(be, 20, 20241008)
+                extra["msm_2^20"] = msm_microbench(be, 20, 20241008, verify=True)
                 extra["msm_2^24"] = msm_microbench(be, 24, 20241010, reps=2)
             except Exception as e:
                 extra["msm_microbench_error"] = str(e)
@@ -365,47 +387,71 @@ def main(argv=None):
                 cols = 25
                 buf = be.to_device(rand_fr(n22, 20241011))
                 w22 = np.array([((pow(7, (R_MOD - 1) >> 22, R_MOD) << 256) % R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+                h22 = rand_fr(n22, 20241011)
                 be.ntt_dev(buf, 22, w22)
+                w22i = np.array([((pow(pow(7, (R_MOD - 1) >> 22, R_MOD), -1, R_MOD) << 256) % R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+                be.ntt_dev(buf, 22, w22i)                       # round trip: iNTT(NTT(a)) = n * a
+                ninv = np.array([((pow(n22, -1, R_MOD) << 256) % R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+                be.fr_scale_dev(buf, ninv, buf, n22)
+                roundtrip_ok = bool((buf.download((n22, 4)) == h22).all())
                 t = time.time()
                 for _ in range(cols):
                     be.ntt_dev(buf, 22, w22)
                 d22 = time.time() - t
-                extra["ntt_2^22_x25"] = {"ms_per_column": round(d22 / cols * 1e3, 3), "GB_per_s_algorithmic": round(64 * n22 * cols / d22 / 1e9, 1),
+                extra["ntt_2^22_x25"] = {"ms_per_column": round(d22 / cols * 1e3, 3), "GB_per_s_algorithmic": round(64 * n22 * cols / d22 / 1e9, 1), "roundtrip_check": roundtrip_ok,
                                          "hbm_frac": round(64 * n22 * cols / d22 / 1e9 / HBM_PEAK_GBS, 4)}
                 buf.free()
             except Exception as e:
                 extra["ntt_microbench_error"] = str(e)
     if world > 1 and not args.no_extras:
-        # MSM with the base table sharded over the ranks: partial XYZZ points all-gathered over RCCL/xGMI
-        try:
-            logn = int(os.environ.get("ZK_BENCH_SHARDED_LOG_N", "24"))
-            n_loc = (1 << logn) // world
-            ks = be.to_device(rand_fr(n_loc, 31 + rank))
-            pts = be.alloc(n_loc * 64)
-            be.g1_fixed_base_mul(ks, n_loc, pts)
-            h = be.bases_register((pts, n_loc))
-            pts.free()
-            ks.upload(rand_fr(n_loc, 77 + rank))
-            gather = [torch.zeros(16, dtype=torch.int64, device=tdev) for _ in range(world)]
+        # MSM with the base table sharded over the ranks (SURVEY 8d cfg 5 / 8e): rank g holds bases and scalars
+        # [g*N/G, (g+1)*N/G); the 128-byte XYZZ partials are all-gathered over RCCL/xGMI and summed on every rank.
+        sizes = [int(x) for x in os.environ.get("ZK_BENCH_SHARDED_LOG_N", "21,24").split(",")]
+        for logn in sizes:
+            try:
+                n_loc = (1 << logn) // world
+                kh = rand_fr(n_loc, 31 + rank)
+                ks = be.to_device(kh)
+                pts = be.alloc(n_loc * 64)
+                be.g1_fixed_base_mul(ks, n_loc, pts)
+                h = be.bases_register((pts, n_loc))
+                pts.free()
+                sh = rand_fr(n_loc, 77 + rank)
+                ks.upload(sh)
+                gather = [torch.zeros(16, dtype=torch.int64, device=tdev) for _ in range(world)]
 
-            def sharded():
-                part = be.msm_partial(h, ks, n_loc)
-                mine = torch.from_numpy(part.view(np.int64).copy()).to(tdev)
-                dist.all_gather(gather, mine)
-                parts = torch.stack(gather).cpu().numpy().view(np.uint64)
-                return be.g1_sum_xyzz(parts)
-            sharded()
-            barrier()
-            t = time.time()
-            for _ in range(3):
-                sharded()
-            barrier()
-            ds = (time.time() - t) / 3
-            extra[f"msm_sharded_2^{logn}"] = {"ranks": world, "ms": round(ds * 1e3, 3), "Mscalar_per_s": round((1 << logn) / ds / 1e6, 2)}
-            be.bases_release(h)
-            ks.free()
-        except Exception as e:
-            extra["msm_sharded_error"] = str(e)
+                def sharded():
+                    part = be.msm_partial(h, ks, n_loc)
+                    mine = torch.from_numpy(part.view(np.int64).copy()).to(tdev)
+                    dist.all_gather(gather, mine)
+                    parts = torch.stack(gather).cpu().numpy().view(np.uint64)
+                    return be.g1_sum_xyzz(parts)
+                res = sharded()
+                barrier()
+                t = time.time()
+                for _ in range(3):
+                    sharded()
+                barrier()
+                ds = (time.time() - t) / 3
+                rec = {"ranks": world, "ms": round(ds * 1e3, 3), "Mscalar_per_s": round((1 << logn) / ds / 1e6, 2)}
+                if logn <= 21:   # closed form across ranks: sum over all shards of s_i k_i, checked via the fixed-base path
+                    rinv = pow(1 << 256, -1, R_MOD)
+                    loc = sum(a_ * b_ for a_, b_ in zip(_ints(kh), _ints(sh))) % R_MOD
+                    lt = torch.tensor([(loc >> (62 * i)) & ((1 << 62) - 1) for i in range(5)], dtype=torch.int64, device=tdev)
+                    allp = [torch.zeros(5, dtype=torch.int64, device=tdev) for _ in range(world)]
+                    dist.all_gather(allp, lt)
+                    tot = sum(sum(int(v) << (62 * i) for i, v in enumerate(p_.cpu().tolist())) for p_ in allp) % R_MOD * rinv % R_MOD
+                    one = be.to_device(np.array([[(tot >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]], dtype=np.uint64))
+                    o = be.alloc(64)
+                    be.g1_fixed_base_mul(one, 1, o)
+                    rec["closed_form_check"] = bool((res[:8] == o.download((8,))).all())
+                    one.free()
+                    o.free()
+                extra[f"msm_sharded_2^{logn}"] = rec
+                be.bases_release(h)
+                ks.free()
+            except Exception as e:
+                extra[f"msm_sharded_2^{logn}_error"] = str(e)
 
     if rank == 0:
         line = {"metric": "proofs/hour sgx_dcap_verifier k=19 (GPU hot path: MSM+NTT+quotient op-mix of create_proof; host witness/transcript excluded)",

@@ -67,5 +67,5 @@ def test_bench_two_ranks_gloo(built, tmp_path):
     mp.spawn(_bench_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     out0 = open(tmp_path / "rank0.txt").read().strip().splitlines()
     line = json.loads(out0[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "msm_sharded_2^7" in line["extra"], line["extra"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["extra"]["msm_sharded_2^7"]["closed_form_check"] is True, line["extra"]
     assert open(tmp_path / "rank1.txt").read().strip() == ""

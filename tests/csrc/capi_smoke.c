@@ -1,0 +1,60 @@
+/* Plain-C consumer of include/zkmi355.h — what a cgo / Rust `extern "C"` binding sees: no HIP, no C++, no Python.
+ * Exit codes: 0 all checks passed, 3 no usable GPU (zk_ctx_create -> ZK_ERR_NODEV), 1 a check failed. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "zkmi355.h"
+
+#define N 4096
+#define CK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, zk_last_error(ctx)); return 1; } } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t next64(void) { uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+
+int main(void) {
+    zk_ctx* ctx = NULL;
+    int rc = zk_ctx_create(0, &ctx);
+    if (rc == ZK_ERR_NODEV) { printf("no usable GPU (ZK_ERR_NODEV) - there is no CPU fallback\n"); return 3; }
+    if (rc) { fprintf(stderr, "zk_ctx_create -> %d\n", rc); return 1; }
+    printf("%s\n", zk_version());
+
+    static uint64_t scal[3][N][4], ks[N][4];
+    for (int c = 0; c < 3; c++) for (int i = 0; i < N; i++) for (int l = 0; l < 4; l++) scal[c][i][l] = next64() >> (l == 3 ? 3 : 0);   /* < 2^253 < r */
+    for (int i = 0; i < N; i++) for (int l = 0; l < 4; l++) ks[i][l] = next64() >> (l == 3 ? 3 : 0);
+
+    /* an SRS-shaped table built on the device, then MSMs through the host-buffer entry points */
+    void *d_ks, *d_pts;
+    CK(zk_dev_alloc(ctx, sizeof ks, &d_ks)); CK(zk_dev_alloc(ctx, (size_t)N * 64, &d_pts));
+    CK(zk_dev_upload(ctx, d_ks, ks, sizeof ks));
+    CK(zk_g1_fixed_base_mul_dev(ctx, d_ks, N, d_pts));
+    uint64_t bases; CK(zk_bases_register_dev(ctx, d_pts, N, &bases));
+    uint64_t single[3][12], batch[3][12];
+    const void* cols[3] = { scal[0], scal[1], scal[2] };
+    for (int c = 0; c < 3; c++) CK(zk_msm(ctx, bases, scal[c], N, single[c]));
+    CK(zk_msm_batch(ctx, bases, cols, 3, N, batch));
+    if (memcmp(single, batch, sizeof single)) { fprintf(stderr, "zk_msm and zk_msm_batch disagree\n"); return 1; }
+    int nonzero = 0; for (int l = 0; l < 8; l++) nonzero |= single[0][l] != 0;
+    if (!nonzero) { fprintf(stderr, "MSM of random scalars returned the identity\n"); return 1; }
+
+    /* NTT round trip on a host buffer: iNTT(NTT(a)) = n * a, checked against a device-side scaling of a */
+    static uint64_t a[N][4], b[N][4], na[N][4];
+    memcpy(a, scal[0], sizeof a); memcpy(b, a, sizeof a);
+    /* omega_12 = ROOT_OF_UNITY^(2^16): obtained by squaring on the device would need field ops; use the domain wrappers instead */
+    CK(zk_lagrange_to_coeff(ctx, b, 12));           /* b = iNTT(a) / n  */
+    void* d_b; CK(zk_dev_alloc(ctx, sizeof b, &d_b));
+    CK(zk_dev_upload(ctx, d_b, b, sizeof b));
+    CK(zk_coeff_to_lagrange_dev(ctx, d_b, 12));     /* NTT back: must reproduce a */
+    CK(zk_dev_download(ctx, na, d_b, sizeof na));
+    if (memcmp(na, a, sizeof a)) { fprintf(stderr, "lagrange_to_coeff / coeff_to_lagrange round trip failed\n"); return 1; }
+
+    /* error path: unknown handle must fail cleanly with a message */
+    uint64_t out[12];
+    if (zk_msm(ctx, 0xdeadbeef, scal[0], N, out) != ZK_ERR_ARG || !strlen(zk_last_error(ctx))) { fprintf(stderr, "error path broken\n"); return 1; }
+
+    CK(zk_bases_release(ctx, bases));
+    CK(zk_dev_free(ctx, d_ks)); CK(zk_dev_free(ctx, d_pts)); CK(zk_dev_free(ctx, d_b));
+    zk_ctx_destroy(ctx);
+    printf("capi_smoke OK\n");
+    return 0;
+}

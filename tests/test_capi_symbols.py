@@ -44,3 +44,25 @@ def test_product_never_references_oracle_or_emulator():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("no CPU", "") or f == "_lib.py" and "import oracle" not in txt, f
                 assert "libzkmi355_emu" not in txt, f
+
+
+def _run_capi_smoke():
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "csrc", "capi_smoke")
+    return subprocess.run([exe], capture_output=True, text=True, timeout=300)
+
+
+def test_plain_c_consumer_without_gpu(built):
+    """tests/csrc/capi_smoke.c is compiled by gcc against include/zkmi355.h only (no HIP, no C++): on a machine
+    without a GPU it must report ZK_ERR_NODEV cleanly (exit code 3) — there is no CPU fallback behind the ABI."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = _run_capi_smoke()
+    assert r.returncode == 3 and "no CPU fallback" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_on_gpu():
+    r = _run_capi_smoke()
+    assert r.returncode == 0 and "capi_smoke OK" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -156,6 +156,10 @@ int zk_lookup_permute_dev(zk_ctx* ctx, const void* input, const void* table, uin
 int zk_eval_polynomial_batch_dev(zk_ctx* ctx, const void* const* polys_dev, size_t count, size_t n, const void* points, void* out);
 /* halo2_proofs src/arithmetic.rs kate_division(a, b): q(X) = (a(X) - a(b)) / (X - b); a: n coefficients, q: n - 1 (DEVICE); b: HOST 32 B */
 int zk_kate_division_dev(zk_ctx* ctx, const void* a_dev, size_t n, const void* b, void* q_dev);
+/* halo2_proofs src/poly/kzg/multiopen/shplonk/prover.rs — the `poly * power_of_y … reduce(acc + &poly)` combinations of create_proof:
+ * out[i] = sum_j scalars[j] * polys[j][i], i < n, in one pass.  polys: HOST array of `count` DEVICE polynomials (n coefficients each);
+ * scalars: HOST count x 32 B; out_dev: DEVICE n x 32 B (may alias one of the inputs). */
+int zk_fr_lincomb_dev(zk_ctx* ctx, const void* const* polys_dev, const void* scalars, size_t count, size_t n, void* out_dev);
 
 /* ---- quotient: replaces plonk::evaluation::Evaluator::evaluate_h ---------------------------- *
  * halo2_proofs src/plonk/evaluation.rs.  The compiled GraphEvaluator of a proving key is uploaded

@@ -12,11 +12,13 @@ meaning and error behaviour — so that tests read like the reference's own:
     kzg.ParamsKZG.commit / commit_lagrange       (halo2_proofs::poly::kzg::commitment)
     evaluation.Evaluator.evaluate_h              (halo2_proofs::plonk::evaluation)
     permutation.permutation_commit / lookup_commit_product   (plonk::{permutation,lookup}::prover grand products)
+    plonk.keygen / plonk.create_proof / plonk.ProverSHPLONK  (plonk::{keygen_vk, keygen_pk, create_proof}, multiopen::ProverSHPLONK)
+    transcript.Blake2bWrite / Blake2bRead                    (halo2_proofs::transcript — host, unchanged)
 
 There is no CPU fallback: importing works anywhere, but creating a Backend without the HIP
 library or without a GPU raises.
 """
 from ._lib import Backend, ZkError, LIB_PATH, default_backend  # noqa: F401
-from . import arithmetic, domain, kzg, evaluation, permutation  # noqa: F401
+from . import arithmetic, domain, kzg, evaluation, permutation, fields, transcript, plonk  # noqa: F401
 
-__all__ = ["Backend", "ZkError", "LIB_PATH", "default_backend", "arithmetic", "domain", "kzg", "evaluation"]
+__all__ = ["Backend", "ZkError", "LIB_PATH", "default_backend", "arithmetic", "domain", "kzg", "evaluation", "permutation", "plonk", "transcript", "fields"]

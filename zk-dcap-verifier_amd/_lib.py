@@ -308,6 +308,13 @@ class Backend:
         bb = self._fe(b)
         self._ck(self.lib.zk_kate_division_dev(self.ctx, C.c_void_p(_dptr(a_dev)), C.c_size_t(n), bb.ctypes.data_as(C.c_void_p), C.c_void_p(_dptr(q_dev))))
 
+    def fr_lincomb_dev(self, polys, scalars, n: int, out_dev):
+        """out[i] = sum_j scalars[j] * polys[j][i] (SHPLONK combinations) in one pass; scalars: (count, 4) Montgomery limbs."""
+        sc = np.ascontiguousarray(np.asarray(scalars, dtype=np.uint64).reshape(-1, 4))
+        assert sc.shape[0] == len(polys)
+        self._ck(self.lib.zk_fr_lincomb_dev(self.ctx, self._ptr_array(polys), sc.ctypes.data_as(C.c_void_p), C.c_size_t(len(polys)), C.c_size_t(n),
+                                            C.c_void_p(_dptr(out_dev))))
+
     # -- quotient -------------------------------------------------------------------------------
     def quotient_program_load(self, blob: bytes) -> int:
         h = C.c_uint64()

@@ -21,6 +21,7 @@ int lookup_product(zk_ctx* ctx, const void* cin, const void* ctab, const void* p
                    const void* blinding, uint32_t bf, void* d_z);
 int eval_polynomial_batch(zk_ctx* ctx, const void* const* polys, size_t count, size_t n, const void* points, void* out);
 int kate_division(zk_ctx* ctx, const void* d_a, size_t n, const void* b_host, void* d_q);
+int fr_lincomb(zk_ctx* ctx, const void* const* polys, const void* scalars, size_t count, size_t n, void* d_out);
 int pk_load(zk_ctx* ctx, uint64_t prog, const void* const* fixed, const void* const* sigma, const void* l0, const void* l_last, const void* l_active,
             int form, uint64_t* handle);
 int pk_release(zk_ctx* ctx, uint64_t h);
@@ -254,6 +255,7 @@ int zk_eval_polynomial_batch_dev(zk_ctx* ctx, const void* const* polys, size_t c
     ENTER; return eval_polynomial_batch(ctx, polys, count, n, points, out);
 }
 int zk_kate_division_dev(zk_ctx* ctx, const void* a_dev, size_t n, const void* b, void* q_dev) { ENTER; return kate_division(ctx, a_dev, n, b, q_dev); }
+int zk_fr_lincomb_dev(zk_ctx* ctx, const void* const* polys_dev, const void* scalars, size_t count, size_t n, void* out_dev) { ENTER; return fr_lincomb(ctx, polys_dev, scalars, count, n, out_dev); }
 
 // ---- quotient -----------------------------------------------------------------------------------
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog) { ENTER; return quotient_program_load(ctx, blob, len, prog); }

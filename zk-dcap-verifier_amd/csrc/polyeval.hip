@@ -142,6 +142,27 @@ ZK_KERNEL void kd_carry_kernel(void* carries, uint32_t nblk, void* out) {
     }
 }
 
+
+// ---- linear combinations (SHPLONK / multiopen polynomial combos) -----------------------------------
+// out[i] = sum_j s_j * p_j[i]: the `poly * power_of_y` ... `reduce(|acc, poly| acc + &poly)` chains of
+// halo2_proofs src/poly/kzg/multiopen/shplonk/prover.rs, one pass over all inputs instead of one pass per term.
+// args: [count pointers | pad to 32 B | count scalars]; a scalar equal to mont(1) skips its multiplication.
+ZK_KERNEL void pe_lincomb_kernel(const void* const* polys, const void* scalars, uint32_t count, size_t n, void* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const u256 one = Fr::one();
+    for (; i < n; i += stride) {
+        u256 acc = Fr::zero();
+        for (uint32_t j = 0; j < count; j++) {
+            const u256 s = load_u256(scalars, j);
+            u256 v = load_u256(polys[j], i);
+            if (!Fr::eq(s, one)) v = Fr::mul(v, s);
+            acc = Fr::add(acc, v);
+        }
+        store_u256(out, i, acc);
+    }
+}
+
 // ---- host ------------------------------------------------------------------------------------------
 int eval_polynomial_batch(zk_ctx* ctx, const void* const* polys, size_t count, size_t n, const void* points, void* out) {
     if (!polys || !points || !out) return ctx->fail(ZK_ERR_ARG, "zk_eval_polynomial_batch_dev: null argument");
@@ -179,6 +200,25 @@ int kate_division(zk_ctx* ctx, const void* d_a, size_t n, const void* b_host, vo
     ZK_LAUNCH(kd_carry_kernel, 1, 64, 0, st, pairs, nblk, cin);
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(kd_scan_kernel, nblk, PE_T, 0, st, d_a, (uint32_t)n, b, 1, cin, d_q);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipStreamSynchronize(st));
+    return ZK_OK;
+}
+
+int fr_lincomb(zk_ctx* ctx, const void* const* polys, const void* scalars, size_t count, size_t n, void* d_out) {
+    if (!polys || !scalars || !d_out) return ctx->fail(ZK_ERR_ARG, "zk_fr_lincomb_dev: null argument");
+    if (count == 0 || count > 65535) return ctx->fail(ZK_ERR_ARG, "zk_fr_lincomb_dev: count out of range");
+    if (n == 0) return ZK_OK;
+    for (size_t i = 0; i < count; i++) if (!polys[i]) return ctx->fail(ZK_ERR_ARG, "zk_fr_lincomb_dev: null polynomial %zu", i);
+    const size_t off_sc = (count * sizeof(void*) + 31) & ~(size_t)31;
+    ZK_HIP(ctx->ws_tmp.ensure(off_sc + count * 32));
+    char* base = (char*)ctx->ws_tmp.p;
+    hipStream_t st = ctx->stream;
+    ZK_HIP(hipMemcpyAsync(base, polys, count * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(base + off_sc, scalars, count * 32, hipMemcpyHostToDevice, st));
+    const int blk = ctx->tune.vec_block;
+    size_t grid = (n + blk - 1) / blk; if (grid > 8192) grid = 8192;
+    ZK_LAUNCH(pe_lincomb_kernel, (uint32_t)grid, blk, 0, st, (const void* const*)base, (const void*)(base + off_sc), (uint32_t)count, n, d_out);
     ZK_CHECK_LAUNCH();
     ZK_HIP(hipStreamSynchronize(st));
     return ZK_OK;

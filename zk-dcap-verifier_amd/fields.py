@@ -1,0 +1,84 @@
+"""Host-side BN254 scalar / base field helpers for the prover's O(proof size) logic (challenges, evaluation
+points, point encoding) — the part of halo2's `create_proof` that stays on the host in the reference too
+(SURVEY.md §8a rows a16/a17).  Bulk arithmetic never goes through here: columns live in HBM as raw Montgomery
+limbs (halo2curves::bn256::{Fr, Fq} layout, [u64; 4] little endian, R = 2^256).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001   # Fr
+P_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47   # Fq
+S = 28
+MULT_GEN = 7
+ROOT_OF_UNITY = pow(MULT_GEN, (R_MOD - 1) >> S, R_MOD)
+DELTA = pow(MULT_GEN, 1 << S, R_MOD)
+ZETA = pow(MULT_GEN, (R_MOD - 1) // 3, R_MOD)
+_MASK = 0xFFFFFFFFFFFFFFFF
+_RINV_R = pow(1 << 256, -1, R_MOD)
+_RINV_P = pow(1 << 256, -1, P_MOD)
+
+
+def limbs(v: int) -> np.ndarray:
+    return np.array([(v >> (64 * i)) & _MASK for i in range(4)], dtype=np.uint64)
+
+
+def unlimbs(a) -> int:
+    a = np.asarray(a, dtype=np.uint64).reshape(-1)
+    return sum(int(a[i]) << (64 * i) for i in range(4))
+
+
+def fr_mont(x: int) -> np.ndarray:
+    """canonical int -> Montgomery limbs (what Rust holds for an Fr)."""
+    return limbs(((x % R_MOD) << 256) % R_MOD)
+
+
+def fr_int(a) -> int:
+    """Montgomery limbs -> canonical int."""
+    return unlimbs(a) * _RINV_R % R_MOD
+
+
+def fq_mont(x: int) -> np.ndarray:
+    return limbs(((x % P_MOD) << 256) % P_MOD)
+
+
+def fq_int(a) -> int:
+    return unlimbs(a) * _RINV_P % P_MOD
+
+
+def fr_mont_array(vals) -> np.ndarray:
+    """list of canonical ints -> (n, 4) uint64 Montgomery array."""
+    out = np.empty((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        m = ((int(v) % R_MOD) << 256) % R_MOD
+        out[i, 0] = m & _MASK
+        out[i, 1] = (m >> 64) & _MASK
+        out[i, 2] = (m >> 128) & _MASK
+        out[i, 3] = m >> 192
+    return out
+
+
+def fr_int_array(a) -> list:
+    b = np.ascontiguousarray(a, dtype="<u8").tobytes()
+    return [int.from_bytes(b[i:i + 32], "little") * _RINV_R % R_MOD for i in range(0, len(b), 32)]
+
+
+def omega(k: int) -> int:
+    return pow(ROOT_OF_UNITY, 1 << (S - k), R_MOD)
+
+
+def g1_affine_ints(jac12) -> tuple | None:
+    """normalised G1 {x, y, z} (12 limbs; z = mont(1) or all zero) from zk_msm -> canonical affine (x, y) or None."""
+    j = np.asarray(jac12, dtype=np.uint64).reshape(12)
+    if not j[8:12].any():
+        return None
+    return fq_int(j[0:4]), fq_int(j[4:8])
+
+
+def rand_fr_array(rng: np.random.Generator, n: int) -> np.ndarray:
+    """n field elements as raw limb patterns below 2^253 (< r), used directly as Montgomery forms.  This is the
+    mirror's stand-in for `Fr::random(&mut rng)` draws (blinding rows / the vanishing argument's random polynomial):
+    deterministic under the caller's seeded generator, which is what makes proof bytes reproducible."""
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 61) - 1)
+    return a

@@ -1,0 +1,15 @@
+"""halo2_proofs::plonk — the prover side the reference calls (keygen_vk / keygen_pk / create_proof at
+circuits/src/sgx_dcap_verifier.rs:803,807,814-822), as a host-side mirror over the MI355X product API.
+
+    ConstraintSystem, Assembly, Expression (Advice / Fixed / Instance / Constant …)      circuit description
+    keygen(params, cs, fixed_columns, assembly) -> ProvingKey                            keygen_vk + keygen_pk
+    create_proof(params, pk, advice_columns, instances, rng, transcript)                 plonk::create_proof + ProverSHPLONK
+
+verify_proof is not part of the product (verifier side, out of scope); the acceptance oracle used by
+the tests is oracle/verifier.py.
+"""
+from .circuit import ADVICE, FIXED, INSTANCE, Assembly, ConstraintSystem, LookupArgument  # noqa: F401
+from .expression import Advice, Constant, Expression, Fixed, Instance  # noqa: F401
+from .keygen import ProvingKey, VerifyingKey, compile_program, keygen  # noqa: F401
+from .prover import create_proof  # noqa: F401
+from .shplonk import ProverSHPLONK  # noqa: F401

@@ -1,0 +1,150 @@
+"""halo2_proofs::plonk::{ConstraintSystem, permutation::keygen::Assembly}, host side.
+
+Mirrors (halo2_proofs 0.2.0 @ zkwebauthn c254c75, Cargo.lock:1314-1327) src/plonk/circuit.rs `ConstraintSystem<F>` —
+what `Circuit::configure` fills in (the sgx circuit: circuits/src/sgx_dcap_verifier.rs:139-238) — restricted to what
+the prover's hot path reads: column counts, gate polynomials, lookup arguments, the permutation's column list, the
+query lists, `degree()` and `blinding_factors()`.  Selectors are ordinary fixed columns
+here (halo2 compresses them into fixed columns before keygen, so the prover never sees a selector either).
+The circuit source itself (chips, regions, layouter, witness synthesis) is host code the north star leaves
+unchanged; this mirror only describes its *output*.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence, Tuple
+
+from ..fields import DELTA, R_MOD, omega
+from . import expression as ex
+
+ADVICE, FIXED, INSTANCE = 0, 1, 2      # column_type numbering of the ZKQ1 blob
+
+
+@dataclass
+class LookupArgument:
+    """plonk::lookup::Argument { input_expressions, table_expressions }"""
+    input_expressions: List[ex.Expression]
+    table_expressions: List[ex.Expression]
+
+    def required_degree(self) -> int:
+        din = max([1] + [ex.degree(e) for e in self.input_expressions])
+        dt = max([1] + [ex.degree(e) for e in self.table_expressions])
+        return max(4, 2 + din + dt)
+
+
+@dataclass
+class ConstraintSystem:
+    num_fixed_columns: int = 0
+    num_advice_columns: int = 0
+    num_instance_columns: int = 0
+    gates: List[ex.Expression] = field(default_factory=list)            # every polynomial of every gate, in order
+    lookups: List[LookupArgument] = field(default_factory=list)
+    permutation_columns: List[Tuple[int, int]] = field(default_factory=list)   # (column_type, index) — enable_equality order
+    minimum_degree: int = 1
+
+    # -- construction (ConstraintSystem::{create_gate, lookup, enable_equality}) -------------------------------------
+    def create_gate(self, *polys: ex.Expression) -> None:
+        self.gates.extend(polys)
+
+    def lookup(self, pairs: Sequence[Tuple[ex.Expression, ex.Expression]]) -> int:
+        self.lookups.append(LookupArgument([p[0] for p in pairs], [p[1] for p in pairs]))
+        return len(self.lookups) - 1
+
+    def enable_equality(self, column_type: int, index: int) -> None:
+        if (column_type, index) not in self.permutation_columns:
+            self.permutation_columns.append((column_type, index))
+
+    # -- derived quantities -------------------------------------------------------------------------------------------
+    def _queries(self) -> Dict[Tuple[str, int, int], None]:
+        q: Dict[Tuple[str, int, int], None] = {}
+        for g in self.gates:
+            ex.queries(g, q)
+        for lk in self.lookups:
+            for e in lk.input_expressions + lk.table_expressions:
+                ex.queries(e, q)
+        # permutation::Argument::add_column queries every equality-enabled column at Rotation::cur()
+        for t, i in self.permutation_columns:
+            q.setdefault(({ADVICE: "advice", FIXED: "fixed", INSTANCE: "instance"}[t], i, 0), None)
+        return q
+
+    def advice_queries(self) -> List[Tuple[int, int]]:
+        return [(c, r) for (k, c, r) in self._queries() if k == "advice"]
+
+    def fixed_queries(self) -> List[Tuple[int, int]]:
+        return [(c, r) for (k, c, r) in self._queries() if k == "fixed"]
+
+    def instance_queries(self) -> List[Tuple[int, int]]:
+        return [(c, r) for (k, c, r) in self._queries() if k == "instance"]
+
+    def degree(self) -> int:
+        d = 3 if self.permutation_columns else 1                       # permutation::Argument::required_degree
+        for lk in self.lookups:
+            d = max(d, lk.required_degree())
+        for g in self.gates:
+            d = max(d, ex.degree(g))
+        return max(d, self.minimum_degree)
+
+    def blinding_factors(self) -> int:
+        per_col = [0] * max(1, self.num_advice_columns)
+        for c, _ in self.advice_queries():
+            per_col[c] += 1
+        return max(3, max(per_col)) + 2
+
+    def permutation_chunk_len(self) -> int:
+        return self.degree() - 2
+
+    def usable_rows(self, k: int) -> int:
+        return (1 << k) - (self.blinding_factors() + 1)
+
+
+class Assembly:
+    """plonk::permutation::keygen::Assembly: union of copy-constraint cycles over the equality-enabled columns.
+    Cell successors are kept as two int32 planes (column, row) so a k = 19 circuit costs a few hundred MB, not GBs."""
+
+    def __init__(self, cs: ConstraintSystem, k: int):
+        import numpy as np
+        self.columns = list(cs.permutation_columns)
+        self.n = 1 << k
+        m = len(self.columns)
+        rows = np.arange(self.n, dtype=np.int32)
+        self.map_c = np.repeat(np.arange(m, dtype=np.int32)[:, None], self.n, axis=1)
+        self.map_r = np.repeat(rows[None, :], m, axis=0)
+        self.aux_c, self.aux_r = self.map_c.copy(), self.map_r.copy()
+        self.sizes = np.ones((m, self.n), dtype=np.int32)
+
+    def copy(self, left: Tuple[int, int, int], right: Tuple[int, int, int]) -> None:
+        """left/right = (column_type, index, row).  Mirrors Assembly::copy (cycle merge by swapping successors)."""
+        lc = self.columns.index((left[0], left[1]))
+        rc = self.columns.index((right[0], right[1]))
+        lr, rr = left[2], right[2]
+        lcyc = (int(self.aux_c[lc, lr]), int(self.aux_r[lc, lr]))
+        rcyc = (int(self.aux_c[rc, rr]), int(self.aux_r[rc, rr]))
+        if lcyc == rcyc:
+            return
+        if self.sizes[lcyc] < self.sizes[rcyc]:
+            lcyc, rcyc = rcyc, lcyc
+            lc, lr, rc, rr = rc, rr, lc, lr
+        self.sizes[lcyc] += self.sizes[rcyc]
+        i, j = rcyc
+        while True:                                                     # relabel the smaller cycle
+            self.aux_c[i, j], self.aux_r[i, j] = lcyc
+            i, j = int(self.map_c[i, j]), int(self.map_r[i, j])
+            if (i, j) == rcyc:
+                break
+        a = (self.map_c[lc, lr], self.map_r[lc, lr])
+        self.map_c[lc, lr], self.map_r[lc, lr] = self.map_c[rc, rr], self.map_r[rc, rr]
+        self.map_c[rc, rr], self.map_r[rc, rr] = a
+
+    def sigma_columns(self, k: int) -> List[List[int]]:
+        """build_pk's permutation polynomials in Lagrange form as canonical ints (small k / tests):
+        sigma_j[i] = DELTA^(j') * omega^(i') for (j', i') = mapping[j][i].  keygen_pk uses the array form below."""
+        w = omega(k)
+        wp = [1] * self.n
+        for i in range(1, self.n):
+            wp[i] = wp[i - 1] * w % R_MOD
+        dp = [pow(DELTA, j, R_MOD) for j in range(len(self.columns))]
+        return [[dp[int(self.map_c[j, i])] * wp[int(self.map_r[j, i])] % R_MOD for i in range(self.n)] for j in range(len(self.columns))]
+
+    def sigma_from_identity(self, ident):
+        """ident: (m, n, 4) uint64 — column j = the Montgomery limbs of DELTA^j * omega^i (built on the GPU as the NTT of
+        DELTA^j * X).  Returns the (m, n, 4) sigma columns: a pure gather through the successor planes."""
+        return ident[self.map_c, self.map_r]

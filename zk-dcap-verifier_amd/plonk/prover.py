@@ -1,0 +1,223 @@
+"""halo2_proofs::plonk::create_proof, MI355X edition — the caller of the whole hot path.
+
+Mirrors (halo2_proofs 0.2.0 @ zkwebauthn c254c75, Cargo.lock:1314-1327) src/plonk/prover.rs as the reference invokes it:
+    create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<Bn256>, Challenge255<G1Affine>, _, Blake2bWrite<..>, _>(
+        &params, &pk, &[circuit], &[&[]], &mut rng, &mut transcript)          circuits/src/sgx_dcap_verifier.rs:814-822
+Phase order, transcript traffic and the per-phase polynomial work follow SURVEY.md §3.1 steps 1-9 / App. C ([3P-MEM]: the
+pinned crate is not on this machine).  Witness synthesis (Circuit::synthesize, :351-733) is host code the north star leaves
+alone: this function receives its OUTPUT — the advice columns — exactly where halo2's prover has them after phase 2.
+Every O(n) step runs on the GPU through the product API and stays resident in HBM between phases:
+    commitments            zk_msm_batch_dev                 (one call per transcript phase)
+    theta-compression      expression programs on the quotient interpreter
+    permute_expression_pair / grand products               zk_lookup_permute_dev, zk_lookup_product_dev, zk_permutation_product_dev
+    lagrange_to_coeff / coeff_to_extended / evaluate_h / divide_by_vanishing / extended_to_coeff
+    evaluations            zk_eval_polynomial_batch_dev
+    SHPLONK                zk_fr_lincomb_dev, zk_kate_division_dev
+The host does what it does in the reference: Fiat-Shamir hashing, point encoding, O(#columns) bookkeeping.
+Single circuit instance per proof (the reference passes `&[circuit]`); no user challenges / multi-phase advice.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from ..fields import R_MOD, fr_int, fr_mont, fr_mont_array, g1_affine_ints, omega, rand_fr_array
+from ..kzg import ParamsKZG
+from ..permutation import lookup_commit_product, permutation_commit, permute_expression_pair
+from .circuit import ADVICE, FIXED, INSTANCE
+from .keygen import ProvingKey
+from .shplonk import ProverQuery, ProverSHPLONK
+
+
+def rotate_omega(x: int, rot: int, k: int) -> int:
+    """EvaluationDomain::rotate_omega."""
+    w = omega(k)
+    return x * pow(w, rot % (1 << k), R_MOD) % R_MOD
+
+
+def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances: Sequence[Sequence[int]], rng: np.random.Generator, transcript) -> dict:
+    """advice: cs.num_advice_columns columns of n rows — (n, 4) uint64 Montgomery host arrays or device buffers; rows past
+    `usable_rows` are overwritten with blinding (device buffers are modified in place).  instances: canonical ints per instance
+    column.  Writes the proof into `transcript`; returns phase timings-free bookkeeping (commitment count etc.) for tests."""
+    be, cs, k, n = pk.backend, pk.vk.cs, params.k, params.n
+    dom = pk.domain
+    ek, en = dom.extended_k, dom.extended_n
+    bf = cs.blinding_factors()
+    usable = n - (bf + 1)
+    L = len(cs.lookups)
+    assert len(advice) == cs.num_advice_columns and len(instances) == cs.num_instance_columns
+    owned = []                                                   # device buffers this proof allocated
+
+    def dev(nbytes):
+        d = be.alloc(nbytes)
+        owned.append(d)
+        return d
+
+    def commit_all(handle, cols):
+        return [g1_affine_ints(r) for r in be.msm_batch(handle, cols, n)] if cols else []
+
+    # ---- 1. vk, instances ---------------------------------------------------------------------------------------------
+    pk.vk.hash_into(transcript)
+    inst_values = []
+    for col in instances:
+        assert len(col) <= usable, "instance column longer than the usable rows"
+        for v in col:                                             # KZG: QUERY_INSTANCE = false -> values go straight into the transcript
+            transcript.common_scalar(v)
+        a = np.zeros((n, 4), dtype=np.uint64)
+        if len(col):
+            a[: len(col)] = fr_mont_array(col)
+        d = dev(n * 32)
+        d.upload(a)
+        inst_values.append(d)
+
+    # ---- 2. advice: blind the unusable rows, commit ----------------------------------------------------------------------
+    adv_values = []
+    for col in advice:
+        blind = rand_fr_array(rng, n - usable)
+        if isinstance(col, np.ndarray):
+            d = dev(n * 32)
+            d.upload(np.ascontiguousarray(col, dtype=np.uint64).reshape(n, 4))
+        else:
+            d = col
+        d.upload(blind, offset=usable * 32)
+        adv_values.append(d)
+    for pt in commit_all(params.g_lagrange.handle, adv_values):
+        transcript.write_point(pt)
+
+    # ---- 3. theta; lookups: compress, permute, commit --------------------------------------------------------------------
+    theta = transcript.squeeze_challenge()
+    one = fr_mont(1)
+    th = fr_mont(theta)
+    compressed, permuted = [], []
+    for (cin_ev, ctab_ev) in pk.lookup_compressors:
+        pair = []
+        for evl in (cin_ev, ctab_ev):
+            out = dev(n * 32)
+            anycol = pk.fixed_values[0] if pk.fixed_values else adv_values[0]
+            evl.evaluate_h(fixed=pk.fixed_values, advice=adv_values, instance=inst_values, l0=anycol, l_last=anycol, l_active_row=anycol,
+                           perm_cosets=[], perm_products=[], lookup_product=[], lookup_input=[], lookup_table=[], challenges=[],
+                           beta=one, gamma=one, theta=th, y=one, out=out)
+            pair.append(out)
+        compressed.append(pair)
+        bi, bt = rand_fr_array(rng, bf + 1), rand_fr_array(rng, bf + 1)
+        a, s = permute_expression_pair(pair[0], pair[1], k, bf, bi, bt, backend=be)   # raises ZkError when an input is not in the table
+        owned += [a, s]
+        permuted.append((a, s))
+    flat = [c for pr in permuted for c in pr]
+    for pt in commit_all(params.g_lagrange.handle, flat):           # per lookup: permuted input, permuted table
+        transcript.write_point(pt)
+
+    # ---- 4. beta, gamma; permutation and lookup grand products ---------------------------------------------------------------
+    beta = transcript.squeeze_challenge()
+    gamma = transcript.squeeze_challenge()
+    bt_m, gm_m = fr_mont(beta), fr_mont(gamma)
+    perm_values = []
+    for t, i in cs.permutation_columns:
+        perm_values.append({ADVICE: adv_values, FIXED: pk.fixed_values, INSTANCE: inst_values}[t][i])
+    chunk = cs.permutation_chunk_len()
+    n_sets = (len(perm_values) + chunk - 1) // chunk if perm_values else 0
+    zs = permutation_commit(perm_values, pk.sigma_values, k, cs.degree(), bt_m, gm_m, [rand_fr_array(rng, bf) for _ in range(n_sets)], backend=be) \
+        if perm_values else []
+    owned += zs
+    for pt in commit_all(params.g_lagrange.handle, zs):
+        transcript.write_point(pt)
+    lzs = []
+    for (cin, ctab), (a, s) in zip(compressed, permuted):
+        z = lookup_commit_product(cin, ctab, a, s, k, bt_m, gm_m, rand_fr_array(rng, bf), backend=be)
+        owned.append(z)
+        lzs.append(z)
+    for pt in commit_all(params.g_lagrange.handle, lzs):
+        transcript.write_point(pt)
+
+    # ---- 5. vanishing argument: random polynomial -----------------------------------------------------------------------------
+    random_poly = dev(n * 32)
+    random_poly.upload(rand_fr_array(rng, n))
+    transcript.write_point(g1_affine_ints(be.msm(params.g.handle, random_poly, n)))
+
+    # ---- 6. y; everything to coefficient form; h(X) ------------------------------------------------------------------------------
+    y = transcript.squeeze_challenge()
+    lag = adv_values + inst_values + zs + lzs + flat                 # the witness-dependent columns, Lagrange basis
+    be.lagrange_to_coeff_batch_dev(lag, k)                           # in place: from here on these buffers hold coefficients
+    adv_polys, inst_polys = adv_values, inst_values
+    ext = [dev(en * 32) for _ in lag]
+    be.coeff_to_extended_batch_dev(lag, ext, k, ek)
+    nA, nI, nZ = len(adv_polys), len(inst_polys), len(zs)
+    e_adv, e_inst = ext[:nA], ext[nA:nA + nI]
+    e_zs, e_lz = ext[nA + nI:nA + nI + nZ], ext[nA + nI + nZ:nA + nI + nZ + L]
+    e_perm = ext[nA + nI + nZ + L:]
+    h_ext = dev(en * 32)
+    pk.evaluator.evaluate_h(fixed=pk.fixed_cosets, advice=e_adv, instance=e_inst, l0=pk.l0, l_last=pk.l_last, l_active_row=pk.l_active_row,
+                            perm_cosets=pk.sigma_cosets, perm_products=e_zs, lookup_product=e_lz, lookup_input=e_perm[0::2],
+                            lookup_table=e_perm[1::2], challenges=[], beta=bt_m, gamma=gm_m, theta=th, y=fr_mont(y), out=h_ext)
+    for d in ext:                                                   # the cosets are dead once the numerator exists
+        d.free()
+        owned.remove(d)
+    # ---- 7. vanishing::construct: divide, back to coefficients, split into d-1 pieces, commit ------------------------------------------
+    be.divide_by_vanishing_poly_dev(h_ext, k, ek)
+    be.extended_to_coeff_dev(h_ext, k, ek)
+    n_pieces = dom.quotient_poly_degree
+    pieces = [h_ext.ptr + i * n * 32 for i in range(n_pieces)]
+    for pt in commit_all(params.g.handle, pieces):
+        transcript.write_point(pt)
+
+    # ---- 8. x; evaluations ---------------------------------------------------------------------------------------------------------------
+    x = transcript.squeeze_challenge()
+    xn = pow(x, n, R_MOD)
+    rot = lambda r: rotate_omega(x, r, k)
+    # h(X) as ONE polynomial of n coefficients: sum_i xn^i piece_i(X) (vanishing::Constructed::evaluate)
+    h_poly = dev(n * 32)
+    be.fr_lincomb_dev(pieces, fr_mont_array([pow(xn, i, R_MOD) for i in range(n_pieces)]), n, h_poly)
+    x_last = rot(-(bf + 1))
+    ev_polys, ev_points = [], []
+
+    def ask(poly, point):
+        ev_polys.append(poly)
+        ev_points.append(point)
+    for c, r in cs.advice_queries():
+        ask(adv_polys[c], rot(r))
+    for c, r in cs.fixed_queries():
+        ask(pk.fixed_polys[c], rot(r))
+    ask(random_poly, x)
+    for s in pk.sigma_polys:                                         # permutation "common" evaluations
+        ask(s, x)
+    for i, z in enumerate(zs):
+        ask(z, x)
+        ask(z, rot(1))
+        if i + 1 < len(zs):
+            ask(z, x_last)
+    for z, (a, s) in zip(lzs, permuted):
+        ask(z, x)
+        ask(z, rot(1))
+        ask(a, x)
+        ask(a, rot(-1))
+        ask(s, x)
+    ask(h_poly, x)                                                  # not written to the proof: the verifier derives it
+    evals_m = be.eval_polynomial_batch_dev(ev_polys, n, fr_mont_array(ev_points))
+    evals = [fr_int(e) for e in evals_m]
+    for e in evals[:-1]:
+        transcript.write_scalar(e)
+
+    # ---- 9. multi-open ------------------------------------------------------------------------------------------------------------------
+    it = iter(zip(ev_polys, ev_points, evals))
+    take = lambda: ProverQuery(*next(it))
+    q_adv = [take() for _ in cs.advice_queries()]
+    q_fix = [take() for _ in cs.fixed_queries()]
+    q_rand = take()
+    q_sigma = [take() for _ in pk.sigma_polys]
+    q_perm_a, q_perm_last = [], []
+    for i in range(len(zs)):
+        q_perm_a += [take(), take()]
+        if i + 1 < len(zs):
+            q_perm_last.append(take())
+    q_lk = []
+    for _ in lzs:
+        pz, pzn, pa, pai, ps = take(), take(), take(), take(), take()
+        q_lk += [pz, pa, ps, pai, pzn]                              # lookup::Evaluated::open order
+    q_h = take()
+    queries = q_adv + q_perm_a + list(reversed(q_perm_last)) + q_lk + q_fix + q_sigma + [q_h, q_rand]
+    ProverSHPLONK(params).create_proof(transcript, queries)
+    info = {"commitments": nA + 2 * L + nZ + L + 1 + n_pieces + 2, "evals": len(evals) - 1, "h_eval": evals[-1]}
+    for d in owned:
+        d.free()
+    return info

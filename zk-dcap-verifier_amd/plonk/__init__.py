@@ -5,8 +5,8 @@ circuits/src/sgx_dcap_verifier.rs:803,807,814-822), as a host-side mirror over t
     keygen(params, cs, fixed_columns, assembly) -> ProvingKey                            keygen_vk + keygen_pk
     create_proof(params, pk, advice_columns, instances, rng, transcript)                 plonk::create_proof + ProverSHPLONK
 
-verify_proof is not part of the product (verifier side, out of scope); the acceptance oracle used by
-the tests is oracle/verifier.py.
+verify_proof is not part of the product (verifier side, out of scope); the tests carry their own
+pure-Python verifier as the acceptance check, outside this package.
 """
 from .circuit import ADVICE, FIXED, INSTANCE, Assembly, ConstraintSystem, LookupArgument  # noqa: F401
 from .expression import Advice, Constant, Expression, Fixed, Instance  # noqa: F401

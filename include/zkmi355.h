@@ -63,6 +63,7 @@ int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** dptr);
 int zk_dev_free(zk_ctx* ctx, void* dptr);
 int zk_dev_upload(zk_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int zk_dev_download(zk_ctx* ctx, void* host, const void* dptr, size_t bytes);
+int zk_dev_copy(zk_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);   /* device -> device */
 int zk_dev_sync(zk_ctx* ctx);
 
 /* ---- MSM: replaces arithmetic::best_multiexp / ParamsKZG::{commit, commit_lagrange} -------- *

@@ -135,3 +135,28 @@ def test_create_proof_round_trip_gpu(gpu, orc, k):
 @pytest.mark.parametrize("what", ["gate", "copy", "lookup", "instance"])
 def test_create_proof_negative_controls_gpu(gpu, orc, what):
     _rejects(gpu, 9, what)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [8, 12])
+def test_sgx_shaped_circuit_proof_verifies_gpu(gpu, orc, k):
+    """The circuit shape bench.py proves at k = 19 (25 advice, 18 fixed, 11 lookups of 4-5 expressions, 16 equality columns,
+    24 gates, degree 5; tools/sgx_shaped_circuit.py) at a size the Python verifier handles in a second."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sgx_shaped_circuit as sc
+    import verifier
+    cs, fixed, asm, advice = sc.build(z, gpu, k)
+    params = z.kzg.ParamsKZG.setup(k, TAU, backend=gpu)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    tr = Blake2bWrite()
+    info = plonk.create_proof(params, pk, advice, [], np.random.default_rng(3), tr)
+    proof = tr.finalize()
+    assert info["commitments"] == 71 and len(proof) == 32 * (71 + info["evals"])
+    assert verifier.verify_proof(pk.vk, TAU, [], proof) is True
+    bad = bytearray(proof)
+    bad[32 * 69 + 5] ^= 4
+    assert verifier.verify_proof(pk.vk, TAU, [], bytes(bad)) is False
+    pk.release()
+    params.release()

@@ -19,6 +19,10 @@ def _case(orc, pyref, k, seed, kind):
     elif kind == "wide":                     # full-width field elements: every radix pass matters
         tab_vals = [rnd.randrange(R) for _ in range(u)]
         inp_vals = [rnd.choice(tab_vals[: max(2, u // 2)]) for _ in range(u)]
+    elif kind == "window_ties":              # full-width keys that agree on the top 64 bits in use and differ far below: the 64-bit window
+        big = (1 << 252) + (0x1234567 << 200)  # sort cannot order them, the order check must send the call down the every-digit path
+        tab_vals = [big + rnd.randrange(1 << 40) for _ in range(u)]
+        inp_vals = [rnd.choice(tab_vals[: max(2, u // 2)]) for _ in range(u)]
     elif kind == "identical":                # all inputs equal
         tab_vals = [7] + [rnd.randrange(R) for _ in range(u - 1)]
         inp_vals = [7] * u
@@ -71,7 +75,7 @@ def _check(be, orc, pyref, k, kind, seed):
         d.free()
 
 
-@pytest.mark.parametrize("kind", ["small", "wide"])
+@pytest.mark.parametrize("kind", ["small", "wide", "window_ties"])
 def test_emulated_lookup_permute(emu, orc, pyref, kind):
     emu.tune(vec_block=64)
     try:
@@ -91,6 +95,16 @@ def test_lookup_permute_rejects_value_outside_table(emu, orc, pyref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,kind", [(7, "small"), (12, "wide"), (16, "small"), (14, "identical"), (15, "perm")])
+@pytest.mark.parametrize("k,kind", [(7, "small"), (12, "wide"), (16, "small"), (14, "identical"), (15, "perm"), (13, "window_ties"), (18, "wide"), (19, "small")])
 def test_gpu_lookup_permute(gpu, orc, pyref, k, kind):
     _check(gpu, orc, pyref, k, kind, seed=k)
+
+
+@pytest.mark.gpu
+def test_gpu_lookup_permute_generic_sort_path(gpu, orc, pyref):
+    """the every-digit sort (taken when rows tie on the 64-bit window) forced on ordinary full-width data: same answer"""
+    gpu.tune(lookup_force_generic_sort=1)
+    try:
+        _check(gpu, orc, pyref, 12, "wide", seed=5)
+    finally:
+        gpu.tune(lookup_force_generic_sort=0)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""GPU-box probe: keygen + create_proof of the sgx-shaped synthetic circuit (tools/sgx_shaped_circuit.py) at a given k,
+verified by the tests' pure-Python verifier; prints per-phase wall times."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
+    sys.path.insert(0, p)
+import zk_dcap_verifier_amd as z
+import sgx_shaped_circuit as sc
+from zk_dcap_verifier_amd.transcript import Blake2bWrite
+
+TAU = 0x1C59A59B6CFF4308740943526ADE1D8C09F71B337A67269CC89586BCDD6DFCBA
+
+
+def main():
+    k = int(sys.argv[1]) if len(sys.argv) > 1 else 19
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    be = z.Backend(0)
+    out = {"k": k}
+    t = time.time(); cs, fixed, asm, advice = sc.build(z, be, k); out["build_witness_s"] = round(time.time() - t, 3)
+    t = time.time(); params = z.kzg.ParamsKZG.setup(k, TAU, backend=be); out["srs_setup_s"] = round(time.time() - t, 3)
+    t = time.time(); pk = z.plonk.keygen(params, cs, fixed, asm); out["keygen_s"] = round(time.time() - t, 3)
+    out["program"] = be.quotient_program_info(pk.evaluator.handle)
+    n = 1 << k
+    master = [be.to_device(a) for a in advice]
+    work = [be.alloc(n * 32) for _ in advice]
+    times, proof = [], None
+    for r in range(reps + 1):
+        for w, m in zip(work, master):
+            w.copy_from(m)
+        be.sync()
+        t = time.time()
+        tr = Blake2bWrite()
+        tm = {}
+        info = z.plonk.create_proof(params, pk, work, [], np.random.default_rng(r), tr, timings=tm)
+        proof = tr.finalize()
+        times.append(time.time() - t)
+    out["create_proof_ms"] = [round(x * 1e3, 2) for x in times]
+    out["phase_ms_last"] = {k_: round(v, 2) for k_, v in tm.items()}
+    out["proof_bytes"] = len(proof)
+    out["info"] = {k_: v for k_, v in info.items() if k_ != "h_eval"}
+    import verifier
+    t = time.time(); out["verified"] = verifier.verify_proof(pk.vk, TAU, [], proof); out["verify_s"] = round(time.time() - t, 2)
+    print(json.dumps(out))
+
+if __name__ == "__main__":
+    main()

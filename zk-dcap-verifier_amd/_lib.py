@@ -81,6 +81,14 @@ class DeviceBuffer:
         b._ck(b.lib.zk_dev_download(b.ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + offset), C.c_size_t(out.nbytes)))
         return out
 
+    def copy_from(self, src, nbytes: int | None = None):
+        """device -> device copy of the first nbytes of `src` into this buffer."""
+        b = self.backend
+        nb = self.nbytes if nbytes is None else int(nbytes)
+        assert nb <= self.nbytes
+        b._ck(b.lib.zk_dev_copy(b.ctx, C.c_void_p(self.ptr), C.c_void_p(_dptr(src)), C.c_size_t(nb)))
+        return self
+
     def free(self):
         if self.ptr:
             self.backend.lib.zk_dev_free(self.backend.ctx, C.c_void_p(self.ptr))

@@ -99,7 +99,7 @@ static int* tune_slot(zk_ctx* ctx, const char* key) {
         {"msm_target_threads", &t.msm_target_threads}, {"msm_min_chunk", &t.msm_min_chunk}, {"msm_max_chunk", &t.msm_max_chunk},
         {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block},
         {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log},
-        {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}};
+        {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}, {"lookup_force_generic_sort", &t.lookup_force_generic_sort}};
     for (auto& e : tab) if (!strcmp(e.k, key)) return e.v;
     return nullptr;
 }
@@ -137,6 +137,10 @@ int zk_dev_upload(zk_ctx* ctx, void* dptr, const void* host, size_t bytes) {
 int zk_dev_download(zk_ctx* ctx, void* host, const void* dptr, size_t bytes) {
     ENTER; if ((!dptr || !host) && bytes) return ctx->fail(ZK_ERR_ARG, "zk_dev_download: null");
     ZK_HIP(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream)); ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
+}
+int zk_dev_copy(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ENTER; if ((!dst || !src) && bytes) return ctx->fail(ZK_ERR_ARG, "zk_dev_copy: null");
+    ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream)); ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
 }
 int zk_dev_sync(zk_ctx* ctx) { ENTER; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
 

@@ -134,6 +134,21 @@ class Assembly:
         self.map_c[lc, lr], self.map_r[lc, lr] = self.map_c[rc, rr], self.map_r[rc, rr]
         self.map_c[rc, rr], self.map_r[rc, rr] = a
 
+    def copy_rows(self, left: Tuple[int, int], right: Tuple[int, int], rows) -> None:
+        """Vectorised `copy((left, r), (right, r)) for r in rows` for cells that are still unconstrained (singleton cycles) —
+        the bulk case of a region that copies a whole column range; falls back to `copy` row by row otherwise."""
+        import numpy as np
+        lc, rc = self.columns.index(left), self.columns.index(right)
+        rows = np.asarray(rows, dtype=np.int64)
+        if lc == rc or (self.sizes[lc, rows] != 1).any() or (self.sizes[rc, rows] != 1).any() or np.unique(rows).size != rows.size:
+            for r in rows.tolist():
+                self.copy((left[0], left[1], r), (right[0], right[1], r))
+            return
+        self.map_c[lc, rows], self.map_r[lc, rows] = rc, rows
+        self.map_c[rc, rows], self.map_r[rc, rows] = lc, rows
+        self.aux_c[rc, rows], self.aux_r[rc, rows] = lc, rows
+        self.sizes[lc, rows] = 2
+
     def sigma_columns(self, k: int) -> List[List[int]]:
         """build_pk's permutation polynomials in Lagrange form as canonical ints (small k / tests):
         sigma_j[i] = DELTA^(j') * omega^(i') for (j', i') = mapping[j][i].  keygen_pk uses the array form below."""

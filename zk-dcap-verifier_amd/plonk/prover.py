@@ -36,7 +36,8 @@ def rotate_omega(x: int, rot: int, k: int) -> int:
     return x * pow(w, rot % (1 << k), R_MOD) % R_MOD
 
 
-def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances: Sequence[Sequence[int]], rng: np.random.Generator, transcript) -> dict:
+def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances: Sequence[Sequence[int]], rng: np.random.Generator, transcript,
+                 timings: Optional[dict] = None) -> dict:
     """advice: cs.num_advice_columns columns of n rows — (n, 4) uint64 Montgomery host arrays or device buffers; rows past
     `usable_rows` are overwritten with blinding (device buffers are modified in place).  instances: canonical ints per instance
     column.  Writes the proof into `transcript`; returns phase timings-free bookkeeping (commitment count etc.) for tests."""
@@ -48,6 +49,14 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     L = len(cs.lookups)
     assert len(advice) == cs.num_advice_columns and len(instances) == cs.num_instance_columns
     owned = []                                                   # device buffers this proof allocated
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            now = _time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (now - _t[0]) * 1e3
+            _t[0] = now
 
     def dev(nbytes):
         d = be.alloc(nbytes)
@@ -71,6 +80,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
         d.upload(a)
         inst_values.append(d)
 
+    lap("1_instances")
     # ---- 2. advice: blind the unusable rows, commit ----------------------------------------------------------------------
     adv_values = []
     for col in advice:
@@ -85,6 +95,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     for pt in commit_all(params.g_lagrange.handle, adv_values):
         transcript.write_point(pt)
 
+    lap("2_advice_commit")
     # ---- 3. theta; lookups: compress, permute, commit --------------------------------------------------------------------
     theta = transcript.squeeze_challenge()
     one = fr_mont(1)
@@ -108,6 +119,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     for pt in commit_all(params.g_lagrange.handle, flat):           # per lookup: permuted input, permuted table
         transcript.write_point(pt)
 
+    lap("3_lookup_permuted")
     # ---- 4. beta, gamma; permutation and lookup grand products ---------------------------------------------------------------
     beta = transcript.squeeze_challenge()
     gamma = transcript.squeeze_challenge()
@@ -130,11 +142,13 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     for pt in commit_all(params.g_lagrange.handle, lzs):
         transcript.write_point(pt)
 
+    lap("4_grand_products")
     # ---- 5. vanishing argument: random polynomial -----------------------------------------------------------------------------
     random_poly = dev(n * 32)
     random_poly.upload(rand_fr_array(rng, n))
     transcript.write_point(g1_affine_ints(be.msm(params.g.handle, random_poly, n)))
 
+    lap("5_random_poly")
     # ---- 6. y; everything to coefficient form; h(X) ------------------------------------------------------------------------------
     y = transcript.squeeze_challenge()
     lag = adv_values + inst_values + zs + lzs + flat                 # the witness-dependent columns, Lagrange basis
@@ -153,6 +167,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     for d in ext:                                                   # the cosets are dead once the numerator exists
         d.free()
         owned.remove(d)
+    lap("6_ntt_evaluate_h")
     # ---- 7. vanishing::construct: divide, back to coefficients, split into d-1 pieces, commit ------------------------------------------
     be.divide_by_vanishing_poly_dev(h_ext, k, ek)
     be.extended_to_coeff_dev(h_ext, k, ek)
@@ -161,6 +176,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     for pt in commit_all(params.g.handle, pieces):
         transcript.write_point(pt)
 
+    lap("7_h_construct_commit")
     # ---- 8. x; evaluations ---------------------------------------------------------------------------------------------------------------
     x = transcript.squeeze_challenge()
     xn = pow(x, n, R_MOD)
@@ -198,6 +214,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     for e in evals[:-1]:
         transcript.write_scalar(e)
 
+    lap("8_evaluations")
     # ---- 9. multi-open ------------------------------------------------------------------------------------------------------------------
     it = iter(zip(ev_polys, ev_points, evals))
     take = lambda: ProverQuery(*next(it))
@@ -217,6 +234,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     q_h = take()
     queries = q_adv + q_perm_a + list(reversed(q_perm_last)) + q_lk + q_fix + q_sigma + [q_h, q_rand]
     ProverSHPLONK(params).create_proof(transcript, queries)
+    lap("9_shplonk")
     info = {"commitments": nA + 2 * L + nZ + L + 1 + n_pieces + 2, "evals": len(evals) - 1, "h_eval": evals[-1]}
     for d in owned:
         d.free()

@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — proofs/hour of the sgx_dcap_verifier k=19 prover hot path on MI355X (BASELINE.json
-configs[1]) and, as extras, the BN254 MSM Mscalar/s at 2^24 (configs[2]) and batched NTT (configs[3]).
+"""bench.py — proofs/hour of the sgx_dcap_verifier k=19 prover on MI355X (BASELINE.json configs[1]) and, as extras, the
+BN254 MSM Mscalar/s at 2^24 (configs[2]) and batched NTT (configs[3]).
 
-A "step" is one pass of the GPU hot path of ONE proof over synthetic inputs already resident in HBM:
-the MSM / NTT / quotient call list of halo2 `create_proof` (SURVEY.md §3.1, §8d cfg 2) for the
-circuit shape A advice columns, L lookups, P permutation products, degree d:
-    (A + 3L + P + 1 + (d-1) + 2) MSMs of 2^k,  (A + 3L + P) iNTT(2^k),  (A + 3L + P) coeff->extended NTT(2^ek),
-    one evaluate_h pass over 2^ek rows, divide_by_vanishing, one extended->coeff iNTT(2^ek).
-Host work of create_proof (witness synthesis, lookup sorting, grand products, transcript) is NOT
-part of the step: the reference's Rust prover cannot be built here (no cargo, un-vendored crates),
-so the metric is the hot-path throughput and says so in `metric`.
+Default (`--mode prove`): a "step" is one batch of `--inflight` REAL proofs: `plonk.create_proof` (the mirror of halo2's
+create_proof, zk-dcap-verifier_amd/plonk/prover.py) over a satisfiable synthetic circuit with the census of the sgx circuit at
+k = 19 (tools/sgx_shaped_circuit.py: 25 advice, 18 fixed, 11 lookups, 16 equality columns, 24 gates, degree 5 => 71 commitments,
+64 iNTT(2^19), 64 NTT(2^21) + 1 iNTT(2^21), evaluate_h over 2^21 rows, 175 evaluations, SHPLONK).  The witness columns are
+resident in HBM when the timed region starts (witness synthesis is host work the north star leaves in Rust); everything from the
+advice commitments to the last SHPLONK commitment — transcript hashing on the host included — is inside it.  Outside the timed
+region one proof per context is handed to the pure-Python verifier together with the CPU baseline (the reference's own
+acceptance check, sgx_dcap_verifier.rs:826-844); a proof that does not verify fails the run.
 
-N > 1: one process per GPU, every rank proves its own stream of proofs (weak scaling, no data-path
-collective); the MSM-sharded path (base table split over ranks, 128-byte partial points all-gathered
-over RCCL) is timed separately and reported under "extra".
+`--mode opmix`: the earlier hot-path op-mix (MSM / NTT / quotient call list of create_proof over synthetic columns, half
+uniform, half witness-like sparse; no grand products / lookup permutation / evaluations / SHPLONK) — kept for continuity with
+profiles/r01 run1-run27.
+
+N > 1: one process per GPU, every rank proves its own stream of proofs (weak scaling, no data-path collective); the MSM-sharded
+path (base table split over ranks, 128-byte partial points all-gathered over RCCL) is timed separately and reported under "extra".
 """
 import argparse
 import json
@@ -171,9 +174,47 @@ class ProofWorkload:
         be.msm(self.g, self.work[1], n)
 
 
-def cpu_baseline(cfg, threads):
-    """Oracle ("port": C restatement of halo2's CPU algorithms, oracle/bn254_oracle.c) timed on a bounded
-    sample of the same op-mix and extrapolated to one proof.  Checker code, never the thing shipped."""
+
+TAU = 0x1C59A59B6CFF4308740943526ADE1D8C09F71B337A67269CC89586BCDD6DFCBA   # SRS trapdoor of the synthetic setup
+
+
+class ProverWorkload:
+    """keygen once, then one create_proof per step on a copy of the resident witness."""
+
+    def __init__(self, z, be, k, circuit):
+        self.z, self.be, self.k, self.n = z, be, k, 1 << k
+        cs, fixed, asm, advice = circuit
+        self.params = z.kzg.ParamsKZG.setup(k, TAU, backend=be)
+        self.pk = z.plonk.keygen(self.params, cs, fixed, asm)
+        self.master = [be.to_device(a) for a in advice]
+        self.work = [be.alloc(self.n * 32) for _ in advice]
+        self.seed = 0
+        self.proof, self.info = None, None
+        dom = self.pk.domain
+        self.ek, self.en, self.d = dom.extended_k, dom.extended_n, cs.degree()
+        L, A = len(cs.lookups), cs.num_advice_columns
+        chunk = cs.permutation_chunk_len()
+        self.P = (len(cs.permutation_columns) + chunk - 1) // chunk
+        self.A, self.F, self.L, self.n_perm = A, cs.num_fixed_columns, L, len(cs.permutation_columns)
+        self.n_msm = A + 3 * L + self.P + 1 + (self.d - 1) + 2
+        self.n_intt = A + 3 * L + self.P
+        self.n_ext = self.n_intt
+
+    def step(self):
+        from zk_dcap_verifier_amd.transcript import Blake2bWrite
+        for w, m in zip(self.work, self.master):
+            w.copy_from(m)                                           # the witness of this proof (create_proof works in place)
+        tr = Blake2bWrite()
+        self.seed += 1
+        self.info = self.z.plonk.create_proof(self.params, self.pk, self.work, [], np.random.default_rng(self.seed), tr)
+        self.proof = tr.finalize()
+
+
+def cpu_baseline(cfg, threads, program_for=None, verify=None):
+    """The CPU leg: (1) the oracle ("port": C restatement of halo2's CPU algorithms, oracle/bn254_oracle.c) timed on a bounded
+    sample of the proof's MSM / NTT / evaluate_h calls and extrapolated to one proof; (2) with `verify` = (vk, tau, instances,
+    proof): the reference's acceptance check — verify_proof (pure-Python, oracle/verifier.py) on a proof the GPU just produced.
+    Checker code, never the thing shipped or measured."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     k, ek = cfg["k"], cfg["ek"]
@@ -187,7 +228,7 @@ def cpu_baseline(cfg, threads):
     # quotient on 2^14 rows of the same program shape, scaled by rows
     import zk_dcap_verifier_amd as z
     ks = 12
-    prog = sgx_shaped_program(z, ks, ks + (ek - k), cfg["A"], cfg["F"], cfg["L"], cfg["n_perm"], cfg["d"])
+    prog = program_for(ks, ks + (ek - k)) if program_for else sgx_shaped_program(z, ks, ks + (ek - k), cfg["A"], cfg["F"], cfg["L"], cfg["n_perm"], cfg["d"])
     size = 1 << (ks + ek - k)
     col = rand_fr(size, 3)
     P = (cfg["n_perm"] + cfg["d"] - 3) // (cfg["d"] - 2)
@@ -196,10 +237,21 @@ def cpu_baseline(cfg, threads):
                    [col] * cfg["L"], [], col[0], col[1], col[2], col[3], size, threads=threads)
     t_q = (time.time() - t) * ((1 << ek) / size)
     total = cfg["n_msm"] * t_msm + cfg["n_intt"] * t_intt + (cfg["n_ext"] + 1) * t_ext + t_q
-    return {"value": round(3600.0 / total, 3), "unit": "proofs/hour", "cores": threads, "kind": "port",
-            "sample": f"1 best_multiexp(2^{k}) {t_msm:.2f}s x{cfg['n_msm']}, 1 lagrange_to_coeff {t_intt:.3f}s x{cfg['n_intt']}, "
-                      f"1 coeff_to_extended(2^{ek}) {t_ext:.3f}s x{cfg['n_ext'] + 1}, evaluate_h on 2^{ks + ek - k} rows scaled to 2^{ek} = {t_q:.2f}s; "
-                      "C restatement of halo2 CPU algorithms (pthreads), not the Rust binary"}
+    out = {"value": round(3600.0 / total, 3), "unit": "proofs/hour", "cores": threads, "kind": "port",
+           "sample": f"1 best_multiexp(2^{k}) {t_msm:.2f}s x{cfg['n_msm']}, 1 lagrange_to_coeff {t_intt:.3f}s x{cfg['n_intt']}, "
+                     f"1 coeff_to_extended(2^{ek}) {t_ext:.3f}s x{cfg['n_ext'] + 1}, evaluate_h on 2^{ks + ek - k} rows scaled to 2^{ek} = {t_q:.2f}s "
+                     "(grand products, lookup permutation, evaluations and SHPLONK of the CPU prover are NOT counted: the baseline is optimistic); "
+                     "C restatement of halo2 CPU algorithms (pthreads), not the Rust binary"}
+    if verify is not None:
+        import verifier
+        vk, tau, instances, proofs = verify
+        t = time.time()
+        oks = [bool(verifier.verify_proof(vk, tau, instances, pr)) for pr in proofs]
+        out["verify_proof"] = {"accepted": all(oks), "proofs": len(oks), "seconds": round(time.time() - t, 2),
+                               "what": "pure-Python plonk::verify_proof + VerifierSHPLONK on the GPU prover's proof bytes (oracle/verifier.py)"}
+        if not all(oks):
+            raise RuntimeError("bench: a proof produced by the GPU prover was REJECTED by verify_proof")
+    return out
 
 
 def _ints(a):
@@ -255,6 +307,7 @@ def main(argv=None):
     ap.add_argument("--lookups", type=int, default=11)
     ap.add_argument("--perm-columns", type=int, default=16)
     ap.add_argument("--degree", type=int, default=5)
+    ap.add_argument("--mode", choices=("prove", "opmix"), default="prove", help="prove: real create_proof over the sgx-shaped circuit (default); opmix: the hot-path call list over synthetic columns")
     ap.add_argument("--inflight", type=int, default=2, help="proofs processed concurrently per step on one GPU (one context + HIP stream each)")
     ap.add_argument("--no-extras", action="store_true", help="skip the MSM 2^24 / NTT 2^22 microbenchmarks and the CPU baseline")
     args = ap.parse_args(argv)
@@ -285,7 +338,13 @@ def main(argv=None):
     import threading
     inflight = max(1, args.inflight)
     bes = [be] + [z.Backend(local) for _ in range(inflight - 1)]
-    wls = [ProofWorkload(z, b, args.k, args.advice, args.fixed, args.lookups, args.perm_columns, args.degree) for b in bes]
+    if args.mode == "prove":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import sgx_shaped_circuit as sgx
+        circuit = sgx.build(z, be, args.k)                      # one satisfying witness, shared by the contexts
+        wls = [ProverWorkload(z, b, args.k, circuit) for b in bes]
+    else:
+        wls = [ProofWorkload(z, b, args.k, args.advice, args.fixed, args.lookups, args.perm_columns, args.degree) for b in bes]
     wl = wls[0]
 
     def step_all():
@@ -368,21 +427,28 @@ def main(argv=None):
                 "int_alu": {"achieved_Gmadd_per_s": round(msm_pairs / acc_s / 1e9, 3), "peak_Gmadd_per_s": XYZZ_MADD_PEAK / 1e9,
                             "frac": round(msm_pairs / acc_s / XYZZ_MADD_PEAK, 4)}}
 
-    cfg = {"k": args.k, "ek": wl.ek, "A": args.advice, "F": args.fixed, "L": args.lookups, "n_perm": args.perm_columns, "d": args.degree,
+    cfg = {"k": args.k, "ek": wl.ek, "A": wl.A, "F": wl.F, "L": wl.L, "n_perm": wl.n_perm, "d": wl.d,
            "n_msm": wl.n_msm, "n_intt": wl.n_intt, "n_ext": wl.n_ext}
     cpu = None
     if rank == 0 and not args.no_extras:
         if world == 1:
-            try:
-                cpu = cpu_baseline(cfg, os.cpu_count() or 1)
-            except Exception as e:  # the baseline is a report, never a dependency of the measurement
-                cpu = {"error": str(e)}
+            if args.mode == "prove":
+                # the CPU leg also runs the reference's acceptance check on one proof per context; a rejected proof is a failed run
+                cpu = cpu_baseline(cfg, os.cpu_count() or 1, program_for=lambda kk, ee: z.plonk.compile_program(wl.pk.vk.cs, kk, ee),
+                                   verify=(wl.pk.vk, TAU, [], [w_.proof for w_ in wls]))
+            else:
+                try:
+                    cpu = cpu_baseline(cfg, os.cpu_count() or 1)
+                except Exception as e:  # the baseline is a report, never a dependency of the measurement
+                    cpu = {"error": str(e)}
             try:
                 extra["msm_2^20"] = msm_microbench(be, 20, 20241008, verify=True)
                 extra["msm_2^24"] = msm_microbench(be, 24, 20241010, reps=2)
             except Exception as e:
                 extra["msm_microbench_error"] = str(e)
             try:
+                if globals().get("PLUMBING_SKIP_NTT22"):
+                    raise RuntimeError("skipped (plumbing test)")
                 n22 = 1 << 22
                 cols = 25
                 buf = be.to_device(rand_fr(n22, 20241011))
@@ -454,14 +520,24 @@ def main(argv=None):
                 extra[f"msm_sharded_2^{logn}_error"] = str(e)
 
     if rank == 0:
-        line = {"metric": "proofs/hour sgx_dcap_verifier k=19 (GPU hot path: MSM+NTT+quotient op-mix of create_proof; host witness/transcript excluded)",
+        if args.mode == "prove":
+            metric = "proofs/hour sgx_dcap_verifier k=19 (create_proof on the GPU: commitments, lookups, grand products, NTTs, evaluate_h, evaluations, SHPLONK, host transcript; witness synthesis excluded)"
+            workload = (f"create_proof (halo2 mirror, zk-dcap-verifier_amd/plonk) of a satisfiable circuit with the sgx_dcap_verifier QE3-report census "
+                        f"(tools/sgx_shaped_circuit.py): k={args.k}, extended_k={wl.ek}, A={wl.A} advice (14 full-width + 11 16-bit), F={wl.F} fixed, L={wl.L} lookups of 4-5 expressions, "
+                        f"{wl.n_perm} equality columns (P={wl.P}), 24 gates, degree {wl.d}; per proof {wl.n_msm} MSM(2^{args.k}) + {wl.n_intt} iNTT + {wl.n_ext + 1} NTT(2^{wl.ek}) + evaluate_h "
+                        f"+ {wl.info['evals'] + 1 if wl.info else '?'} evaluations + SHPLONK -> {len(wl.proof) if wl.proof else '?'}-byte proof; witness resident in HBM; "
+                        f"one step = a batch of {inflight} proofs in flight on the GPU (one context + HIP stream + host thread each)")
+        else:
+            metric = "proofs/hour sgx_dcap_verifier k=19 (GPU hot path: MSM+NTT+quotient op-mix of create_proof; host witness/transcript excluded)"
+            workload = (f"sgx_dcap_verifier QE3-report circuit shape, k={args.k}, extended_k={wl.ek}, A={args.advice} advice, F={args.fixed} fixed, "
+                        f"L={args.lookups} lookups, {args.perm_columns} permutation columns (P={wl.P}), degree {args.degree}; "
+                        f"{wl.n_msm} MSM(2^{args.k}) + {wl.n_intt} iNTT + {wl.n_ext + 1} NTT(2^{wl.ek}) + evaluate_h per proof; columns half uniform, half witness-like sparse; "
+                        f"one step = a batch of {inflight} proofs in flight on the GPU (one HIP stream each)")
+        line = {"metric": metric,
                 "value": round(proofs_per_hour, 2), "unit": "proofs/hour", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (256-bit Montgomery integers)",
                 "data": "synthetic",
-                "config": {"workload": f"sgx_dcap_verifier QE3-report circuit shape, k={args.k}, extended_k={wl.ek}, A={args.advice} advice, F={args.fixed} fixed, "
-                                       f"L={args.lookups} lookups, {args.perm_columns} permutation columns (P={wl.P}), degree {args.degree}; "
-                                       f"{wl.n_msm} MSM(2^{args.k}) + {wl.n_intt} iNTT + {wl.n_ext + 1} NTT(2^{wl.ek}) + evaluate_h per proof; columns half uniform, half witness-like sparse; "
-                                       f"one step = a batch of {inflight} proofs in flight on the GPU (one HIP stream each)",
+                "config": {"workload": workload, "mode": args.mode,
                            "parallelism": f"{world} x independent proofs (one process per GPU)"},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line), flush=True)

@@ -23,7 +23,7 @@ def test_bench_emits_contract_json(built, capsys, monkeypatch):
         self.tune(msm_sort_threads=32, msm_sort_wgs=2, msm_block=32, ntt_threads=32, ntt_tile_log=6, ntt_max_radix_log=4,
                   msm_target_threads=64, msm_min_chunk=2, vec_block=32, quot_threads=32)
     monkeypatch.setattr(z.Backend, "__init__", small_init)
-    bench.main(["--steps", "1", "--warmup", "0", "--k", "5", "--advice", "3", "--fixed", "2", "--lookups", "1", "--perm-columns", "3",
+    bench.main(["--mode", "opmix", "--steps", "1", "--warmup", "0", "--k", "5", "--advice", "3", "--fixed", "2", "--lookups", "1", "--perm-columns", "3",
                 "--degree", "4", "--no-extras"])
     out = capsys.readouterr().out.strip().splitlines()[-1]
     line = json.loads(out)
@@ -33,6 +33,34 @@ def test_bench_emits_contract_json(built, capsys, monkeypatch):
     assert line["unit"] == "proofs/hour" and line["n_gpus"] == 1 and "workload" in line["config"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in line["roofline"]
+
+
+def test_bench_prove_mode_emits_verified_proof(built, capsys, monkeypatch):
+    """The default mode (real create_proof) end to end on the emulator, with the circuit generator shrunk to 2 + 2 advice
+    columns at k = 6: the JSON line carries the contract keys and the CPU leg's verify_proof accepted the proof."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import zk_dcap_verifier_amd as z
+    import bench
+    import sgx_shaped_circuit as sgx
+    monkeypatch.setattr(z._lib, "LIB_PATH", EMU_SO)
+    monkeypatch.setenv("ZK_BENCH_PLUMBING_TEST", "1")
+    for name, val in (("N_GATE_COLS", 2), ("N_LOOKUP_COLS", 2), ("N_FIXED", 7), ("N_GATES", 3)):
+        monkeypatch.setattr(sgx, name, val)
+    real_init = z.Backend.__init__
+
+    def small_init(self, device=0, lib_path=None):
+        real_init(self, device, lib_path)
+        self.tune(msm_sort_threads=32, msm_sort_wgs=2, msm_block=32, ntt_threads=32, ntt_tile_log=6, ntt_max_radix_log=4,
+                  msm_target_threads=64, msm_min_chunk=2, vec_block=32, quot_threads=32)
+    monkeypatch.setattr(z.Backend, "__init__", small_init)
+    monkeypatch.setattr(bench, "msm_microbench", lambda *a, **k: {"skipped": "plumbing test"})
+    monkeypatch.setattr(bench, "PLUMBING_SKIP_NTT22", True, raising=False)
+    bench.main(["--steps", "1", "--warmup", "0", "--k", "6", "--inflight", "1"])
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["config"]["mode"] == "prove" and line["unit"] == "proofs/hour"
+    assert line["cpu_baseline"]["verify_proof"]["accepted"] is True
+    assert line["roofline"]["kernel"] == "msm_accumulate_kernel"
 
 
 def _bench_rank(rank, world, port, out_dir):
@@ -53,7 +81,7 @@ def _bench_rank(rank, world, port, out_dir):
     z.Backend.__init__ = small_init
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "0", "--k", "4", "--advice", "2", "--fixed", "2", "--lookups", "1",
+        bench.main(["--mode", "opmix", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--k", "4", "--advice", "2", "--fixed", "2", "--lookups", "1",
                     "--perm-columns", "2", "--degree", "4"])
     open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(buf.getvalue())
 

@@ -327,6 +327,12 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
             }
             writer[g.calcs[i].target] = (int)i;
         }
+        // Store(column | constant | challenge) — what halo2's add_expression emits for every query — is an ALIAS here: its readers
+        // take the memory operand directly (one more 32-byte load per use) instead of parking the value in a slot from its first
+        // to its last use; with CSE'd selectors and rotations shared between gates those slots are what limits occupancy.
+        std::vector<char> is_alias(nc, 0);
+        for (size_t i = 0; i + 1 < nc; i++)
+            if (g.calcs[i].op == OP_STORE && dep[i][0] < 0 && g.calcs[i].s0.kind != VS_PREV) is_alias[i] = 1;
         std::vector<int> vreg(nc, -1);
         bool ok = true;
         auto leaf = [&](const VSrc& s) -> Builder::Opnd {
@@ -360,12 +366,13 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
             auto opnd_at = [&](size_t oi) -> Builder::Opnd {
                 const VSrc& sv = oi == 0 ? k.s0 : (oi == 1 && (k.op == OP_ADD || k.op == OP_SUB || k.op == OP_MUL || k.op == OP_HORNER)) ? k.s1
                                                 : k.parts[oi - 2];
-                return d[oi] >= 0 ? B.slot(vreg[d[oi]]) : leaf(sv);
+                if (d[oi] >= 0) return is_alias[d[oi]] ? leaf(g.calcs[d[oi]].s0) : B.slot(vreg[d[oi]]);
+                return leaf(sv);
             };
             if (k.op != OP_HORNER) {
                 if (f.next < d.size()) {               // make operand f.next available
                     const size_t oi = f.next++;
-                    if (d[oi] >= 0 && vreg[d[oi]] < 0) st.push_back(Frame{d[oi], 0});
+                    if (d[oi] >= 0 && vreg[d[oi]] < 0 && !is_alias[d[oi]]) st.push_back(Frame{d[oi], 0});
                     continue;
                 }
                 int v = -1;
@@ -384,7 +391,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
                 // operands: 0 = start, 1 = factor, 2.. = parts.  Steps happen as soon as part i is ready.
                 if (f.next < d.size()) {
                     const size_t oi = f.next;
-                    if (d[oi] >= 0 && vreg[d[oi]] < 0) { st.push_back(Frame{d[oi], 0}); continue; }
+                    if (d[oi] >= 0 && vreg[d[oi]] < 0 && !is_alias[d[oi]]) { st.push_back(Frame{d[oi], 0}); continue; }
                     f.next++;
                     if (oi >= 2) {
                         Builder::Opnd curv = horner_cur[ci] >= 0 ? B.slot(horner_cur[ci]) : opnd_at(0);

@@ -79,6 +79,6 @@ def rand_fr_array(rng: np.random.Generator, n: int) -> np.ndarray:
     """n field elements as raw limb patterns below 2^253 (< r), used directly as Montgomery forms.  This is the
     mirror's stand-in for `Fr::random(&mut rng)` draws (blinding rows / the vanishing argument's random polynomial):
     deterministic under the caller's seeded generator, which is what makes proof bytes reproducible."""
-    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
     a[:, 3] &= np.uint64((1 << 61) - 1)
     return a

@@ -49,6 +49,6 @@ def test_emulated_eval_phase(emu, orc, pyref, n, count):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,count", [(1, 1), (3, 2), (1 << 12, 5), (100003, 7), (1 << 19, 4)])
+@pytest.mark.parametrize("n,count", [(1, 1), (3, 2), (1 << 12, 5), (100003, 7), (1 << 19, 4), ((1 << 20) + 4099, 2)])   # the last one: kate_division carries over two rounds of workgroups
 def test_gpu_eval_phase(gpu, orc, pyref, n, count):
     _check(gpu, orc, pyref, n, count, seed=n)

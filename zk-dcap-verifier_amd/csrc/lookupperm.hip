@@ -22,13 +22,19 @@ constexpr uint32_t LP_T = 256;
 // canonical keys + identity permutation; ormask[0..8) collects the OR of all keys so that the sort only visits the
 // digits some key actually uses (witness values are mostly far below 254 bits)
 ZK_KERNEL void lp_canon_kernel(const void* x, uint32_t u, void* canon, uint32_t* idx, uint32_t* ormask) {
+    __shared__ uint32_t lor[8];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= u) return;
-    const u256 c = Fr::from_mont(load_u256(x, i));
-    store_u256(canon, i, c);
-    idx[i] = i;
+    if (threadIdx.x < 8) lor[threadIdx.x] = 0;
+    __syncthreads();
+    if (i < u) {
+        const u256 c = Fr::from_mont(load_u256(x, i));
+        store_u256(canon, i, c);
+        idx[i] = i;
 #pragma unroll
-    for (int w = 0; w < 8; w++) if (c.v[w] & ~ormask[w]) atomicOr(&ormask[w], c.v[w]);
+        for (int w = 0; w < 8; w++) if (c.v[w] & ~lor[w]) atomicOr(&lor[w], c.v[w]);   // workgroup-local first: the global words are hit once per workgroup
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && lor[threadIdx.x]) atomicOr(&ormask[threadIdx.x], lor[threadIdx.x]);
 }
 ZK_HD uint32_t lp_digit(const void* canon, uint32_t row, uint32_t d) {  // d-th 4-bit digit, d = 0 least significant
     const uint32_t w = reinterpret_cast<const uint32_t*>(canon)[(size_t)row * 8 + (d >> 3)];

@@ -131,17 +131,39 @@ ZK_KERNEL void kd_scan_kernel(const void* a, uint32_t n, u256 b, int mode, void*
         bp = Fr::mul(bp, b);
     }
 }
-// single workgroup: carries[2*blk] = (total, mult) pairs -> carries[blk] = carry-in of workgroup blk (serial over <= a few thousand entries per thread chunk)
+// single workgroup: carries[2*blk] = (total, mult) pairs -> out[blk] = carry-in of workgroup blk: the same (value, multiplier) scan as
+// inside kd_scan_kernel, one pair per thread per round of PE_T workgroups (a serial walk over a few hundred dependent products cost 0.2 ms)
 ZK_KERNEL void kd_carry_kernel(void* carries, uint32_t nblk, void* out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u256 c = Fr::zero();
-    for (uint32_t b = 0; b < nblk; b++) {
-        const u256 tot = load_u256(carries, 2 * (size_t)b), mul = load_u256(carries, 2 * (size_t)b + 1);
-        store_u256(out, b, c);
-        c = Fr::add(tot, Fr::mul(mul, c));
+    __shared__ uint4 vlo[PE_T], vhi[PE_T], mlo[PE_T], mhi[PE_T];
+    const uint32_t tid = threadIdx.x, T = blockDim.x;
+    u256 cin = Fr::zero();                                  // carry into the current round of T workgroups
+    for (uint32_t base = 0; base < nblk; base += T) {
+        const uint32_t b = base + tid;
+        u256 val = Fr::zero(), mul = Fr::one();
+        if (b < nblk) { val = load_u256(carries, 2 * (size_t)b); mul = load_u256(carries, 2 * (size_t)b + 1); }
+        kd_lds_put(vlo, vhi, tid, val); kd_lds_put(mlo, mhi, tid, mul);
+        __syncthreads();
+        for (uint32_t d = 1; d < T; d <<= 1) {
+            u256 pv = Fr::zero(), pm = Fr::one();
+            const bool act = tid >= d;
+            if (act) { pv = kd_lds_get(vlo, vhi, tid - d); pm = kd_lds_get(mlo, mhi, tid - d); }
+            __syncthreads();
+            if (act) {
+                val = Fr::add(val, Fr::mul(mul, pv));
+                mul = Fr::mul(mul, pm);
+                kd_lds_put(vlo, vhi, tid, val); kd_lds_put(mlo, mhi, tid, mul);
+            }
+            __syncthreads();
+        }
+        // exclusive: carry-in of workgroup b = inclusive(b - 1) applied to cin
+        u256 c = cin;
+        if (tid > 0) c = Fr::add(kd_lds_get(vlo, vhi, tid - 1), Fr::mul(kd_lds_get(mlo, mhi, tid - 1), cin));
+        if (b < nblk) store_u256(out, b, c);
+        const u256 last_v = kd_lds_get(vlo, vhi, T - 1), last_m = kd_lds_get(mlo, mhi, T - 1);
+        cin = Fr::add(last_v, Fr::mul(last_m, cin));
+        __syncthreads();
     }
 }
-
 
 // ---- linear combinations (SHPLONK / multiopen polynomial combos) -----------------------------------
 // out[i] = sum_j s_j * p_j[i]: the `poly * power_of_y` ... `reduce(|acc, poly| acc + &poly)` chains of
@@ -197,7 +219,7 @@ int kate_division(zk_ctx* ctx, const void* d_a, size_t n, const void* b_host, vo
     hipStream_t st = ctx->stream;
     ZK_LAUNCH(kd_scan_kernel, nblk, PE_T, 0, st, d_a, (uint32_t)n, b, 0, pairs, d_q);
     ZK_CHECK_LAUNCH();
-    ZK_LAUNCH(kd_carry_kernel, 1, 64, 0, st, pairs, nblk, cin);
+    ZK_LAUNCH(kd_carry_kernel, 1, PE_T, 0, st, pairs, nblk, cin);
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(kd_scan_kernel, nblk, PE_T, 0, st, d_a, (uint32_t)n, b, 1, cin, d_q);
     ZK_CHECK_LAUNCH();

@@ -333,6 +333,19 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         std::vector<char> is_alias(nc, 0);
         for (size_t i = 0; i + 1 < nc; i++)
             if (g.calcs[i].op == OP_STORE && dep[i][0] < 0 && g.calcs[i].s0.kind != VS_PREV) is_alias[i] = 1;
+        // Rematerialisation: halo2's add_calculation shares every repeated sub-expression, however far apart its uses are (on the CPU an
+        // intermediate is a memory cell).  Here a shared value occupies a slot from its first to its last use, and slots (LDS) set the
+        // occupancy of the kernel: a value that costs at most QUOT_REMAT_OPS operations over memory operands is recomputed at each use.
+        constexpr uint32_t QUOT_REMAT_OPS = 4;
+        std::vector<uint32_t> cost(nc, 0);
+        std::vector<char> cheap(nc, 0);
+        for (size_t i = 0; i < nc; i++) {
+            if (is_alias[i]) continue;
+            uint64_t c = g.calcs[i].op == OP_HORNER ? std::max<size_t>(g.calcs[i].parts.size(), 1) : 1;
+            for (int dd : dep[i]) if (dd >= 0) c += cost[dd];
+            cost[i] = (uint32_t)std::min<uint64_t>(c, 1u << 20);
+            cheap[i] = g.calcs[i].op != OP_HORNER && cost[i] <= QUOT_REMAT_OPS && i + 1 < nc;
+        }
         std::vector<int> vreg(nc, -1);
         bool ok = true;
         auto leaf = [&](const VSrc& s) -> Builder::Opnd {
@@ -375,6 +388,12 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
                     if (d[oi] >= 0 && vreg[d[oi]] < 0 && !is_alias[d[oi]]) st.push_back(Frame{d[oi], 0});
                     continue;
                 }
+                {   // an operand computed earlier may have been handed back (rematerialisation) while a later operand was being produced
+                    bool missing = false;
+                    for (size_t oi = 0; oi < d.size() && !missing; oi++)
+                        if (d[oi] >= 0 && !is_alias[d[oi]] && vreg[d[oi]] < 0) { f.next = oi; missing = true; }
+                    if (missing) continue;
+                }
                 int v = -1;
                 switch (k.op) {
                     case OP_ADD: v = B.tmp(M_ADD, {opnd_at(0), opnd_at(1)}); break;
@@ -386,6 +405,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
                     default: v = B.tmp(M_MOV, {opnd_at(0)}); break;
                 }
                 vreg[ci] = v;
+                for (int dd : d) if (dd >= 0 && cheap[dd]) vreg[dd] = -1;   // recompute at the next use instead of keeping it live
                 st.pop_back();
             } else {
                 // operands: 0 = start, 1 = factor, 2.. = parts.  Steps happen as soon as part i is ready.
@@ -396,6 +416,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
                     if (oi >= 2) {
                         Builder::Opnd curv = horner_cur[ci] >= 0 ? B.slot(horner_cur[ci]) : opnd_at(0);
                         horner_cur[ci] = B.tmp(M_MULADD, {curv, opnd_at(1), opnd_at(oi)});
+                        if (d[oi] >= 0 && cheap[d[oi]] && d[oi] != d[0] && d[oi] != d[1]) vreg[d[oi]] = -1;
                     }
                     continue;
                 }

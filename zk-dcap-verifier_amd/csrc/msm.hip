@@ -77,7 +77,7 @@ struct MsmPlan {
     void* sub[2];                          // level r lives in sub[r & 1]
     uint64_t sub_stride[2];                // entries per column
     void* cls[2];
-    uint32_t groups0;                      // entries per class after the first class kernel
+    uint32_t lo_bits;                      // bucket reduction: weight = hi * 2^lo_bits + lo
 };
 ZK_HD uint32_t* plan_small(const MsmPlan& p, uint32_t col) { return p.small + (size_t)col * p.small_stride; }
 ZK_HD const uint32_t* plan_suboff(const MsmPlan& p, uint32_t col, uint32_t level) { return plan_small(p, col) + p.o_suboff + (size_t)level * (p.B + 1); }
@@ -274,43 +274,79 @@ ZK_KERNEL void msm_merge_kernel(MsmPlan p, uint32_t r, uint32_t Mpow_prev) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// bucket reduction by weight bits.  Bucket b has weight w = b + 1 in [1, 2^(c-1)].
-//   class t < c-1 : { w < 2^(c-1) : bit t of w set }   (2^(c-2) members)
-//   class c-1     : { w = 2^(c-1) }                     (1 member)
-// result = sum_t 2^t * C_t with C_t the plain sum of class t.   blockIdx.y = col * c + t.
+// bucket reduction  sum_w w * B_w,  bucket b has weight w = b + 1 in [1, 2^(c-1)].
+// Split w = hi * 2^L + lo (L = ceil((c-1)/2)):  sum_w w B_w = 2^L * sum_hi hi * R_hi + sum_lo lo * C_lo  with the row sums
+// R_hi = sum_lo B_(hi,lo) and column sums C_lo = sum_hi B_(hi,lo) — about 2 * 2^(c-1) plain additions instead of the
+// (c-1) * 2^(c-2) of summing every weight-bit class over the buckets directly.  The two small weighted sums (<= 2^L + 1
+// and 2^L entries) are then done by weight bits:  H_t = sum_{hi: bit t} R_hi,  L_t = sum_{lo: bit t} C_lo, c class sums
+// per column in all, and the host folds 2^L * sum_t 2^t H_t + sum_t 2^t L_t  (about 3c group operations).
+// One wave per group: every lane adds its members serially, then an LDS tree over the 64 lanes.
 // ------------------------------------------------------------------------------------------------
-ZK_KERNEL void msm_class_first_kernel(MsmPlan p, uint32_t TM) {
-    const uint32_t col = blockIdx.y / (uint32_t)p.c, t = blockIdx.y % (uint32_t)p.c;
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= p.groups0) return;
+constexpr uint32_t RC_T = 64;
+__device__ __forceinline__ XYZZ rc_wave_sum(XYZZ acc) {
+    __shared__ uint4 pl[8 * RC_T];
+    const uint32_t tid = threadIdx.x;
+    auto put = [&](const XYZZ& v) {
+        const u256* f = &v.x;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            pl[(2 * q) * RC_T + tid] = make_uint4(f[q].v[0], f[q].v[1], f[q].v[2], f[q].v[3]);
+            pl[(2 * q + 1) * RC_T + tid] = make_uint4(f[q].v[4], f[q].v[5], f[q].v[6], f[q].v[7]);
+        }
+    };
+    auto get = [&](uint32_t t) {
+        XYZZ v;
+        u256* f = &v.x;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 l = pl[(2 * q) * RC_T + t], h = pl[(2 * q + 1) * RC_T + t];
+            f[q].v[0] = l.x; f[q].v[1] = l.y; f[q].v[2] = l.z; f[q].v[3] = l.w; f[q].v[4] = h.x; f[q].v[5] = h.y; f[q].v[6] = h.z; f[q].v[7] = h.w;
+        }
+        return v;
+    };
+    put(acc);
+    __syncthreads();
+    for (uint32_t d = RC_T >> 1; d > 0; d >>= 1) {
+        if (tid < d) { xyzz_add(acc, get(tid + d)); }
+        __syncthreads();
+        if (tid < d) put(acc);
+        __syncthreads();
+    }
+    return acc;   // valid in lane 0
+}
+// grid (n_hi + n_lo, nb): group g < n_hi is row hi = g, else column lo = g - n_hi.  out[col * (n_hi + n_lo) + g]
+ZK_KERNEL void msm_rowcol_kernel(MsmPlan p) {
+    const uint32_t col = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, B = p.B;
+    const uint32_t lo_bits = p.lo_bits, n_lo = 1u << lo_bits, n_hi = (B >> lo_bits) + 1;
     const uint32_t r = plan_eff_levels(p, plan_small(p, col)[p.o_info]);
     const uint32_t* so = plan_suboff(p, col, r);
     const void* buf = p.sub[r & 1];
     const size_t cbase = (size_t)col * p.sub_stride[r & 1];
     XYZZ acc = xyzz_identity();
-    if ((int)t == p.c - 1) {
-        const uint32_t b = p.B - 1;
-        if (g == 0 && so[b + 1] > so[b]) acc = load_xyzz(buf, cbase + so[b]);
-    } else {
-        const uint32_t Kc = 1u << (p.c - 2);
-        for (uint32_t m = 0; m < TM; m++) {
-            const uint32_t k = g * TM + m;
-            if (k >= Kc) break;
-            const uint32_t w = ((k >> t) << (t + 1)) | (1u << t) | (k & ((1u << t) - 1u));
+    const bool row = g < n_hi;
+    const uint32_t fixed = row ? g : g - n_hi, count = row ? n_lo : n_hi;
+    for (uint32_t m = tid; m < count; m += RC_T) {
+        const uint32_t w = row ? ((fixed << lo_bits) | m) : ((m << lo_bits) | fixed);
+        if (w >= 1 && w <= B) {
             const uint32_t b = w - 1;
             if (so[b + 1] > so[b]) xyzz_add(acc, load_xyzz(buf, cbase + so[b]));
         }
     }
-    store_xyzz(p.cls[0], ((size_t)col * p.c + t) * p.groups0 + g, acc);
+    acc = rc_wave_sum(acc);
+    if (tid == 0) store_xyzz(p.cls[0], (size_t)col * (n_hi + n_lo) + g, acc);
 }
-ZK_KERNEL void msm_class_round_kernel(const void* in, uint32_t count_in, void* out, uint32_t count_out, uint32_t M) {
-    const uint32_t t = blockIdx.y;  // (col, class) flattened
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= count_out) return;
-    const size_t base = (size_t)t * count_in;
-    XYZZ acc = load_xyzz(in, base + (size_t)g * M);
-    for (uint32_t m = 1; m < M && g * M + m < count_in; m++) xyzz_add(acc, load_xyzz(in, base + (size_t)g * M + m));
-    store_xyzz(out, (size_t)t * count_out + g, acc);
+// grid (c, nb): class t < hi_bits sums the rows whose index has bit t, class hi_bits + t' the columns whose index has bit t'
+ZK_KERNEL void msm_rc_class_kernel(MsmPlan p) {
+    const uint32_t col = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    const uint32_t lo_bits = p.lo_bits, n_lo = 1u << lo_bits, n_hi = (p.B >> lo_bits) + 1, hi_bits = (uint32_t)p.c - lo_bits;
+    const bool rows = t < hi_bits;
+    const uint32_t bit = rows ? t : t - hi_bits, count = rows ? n_hi : n_lo;
+    const size_t base = (size_t)col * (n_hi + n_lo) + (rows ? 0 : n_hi);
+    XYZZ acc = xyzz_identity();
+    for (uint32_t m = tid; m < count; m += RC_T)
+        if ((m >> bit) & 1u) xyzz_add(acc, load_xyzz(p.cls[0], base + m));
+    acc = rc_wave_sum(acc);
+    if (tid == 0) store_xyzz(p.cls[1], (size_t)col * p.c + t, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,7 +530,7 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     const uint64_t pairs_max = (uint64_t)n * W;
     uint32_t Mlog = 1;
     while ((2u << Mlog) <= (uint32_t)std::max(2, tn.msm_merge_fanin) && Mlog < 8) Mlog++;
-    const uint32_t M = 1u << Mlog, TM = (uint32_t)std::max(2, tn.msm_tree_fanin);   // merge fan-in rounded down to a power of two
+    const uint32_t M = 1u << Mlog;   // merge fan-in rounded down to a power of two
     uint32_t L = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)nb * pairs_max / (uint64_t)tn.msm_target_threads, (uint64_t)tn.msm_min_chunk),
                                               (uint64_t)tn.msm_max_chunk);
     MsmPlan p;
@@ -525,10 +561,10 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     ZK_HIP(ctx->ws_sub0.ensure((size_t)nb * p.sub_stride[0] * 128));
     ZK_HIP(ctx->ws_sub1.ensure((size_t)nb * p.sub_stride[1] * 128));
     p.sub[0] = ctx->ws_sub0.p; p.sub[1] = ctx->ws_sub1.p;
-    const uint32_t Kc = 1u << (c - 2);
-    p.groups0 = ceil_div(Kc, TM);
-    ZK_HIP(ctx->ws_cls0.ensure((size_t)nb * c * p.groups0 * 128));
-    ZK_HIP(ctx->ws_cls1.ensure((size_t)nb * c * ceil_div(p.groups0, TM) * 128 + 128));
+    p.lo_bits = (uint32_t)(c - 1 + 1) / 2;                               // ceil((c-1)/2)
+    const uint32_t n_groups = (B >> p.lo_bits) + 1 + (1u << p.lo_bits);  // rows + columns of the weight matrix
+    ZK_HIP(ctx->ws_cls0.ensure((size_t)nb * n_groups * 128));
+    ZK_HIP(ctx->ws_cls1.ensure((size_t)nb * c * 128 + 128));
     p.cls[0] = ctx->ws_cls0.p; p.cls[1] = ctx->ws_cls1.p;
 
     hipStream_t st = ctx->stream;
@@ -566,20 +602,13 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
             pw *= M;
         }
     }
-    uint32_t count = p.groups0;
-    ZK_LAUNCH(msm_class_first_kernel, dim3(ceil_div(p.groups0, (uint32_t)blk), nb * c), blk, 0, st, p, TM);
+    ZK_LAUNCH(msm_rowcol_kernel, dim3(n_groups, nb), RC_T, 0, st, p);
     ZK_CHECK_LAUNCH();
-    int flip = 0;
-    while (count > 1) {
-        uint32_t nxt = ceil_div(count, TM);
-        ZK_LAUNCH(msm_class_round_kernel, dim3(ceil_div(nxt, (uint32_t)blk), nb * c), blk, 0, st, (const void*)p.cls[flip], count, p.cls[flip ^ 1], nxt, TM);
-        ZK_CHECK_LAUNCH();
-        count = nxt;
-        flip ^= 1;
-    }
+    ZK_LAUNCH(msm_rc_class_kernel, dim3((uint32_t)c, nb), RC_T, 0, st, p);
+    ZK_CHECK_LAUNCH();
     t_red.stop();
     std::vector<XYZZ> cls((size_t)nb * c);
-    ZK_HIP(hipMemcpyAsync(cls.data(), p.cls[flip], (size_t)nb * c * 128, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(cls.data(), p.cls[1], (size_t)nb * c * 128, hipMemcpyDeviceToHost, st));
     std::vector<uint32_t> npairs(ctx->timing ? nb : 0);
     for (uint32_t col = 0; col < (uint32_t)npairs.size(); col++)   // off[B] = pairs of the column (zero digits are skipped)
         ZK_HIP(hipMemcpyAsync(&npairs[col], plan_small(p, col) + p.o_off + B, 4, hipMemcpyDeviceToHost, st));
@@ -587,14 +616,16 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     for (uint32_t v : npairs) ctx->last_ms["msm_pairs"] += (double)v;
     if (ctx->timing) ctx->last_ms["msm_columns"] += (double)nb;
     t_sort.resolve(); t_acc.resolve(); t_red.resolve();
-    for (uint32_t col = 0; col < nb; col++) {   // sum_t 2^t C_t, Horner from the top class
+    const int hi_bits = c - (int)p.lo_bits;
+    for (uint32_t col = 0; col < nb; col++) {   // 2^L * sum_t 2^t H_t + sum_t 2^t L_t, Horner from the top class of each half
         const XYZZ* cc = &cls[(size_t)col * c];
-        XYZZ acc = cc[c - 1];
-        for (int t = c - 2; t >= 0; t--) {
-            acc = xyzz_dbl(acc);
-            xyzz_add(acc, cc[t]);
-        }
-        out_xyzz[col] = acc;
+        XYZZ h = cc[hi_bits - 1];
+        for (int t = hi_bits - 2; t >= 0; t--) { h = xyzz_dbl(h); xyzz_add(h, cc[t]); }
+        for (uint32_t t = 0; t < p.lo_bits; t++) h = xyzz_dbl(h);
+        XYZZ l = cc[c - 1];
+        for (int t = (int)p.lo_bits - 2; t >= 0; t--) { l = xyzz_dbl(l); xyzz_add(l, cc[hi_bits + t]); }
+        xyzz_add(h, l);
+        out_xyzz[col] = h;
     }
     return ZK_OK;
 }

@@ -151,6 +151,11 @@ int zk_lookup_product_dev(zk_ctx* ctx, const void* compressed_input, const void*
 int zk_lookup_permute_dev(zk_ctx* ctx, const void* input, const void* table, uint32_t k, uint32_t blinding_factors, const void* blind_input,
                           const void* blind_table, void* out_input, void* out_table);
 
+/* all lookup arguments of a proof in one call (the `for lookup in lookups { lookup.commit_permuted(..) }` loop of create_proof): inputs /
+ * tables / out_inputs / out_tables are HOST arrays of `count` DEVICE columns; blind_inputs / blind_tables: HOST, count x (blinding_factors + 1) x 32 B. */
+int zk_lookup_permute_batch_dev(zk_ctx* ctx, const void* const* inputs, const void* const* tables, size_t count, uint32_t k, uint32_t blinding_factors,
+                                const void* blind_inputs, const void* blind_tables, void* const* out_inputs, void* const* out_tables);
+
 /* ---- evaluation phase (SURVEY 8f "next 2") ----------------------------------------------------- *
  * halo2_proofs src/arithmetic.rs eval_polynomial(poly, point): out[q] = polys[q](points[q]) for `count` queries of n coefficients
  * each (a polynomial queried at several rotations appears several times).  polys: HOST array of DEVICE pointers; points, out: HOST. */

@@ -108,3 +108,32 @@ def test_gpu_lookup_permute_generic_sort_path(gpu, orc, pyref):
         _check(gpu, orc, pyref, 12, "wide", seed=5)
     finally:
         gpu.tune(lookup_force_generic_sort=0)
+
+
+def _check_batch(be, orc, pyref, k, kinds, seed):
+    """several lookups in one zk_lookup_permute_batch_dev call (narrow keys, full-width keys and window ties side by side)"""
+    n = 1 << k
+    M = orc.fr_from_ints
+    ins, tabs, bis, bts, wants = [], [], [], [], []
+    for j, kind in enumerate(kinds):
+        inp, tab, bf = _case(orc, pyref, k, seed + j, kind)
+        bi, bt = pc.rand_fr(orc, pyref, bf + 1, seed + 10 + j), pc.rand_fr(orc, pyref, bf + 1, seed + 20 + j)
+        A, T = M(inp), M(tab)
+        wants.append(orc.lookup_permute(A, T, k, bf, bi, bt))
+        ins.append(be.to_device(A)); tabs.append(be.to_device(T)); bis.append(bi); bts.append(bt)
+    outs = z.permutation.permute_expression_pairs(ins, tabs, k, bf, np.stack(bis), np.stack(bts), backend=be)
+    for (oa, ot), (wi, wt), kind in zip(outs, wants, kinds):
+        assert (oa.download((n, 4)) == wi).all() and (ot.download((n, 4)) == wt).all(), kind
+
+
+def test_emulated_lookup_permute_batch(emu, orc, pyref):
+    emu.tune(vec_block=64)
+    try:
+        _check_batch(emu, orc, pyref, 5, ["small", "window_ties", "wide"], seed=11)
+    finally:
+        emu.tune(vec_block=32)
+
+
+@pytest.mark.gpu
+def test_gpu_lookup_permute_batch(gpu, orc, pyref):
+    _check_batch(gpu, orc, pyref, 13, ["small", "wide", "window_ties", "identical", "perm", "wide", "small"], seed=31)

@@ -322,6 +322,14 @@ class Backend:
                                                 bi.ctypes.data_as(C.c_void_p), bt.ctypes.data_as(C.c_void_p), C.c_void_p(_dptr(out_input)),
                                                 C.c_void_p(_dptr(out_table))))
 
+    def lookup_permute_batch_dev(self, inputs, tables, k: int, blinding_factors: int, blind_inputs, blind_tables, out_inputs, out_tables):
+        cnt = len(inputs)
+        bi = np.ascontiguousarray(np.asarray(blind_inputs, dtype=np.uint64).reshape(cnt, blinding_factors + 1, 4))
+        bt = np.ascontiguousarray(np.asarray(blind_tables, dtype=np.uint64).reshape(cnt, blinding_factors + 1, 4))
+        self._ck(self.lib.zk_lookup_permute_batch_dev(self.ctx, self._ptr_array(inputs), self._ptr_array(tables), C.c_size_t(cnt), C.c_uint32(k),
+                                                      C.c_uint32(blinding_factors), bi.ctypes.data_as(C.c_void_p), bt.ctypes.data_as(C.c_void_p),
+                                                      self._ptr_array(out_inputs), self._ptr_array(out_tables)))
+
     # -- evaluation phase -----------------------------------------------------------------------
     def eval_polynomial_batch_dev(self, polys, n: int, points) -> np.ndarray:
         pts = np.ascontiguousarray(np.asarray(points, dtype=np.uint64).reshape(-1, 4))

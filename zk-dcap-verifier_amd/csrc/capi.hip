@@ -31,6 +31,8 @@ int evaluate_h_host(zk_ctx* ctx, uint64_t pkh, const void* const* advice, const 
                     const void* beta, const void* gamma, const void* theta, const void* y, int finish, void* out);
 int lookup_permute(zk_ctx* ctx, const void* d_input, const void* d_table, uint32_t k, uint32_t blinding_factors, const void* h_blind_input,
                    const void* h_blind_table, void* d_out_input, void* d_out_table);
+int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* const* d_tables, size_t count, uint32_t k, uint32_t blinding_factors,
+                         const void* h_blind_inputs, const void* h_blind_tables, void* const* d_out_inputs, void* const* d_out_tables);
 int g1_ntt(zk_ctx* ctx, const void* d_affine_in, uint32_t log_n, const void* omega_host, const void* scale_host, void* d_affine_out);
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
@@ -252,6 +254,11 @@ int zk_lookup_product_dev(zk_ctx* ctx, const void* cin, const void* ctab, const 
 int zk_lookup_permute_dev(zk_ctx* ctx, const void* input, const void* table, uint32_t k, uint32_t blinding_factors, const void* blind_input,
                           const void* blind_table, void* out_input, void* out_table) {
     ENTER; return lookup_permute(ctx, input, table, k, blinding_factors, blind_input, blind_table, out_input, out_table);
+}
+
+int zk_lookup_permute_batch_dev(zk_ctx* ctx, const void* const* inputs, const void* const* tables, size_t count, uint32_t k, uint32_t blinding_factors,
+                                const void* blind_inputs, const void* blind_tables, void* const* out_inputs, void* const* out_tables) {
+    ENTER; return lookup_permute_batch(ctx, inputs, tables, count, k, blinding_factors, blind_inputs, blind_tables, out_inputs, out_tables);
 }
 
 // ---- evaluation phase ---------------------------------------------------------------------------

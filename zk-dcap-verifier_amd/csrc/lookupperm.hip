@@ -347,8 +347,8 @@ static int xs_scan(zk_ctx* ctx, uint32_t* v, uint32_t m, uint32_t* sums, uint32_
     return ZK_OK;
 }
 
-int lookup_permute(zk_ctx* ctx, const void* d_input, const void* d_table, uint32_t k, uint32_t blinding_factors, const void* h_blind_input,
-                   const void* h_blind_table, void* d_out_input, void* d_out_table) {
+static int lookup_permute_one(zk_ctx* ctx, const void* d_input, const void* d_table, uint32_t k, uint32_t blinding_factors, const void* h_blind_input,
+                              const void* h_blind_table, void* d_out_input, void* d_out_table, bool generic_only) {
     if (!d_input || !d_table || !d_out_input || !d_out_table || !h_blind_input || !h_blind_table)
         return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_dev: null argument");
     if (k < 1 || k > 26) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_dev: k = %u out of range", k);
@@ -409,7 +409,7 @@ int lookup_permute(zk_ctx* ctx, const void* d_input, const void* d_table, uint32
         uint32_t viol = 0;
         ZK_HIP(hipMemcpyAsync(&viol, scal + 12, 4, hipMemcpyDeviceToHost, st));
         ZK_HIP(hipStreamSynchronize(st));
-        if (viol || ctx->tune.lookup_force_generic_sort) {   // rows that tie on the window but differ below it: generic sort on every digit in use
+        if (viol || generic_only) {   // rows that tie on the window but differ below it: generic sort on every digit in use
             ZK_LAUNCH(lp_canon_kernel, g, blk, 0, st, d_input, u, canon_in, in_a, scal + 4);   // (re-creates the identity permutations)
             ZK_CHECK_LAUNCH();
             ZK_LAUNCH(lp_canon_kernel, g, blk, 0, st, d_table, u, canon_tab, tab_a, scal + 4);
@@ -444,6 +444,354 @@ int lookup_permute(zk_ctx* ctx, const void* d_input, const void* d_table, uint32
     ZK_CHECK_LAUNCH();
     ZK_HIP(hipStreamSynchronize(st));
     return ZK_OK;
+}
+
+
+// ================================================================================================================
+// batched form: all lookup arguments of a proof in one call.  Every kernel below is the single-lookup kernel with
+// blockIdx.y selecting the sort (s = 2 * lookup + {0 input, 1 table}) or the lookup, so a proof pays 2 launches per
+// radix pass instead of 2 per pass per column, and the grids are large enough to fill the chip.
+// Layout (S = 2 * count sorts, u rows each): canon[s][u] | keys a/b [s][u] | idx a/b [s][u] | flags[s][u] (repeated / unconsumed)
+// | ranks[s][u] | leftover[l][u] | ghist[s][nwg][256] | xsums[s][nxs] | scal[l][16]
+// ================================================================================================================
+struct LpbArgs {
+    const void* const* cols;     // S device pointers: input_0, table_0, input_1, table_1, ...
+    void* const* outs;           // S device pointers: out_input_0, out_table_0, ...
+    uint32_t u, n, nb, S, nwg, nxs;
+    void* canon; uint2* key_a; uint2* key_b; uint32_t* idx_a; uint32_t* idx_b;
+    uint32_t* flags; uint32_t* ranks; uint32_t* leftover; uint32_t* ghist; uint32_t* xsums; uint32_t* scal;
+    const uint32_t* shifts;      // S words
+    const void* blind;           // [l][2][nb] x 32 B
+};
+ZK_KERNEL void lpb_canon_kernel(LpbArgs a) {
+    __shared__ uint32_t lor[8];
+    const uint32_t s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x < 8) lor[threadIdx.x] = 0;
+    __syncthreads();
+    if (i < a.u) {
+        const u256 c = Fr::from_mont(load_u256(a.cols[s], i));
+        store_u256(a.canon, (size_t)s * a.u + i, c);
+#pragma unroll
+        for (int w = 0; w < 8; w++) if (c.v[w] & ~lor[w]) atomicOr(&lor[w], c.v[w]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && lor[threadIdx.x]) atomicOr(&a.scal[(s >> 1) * 16 + 4 + threadIdx.x], lor[threadIdx.x]);
+}
+ZK_KERNEL void lpb_keys_kernel(LpbArgs a) {
+    const uint32_t s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.u) return;
+    const uint32_t shift = a.shifts[s];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(a.canon) + ((size_t)s * a.u + i) * 8;
+    const uint32_t ws = shift >> 5, bs = shift & 31;
+    uint32_t x[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) x[j] = ws + j < 8 ? w[ws + j] : 0u;
+    uint2 k;
+    k.x = bs ? (x[0] >> bs) | (x[1] << (32 - bs)) : x[0];
+    k.y = bs ? (x[1] >> bs) | (x[2] << (32 - bs)) : x[1];
+    a.key_a[(size_t)s * a.u + i] = k;
+    a.idx_a[(size_t)s * a.u + i] = i;
+}
+ZK_KERNEL void lpb_hist_kernel(const uint2* keys, uint32_t u, uint32_t pass, uint32_t* ghist, uint32_t nwg) {
+    __shared__ uint32_t lh[256];
+    const uint32_t s = blockIdx.y, tid = threadIdx.x, base = blockIdx.x * FS_TILE;
+    keys += (size_t)s * u;
+    lh[tid] = 0;
+    __syncthreads();
+    for (uint32_t e = 0; e < FS_E; e++) {
+        const uint32_t i = base + e * FS_T + tid;
+        if (i < u) atomicAdd(&lh[fs_digit(keys[i], pass)], 1u);
+    }
+    __syncthreads();
+    ghist[((size_t)s * nwg + blockIdx.x) * 256 + tid] = lh[tid];
+}
+ZK_KERNEL void lpb_scatter_kernel(const uint2* keys_in, const uint32_t* idx_in, uint2* keys_out, uint32_t* idx_out, uint32_t u, uint32_t pass,
+                                  const uint32_t* ghist, uint32_t nwg) {
+    __shared__ uint16_t cnt[FS_T * FS_PAD];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t scan[256];
+    const uint32_t s = blockIdx.y, tid = threadIdx.x, wg = blockIdx.x, base = wg * FS_TILE;
+    keys_in += (size_t)s * u; idx_in += (size_t)s * u; keys_out += (size_t)s * u; idx_out += (size_t)s * u;
+    ghist += (size_t)s * nwg * 256;
+    for (uint32_t d = 0; d < 256; d++) cnt[tid * FS_PAD + d] = 0;
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < nwg; w++) {
+        const uint32_t c = ghist[(size_t)w * 256 + tid];
+        if (w < wg) before += c;
+        total += c;
+    }
+    scan[tid] = total;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t add = tid >= d ? scan[tid - d] : 0;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+    }
+    gbase[tid] = scan[tid] - total + before;
+    uint2 k[FS_E];
+    uint32_t v[FS_E];
+    uint16_t rl[FS_E];
+    const uint32_t lo = base + tid * FS_E;
+#pragma unroll
+    for (uint32_t e = 0; e < FS_E; e++) {
+        const uint32_t i = lo + e;
+        if (i < u) {
+            k[e] = keys_in[i]; v[e] = idx_in[i];
+            rl[e] = cnt[tid * FS_PAD + fs_digit(k[e], pass)]++;
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < FS_T; t++) {
+            const uint32_t c = cnt[t * FS_PAD + tid];
+            cnt[t * FS_PAD + tid] = (uint16_t)run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < FS_E; e++) {
+        const uint32_t i = lo + e;
+        if (i < u) {
+            const uint32_t d = fs_digit(k[e], pass);
+            const uint32_t pos = gbase[d] + cnt[tid * FS_PAD + d] + rl[e];
+            keys_out[pos] = k[e];
+            idx_out[pos] = v[e];
+        }
+    }
+}
+ZK_KERNEL void lpb_check_kernel(LpbArgs a, const uint32_t* idx_sorted) {
+    const uint32_t s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 || i >= a.u || a.shifts[s] == 0) return;
+    const uint32_t* canon = reinterpret_cast<const uint32_t*>(a.canon) + (size_t)s * a.u * 8;
+    const uint32_t* idx = idx_sorted + (size_t)s * a.u;
+    const uint32_t* x = canon + (size_t)idx[i - 1] * 8;
+    const uint32_t* y = canon + (size_t)idx[i] * 8;
+    for (int w = 7; w >= 0; w--) {
+        if (x[w] < y[w]) return;
+        if (x[w] > y[w]) { atomicAdd(&a.scal[(s >> 1) * 16 + 12], 1u); return; }
+    }
+}
+// flags[2l][i] = repeated, flags[2l+1][t] = unconsumed (pre-set to 1 by the caller)
+ZK_KERNEL void lpb_mark_kernel(LpbArgs a, const uint32_t* idx_sorted) {
+    const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x, u = a.u;
+    if (i >= u) return;
+    const void* in_canon = (const char*)a.canon + (size_t)(2 * l) * u * 32;
+    const void* tab_canon = (const char*)a.canon + (size_t)(2 * l + 1) * u * 32;
+    const uint32_t* in_idx = idx_sorted + (size_t)(2 * l) * u;
+    const uint32_t* tab_idx = idx_sorted + (size_t)(2 * l + 1) * u;
+    uint32_t* repeated = a.flags + (size_t)(2 * l) * u;
+    uint32_t* unconsumed = a.flags + (size_t)(2 * l + 1) * u;
+    const u256 v = load_u256(in_canon, in_idx[i]);
+    const bool first = i == 0 || lp_cmp(v, load_u256(in_canon, in_idx[i - 1])) != 0;
+    repeated[i] = first ? 0u : 1u;
+    if (!first) return;
+    uint32_t lo = 0, hi = u;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (lp_cmp(load_u256(tab_canon, tab_idx[mid]), v) < 0) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= u || lp_cmp(load_u256(tab_canon, tab_idx[lo]), v) != 0) { atomicAdd(&a.scal[l * 16 + 1], 1u); return; }
+    unconsumed[lo] = 0;
+}
+ZK_KERNEL void lpb_fill_unconsumed_kernel(LpbArgs a) {
+    const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.u) a.flags[(size_t)(2 * l + 1) * a.u + i] = 1u;
+}
+ZK_KERNEL void lpb_tile_sum_kernel(LpbArgs a) {      // over ranks[s] (a copy of flags[s])
+    __shared__ uint32_t part[XS_T];
+    const uint32_t s = blockIdx.y, tid = threadIdx.x, base = blockIdx.x * XS_TILE;
+    const uint32_t* v = a.ranks + (size_t)s * a.u;
+    uint32_t sum = 0;
+    for (uint32_t e = 0; e < XS_E; e++) { const uint32_t i = base + e * XS_T + tid; if (i < a.u) sum += v[i]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = XS_T >> 1; d > 0; d >>= 1) { if (tid < d) part[tid] += part[tid + d]; __syncthreads(); }
+    if (tid == 0) a.xsums[(size_t)s * a.nxs + blockIdx.x] = part[0];
+}
+ZK_KERNEL void lpb_sum_scan_kernel(LpbArgs a) {      // one workgroup per sort: exclusive scan of its tile sums, total -> scal[l][2 + j]
+    __shared__ uint32_t part[1024];
+    const uint32_t s = blockIdx.x, T = blockDim.x, tid = threadIdx.x, m = a.nxs - 1;
+    uint32_t* v = a.xsums + (size_t)s * a.nxs;
+    const uint32_t per = (m + T - 1) / T;
+    const uint32_t lo = tid * per < m ? tid * per : m, hi = lo + per < m ? lo + per : m;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += v[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < T; d <<= 1) {
+        const uint32_t add = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t x = v[i]; v[i] = run; run += x; }
+    if (tid == T - 1) a.scal[(s >> 1) * 16 + 2 + (s & 1)] = part[T - 1];
+}
+ZK_KERNEL void lpb_apply_kernel(LpbArgs a) {
+    __shared__ uint32_t part[XS_T];
+    const uint32_t s = blockIdx.y, tid = threadIdx.x, lo = blockIdx.x * XS_TILE + tid * XS_E, m = a.u;
+    uint32_t* v = a.ranks + (size_t)s * a.u;
+    uint32_t x[XS_E], sum = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < XS_E; e++) { x[e] = lo + e < m ? v[lo + e] : 0u; sum += x[e]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < XS_T; d <<= 1) {
+        const uint32_t add = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    uint32_t run = a.xsums[(size_t)s * a.nxs + blockIdx.x] + part[tid] - sum;
+#pragma unroll
+    for (uint32_t e = 0; e < XS_E; e++) { if (lo + e < m) v[lo + e] = run; run += x[e]; }
+}
+ZK_KERNEL void lpb_compact_kernel(LpbArgs a) {
+    const uint32_t l = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < a.u && a.flags[(size_t)(2 * l + 1) * a.u + t]) a.leftover[(size_t)l * a.u + a.ranks[(size_t)(2 * l + 1) * a.u + t]] = t;
+}
+ZK_KERNEL void lpb_assemble_kernel(LpbArgs a, const uint32_t* idx_sorted) {
+    const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x, u = a.u;
+    if (i >= a.n) return;
+    void* out_in = a.outs[2 * l];
+    void* out_tab = a.outs[2 * l + 1];
+    if (i >= u) {
+        store_u256(out_in, i, load_u256(a.blind, (size_t)(2 * l) * a.nb + (i - u)));
+        store_u256(out_tab, i, load_u256(a.blind, (size_t)(2 * l + 1) * a.nb + (i - u)));
+        return;
+    }
+    const uint32_t* in_idx = idx_sorted + (size_t)(2 * l) * u;
+    const uint32_t* tab_idx = idx_sorted + (size_t)(2 * l + 1) * u;
+    const u256 v = load_u256(a.cols[2 * l], in_idx[i]);
+    store_u256(out_in, i, v);
+    if (!a.flags[(size_t)(2 * l) * u + i]) store_u256(out_tab, i, v);
+    else {
+        const uint32_t n_rep = a.scal[l * 16 + 2];
+        store_u256(out_tab, i, load_u256(a.cols[2 * l + 1], tab_idx[a.leftover[(size_t)l * u + (n_rep - 1 - a.ranks[(size_t)(2 * l) * u + i])]]));
+    }
+}
+
+int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* const* d_tables, size_t count, uint32_t k, uint32_t blinding_factors,
+                         const void* h_blind_inputs, const void* h_blind_tables, void* const* d_out_inputs, void* const* d_out_tables) {
+    if (count == 0) return ZK_OK;
+    if (!d_inputs || !d_tables || !d_out_inputs || !d_out_tables || !h_blind_inputs || !h_blind_tables)
+        return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_batch_dev: null argument");
+    if (k < 1 || k > 26 || count > 4096) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_batch_dev: k = %u / count = %zu out of range", k, count);
+    const uint32_t n = 1u << k, nb = blinding_factors + 1;
+    if (nb >= n) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_batch_dev: blinding_factors too large");
+    for (size_t l = 0; l < count; l++)
+        if (!d_inputs[l] || !d_tables[l] || !d_out_inputs[l] || !d_out_tables[l]) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_batch_dev: null column %zu", l);
+    const uint32_t u = n - nb, S = 2 * (uint32_t)count;
+    const uint32_t nwg = (u + FS_TILE - 1) / FS_TILE, nxs = (u + XS_TILE - 1) / XS_TILE + 1;
+    // workspace carve-up (32-byte aligned pieces first)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_canon = take((size_t)S * u * 32), o_blind = take((size_t)S * nb * 32), o_ka = take((size_t)S * u * 8), o_kb = take((size_t)S * u * 8),
+                 o_ia = take((size_t)S * u * 4), o_ib = take((size_t)S * u * 4), o_fl = take((size_t)S * u * 4), o_rk = take((size_t)S * u * 4),
+                 o_lo = take((size_t)count * u * 4), o_gh = take((size_t)S * nwg * 256 * 4), o_xs = take((size_t)S * nxs * 4), o_sc = take((size_t)count * 64),
+                 o_sh = take((size_t)S * 4), o_cp = take((size_t)S * sizeof(void*)), o_op = take((size_t)S * sizeof(void*));
+    ZK_HIP(ctx->ws_tmp.ensure(off + 256));
+    char* base = (char*)ctx->ws_tmp.p;
+    hipStream_t st = ctx->stream;
+    std::vector<const void*> cols(S);
+    std::vector<void*> outs(S);
+    std::vector<unsigned char> blind((size_t)S * nb * 32);
+    for (size_t l = 0; l < count; l++) {
+        cols[2 * l] = d_inputs[l]; cols[2 * l + 1] = d_tables[l];
+        outs[2 * l] = d_out_inputs[l]; outs[2 * l + 1] = d_out_tables[l];
+        memcpy(&blind[(2 * l) * (size_t)nb * 32], (const char*)h_blind_inputs + l * (size_t)nb * 32, (size_t)nb * 32);
+        memcpy(&blind[(2 * l + 1) * (size_t)nb * 32], (const char*)h_blind_tables + l * (size_t)nb * 32, (size_t)nb * 32);
+    }
+    ZK_HIP(hipMemcpyAsync(base + o_cp, cols.data(), S * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(base + o_op, outs.data(), S * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(base + o_blind, blind.data(), blind.size(), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemsetAsync(base + o_sc, 0, count * 64, st));
+    LpbArgs a;
+    memset(&a, 0, sizeof a);
+    a.cols = (const void* const*)(base + o_cp); a.outs = (void* const*)(base + o_op);
+    a.u = u; a.n = n; a.nb = nb; a.S = S; a.nwg = nwg; a.nxs = nxs;
+    a.canon = base + o_canon; a.key_a = (uint2*)(base + o_ka); a.key_b = (uint2*)(base + o_kb); a.idx_a = (uint32_t*)(base + o_ia); a.idx_b = (uint32_t*)(base + o_ib);
+    a.flags = (uint32_t*)(base + o_fl); a.ranks = (uint32_t*)(base + o_rk); a.leftover = (uint32_t*)(base + o_lo); a.ghist = (uint32_t*)(base + o_gh);
+    a.xsums = (uint32_t*)(base + o_xs); a.scal = (uint32_t*)(base + o_sc); a.shifts = (const uint32_t*)(base + o_sh); a.blind = base + o_blind;
+    const int blk = ctx->tune.vec_block;
+    const uint32_t g = (u + blk - 1) / blk;
+    ZK_LAUNCH(lpb_canon_kernel, dim3(g, S), blk, 0, st, a);
+    ZK_CHECK_LAUNCH();
+    std::vector<uint32_t> sc((size_t)count * 16);
+    ZK_HIP(hipMemcpyAsync(sc.data(), a.scal, count * 64, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    std::vector<uint32_t> shifts(S);
+    uint32_t max_bits = 1;
+    bool any_shift = false;
+    for (size_t l = 0; l < count; l++) {
+        const uint32_t* om = &sc[l * 16 + 4];
+        uint32_t nbits = 1;
+        for (int wd = 7; wd >= 0; wd--)
+            if (om[wd]) { uint32_t top = 31; while (!((om[wd] >> top) & 1)) top--; nbits = (uint32_t)wd * 32 + top + 1; break; }
+        const uint32_t sh = nbits > 64 ? nbits - 64 : 0;
+        shifts[2 * l] = shifts[2 * l + 1] = sh;
+        any_shift |= sh != 0;
+        max_bits = std::max(max_bits, std::min(nbits, 64u));
+    }
+    ZK_HIP(hipMemcpyAsync(base + o_sh, shifts.data(), S * 4, hipMemcpyHostToDevice, st));
+    ZK_LAUNCH(lpb_keys_kernel, dim3((u + 255) / 256, S), 256, 0, st, a);
+    ZK_CHECK_LAUNCH();
+    const uint32_t passes = (max_bits + 7) / 8;
+    uint2 *kin = a.key_a, *kout = a.key_b;
+    uint32_t *iin = a.idx_a, *iout = a.idx_b;
+    for (uint32_t p = 0; p < passes; p++) {
+        ZK_LAUNCH(lpb_hist_kernel, dim3(nwg, S), FS_T, 0, st, (const uint2*)kin, u, p, a.ghist, nwg);
+        ZK_CHECK_LAUNCH();
+        ZK_LAUNCH(lpb_scatter_kernel, dim3(nwg, S), FS_T, 0, st, (const uint2*)kin, (const uint32_t*)iin, kout, iout, u, p, (const uint32_t*)a.ghist, nwg);
+        ZK_CHECK_LAUNCH();
+        std::swap(kin, kout);
+        std::swap(iin, iout);
+    }
+    const uint32_t* sorted = iin;
+    if (any_shift) { ZK_LAUNCH(lpb_check_kernel, dim3(g, S), blk, 0, st, a, sorted); ZK_CHECK_LAUNCH(); }
+    ZK_LAUNCH(lpb_fill_unconsumed_kernel, dim3(g, (uint32_t)count), blk, 0, st, a);
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(lpb_mark_kernel, dim3(g, (uint32_t)count), blk, 0, st, a, sorted);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipMemcpyAsync(a.ranks, a.flags, (size_t)S * u * 4, hipMemcpyDeviceToDevice, st));
+    ZK_LAUNCH(lpb_tile_sum_kernel, dim3(nxs - 1, S), XS_T, 0, st, a);
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(lpb_sum_scan_kernel, S, lp_scan_threads(nxs - 1), 0, st, a);
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(lpb_apply_kernel, dim3(nxs - 1, S), XS_T, 0, st, a);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipMemcpyAsync(sc.data(), a.scal, count * 64, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    std::vector<size_t> redo;
+    for (size_t l = 0; l < count; l++) {
+        const uint32_t* h = &sc[l * 16];
+        if (h[12] || ctx->tune.lookup_force_generic_sort) { redo.push_back(l); continue; }   // window ties: every-digit sort for this lookup
+        if (h[1]) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_dev: %u input value(s) of lookup %zu are not in the table (halo2: Error::ConstraintSystemFailure)", h[1], l);
+        if (h[2] != h[3]) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_dev: internal count mismatch in lookup %zu (%u repeated rows, %u leftover table values)", l, h[2], h[3]);
+    }
+    ZK_LAUNCH(lpb_compact_kernel, dim3(g, (uint32_t)count), blk, 0, st, a);
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(lpb_assemble_kernel, dim3((n + blk - 1) / blk, (uint32_t)count), blk, 0, st, a, sorted);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipStreamSynchronize(st));
+    for (size_t l : redo) {
+        int rc = lookup_permute_one(ctx, d_inputs[l], d_tables[l], k, blinding_factors, (const char*)h_blind_inputs + l * (size_t)nb * 32,
+                                    (const char*)h_blind_tables + l * (size_t)nb * 32, d_out_inputs[l], d_out_tables[l], true);
+        if (rc) return rc;
+    }
+    return ZK_OK;
+}
+int lookup_permute(zk_ctx* ctx, const void* d_input, const void* d_table, uint32_t k, uint32_t blinding_factors, const void* h_blind_input,
+                   const void* h_blind_table, void* d_out_input, void* d_out_table) {
+    if (!d_input || !d_table || !d_out_input || !d_out_table || !h_blind_input || !h_blind_table)
+        return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_dev: null argument");
+    const void* ins[1] = {d_input}; const void* tabs[1] = {d_table};
+    void* oi[1] = {d_out_input}; void* ot[1] = {d_out_table};
+    return lookup_permute_batch(ctx, ins, tabs, 1, k, blinding_factors, h_blind_input, h_blind_table, oi, ot);
 }
 
 }  // namespace zk

@@ -54,3 +54,15 @@ def permute_expression_pair(compressed_input, compressed_table, k: int, blinding
     a, s = be.alloc(n * 32), be.alloc(n * 32)
     be.lookup_permute_dev(compressed_input, compressed_table, k, blinding_factors, blind_input, blind_table, a, s)
     return a, s
+
+
+def permute_expression_pairs(compressed_inputs, compressed_tables, k: int, blinding_factors: int, blind_inputs, blind_tables, backend: Backend | None = None):
+    """All lookup arguments of a proof at once (the loop over `lookups` in create_proof's phase 3): one launch sequence for every sort.
+    blind_inputs / blind_tables: (count, blinding_factors + 1, 4).  Returns [(permuted_input, permuted_table)] device buffers."""
+    be = backend or default_backend()
+    n = 1 << k
+    outs = [(be.alloc(n * 32), be.alloc(n * 32)) for _ in compressed_inputs]
+    if outs:
+        be.lookup_permute_batch_dev(compressed_inputs, compressed_tables, k, blinding_factors, blind_inputs, blind_tables,
+                                    [o[0] for o in outs], [o[1] for o in outs])
+    return outs

@@ -24,7 +24,7 @@ import numpy as np
 
 from ..fields import R_MOD, fr_int, fr_mont, fr_mont_array, g1_affine_ints, omega, rand_fr_array
 from ..kzg import ParamsKZG
-from ..permutation import lookup_commit_product, permutation_commit, permute_expression_pair
+from ..permutation import lookup_commit_product, permutation_commit, permute_expression_pairs
 from .circuit import ADVICE, FIXED, INSTANCE
 from .keygen import ProvingKey
 from .shplonk import ProverQuery, ProverSHPLONK
@@ -100,7 +100,7 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     theta = transcript.squeeze_challenge()
     one = fr_mont(1)
     th = fr_mont(theta)
-    compressed, permuted = [], []
+    compressed = []
     for (cin_ev, ctab_ev) in pk.lookup_compressors:
         pair = []
         for evl in (cin_ev, ctab_ev):
@@ -111,10 +111,12 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
                            beta=one, gamma=one, theta=th, y=one, out=out)
             pair.append(out)
         compressed.append(pair)
-        bi, bt = rand_fr_array(rng, bf + 1), rand_fr_array(rng, bf + 1)
-        a, s = permute_expression_pair(pair[0], pair[1], k, bf, bi, bt, backend=be)   # raises ZkError when an input is not in the table
-        owned += [a, s]
-        permuted.append((a, s))
+    # permute_expression_pair of every lookup in one device call (raises ZkError when an input is not in the table)
+    bi = np.stack([rand_fr_array(rng, bf + 1) for _ in compressed]) if compressed else np.zeros((0, bf + 1, 4), np.uint64)
+    bt = np.stack([rand_fr_array(rng, bf + 1) for _ in compressed]) if compressed else np.zeros((0, bf + 1, 4), np.uint64)
+    permuted = permute_expression_pairs([c[0] for c in compressed], [c[1] for c in compressed], k, bf, bi, bt, backend=be)
+    for a_, s_ in permuted:
+        owned += [a_, s_]
     flat = [c for pr in permuted for c in pr]
     for pt in commit_all(params.g_lagrange.handle, flat):           # per lookup: permuted input, permuted table
         transcript.write_point(pt)

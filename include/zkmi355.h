@@ -144,6 +144,16 @@ int zk_lookup_product_dev(zk_ctx* ctx, const void* compressed_input, const void*
                           const void* permuted_table, uint32_t k, const void* beta, const void* gamma, const void* blinding,
                           uint32_t blinding_factors, void* z_dev);
 
+/* permutation::Argument::commit for ALL column sets in one call: values / sigmas = the n_columns equality-enabled columns in cs.permutation.columns order
+ * (HOST arrays of DEVICE columns), cut into sets of chunk_len = cs.degree() - 2; set s starts at the last unblinded value of set s - 1 and delta powers
+ * continue across sets; blinding: HOST n_sets x blinding_factors x 32 B; z_devs: HOST array of n_sets DEVICE outputs. */
+int zk_permutation_product_all_dev(zk_ctx* ctx, const void* const* values, const void* const* sigmas, size_t n_columns, uint32_t chunk_len, uint32_t k,
+                                   const void* beta, const void* gamma, const void* blinding, uint32_t blinding_factors, void* const* z_devs);
+/* commit_product of `count` lookups in one call: cols4 = HOST array of 4*count DEVICE columns (compressed_input, compressed_table, permuted_input,
+ * permuted_table per lookup); blinding: HOST count x blinding_factors x 32 B; z_devs: HOST array of count DEVICE outputs (n x 32 B each). */
+int zk_lookup_product_batch_dev(zk_ctx* ctx, const void* const* cols4, size_t count, uint32_t k, const void* beta, const void* gamma, const void* blinding,
+                                uint32_t blinding_factors, void* const* z_devs);
+
 /* halo2_proofs src/plonk/lookup/prover.rs permute_expression_pair (SURVEY 8f "next 4"): input / table = the theta-compressed
  * expressions over the n = 2^k rows (DEVICE); the first n - (blinding_factors + 1) rows are permuted (A' sorted, S' aligned),
  * the remaining rows take blind_input / blind_table (HOST, (blinding_factors + 1) x 32 B each — the caller's Fr::random draws).

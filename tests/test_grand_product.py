@@ -71,7 +71,14 @@ def _check_backend(be, orc, pyref, k, count, seed, bf=5):
     want_l = orc.lookup_product(vals[0], sig[0], vals[-1], sig[-1], k, beta, gamma, blind)
     be.lookup_product_dev(dv[0], ds[0], dv[-1], ds[-1], k, beta, gamma, blind, dz)
     assert (dz.download((n, 4)) == want_l).all()
-    for d in dv + ds + [dz]:
+    # every lookup of a proof in one call (k >= 11 takes the batched launch sequence, smaller domains the per-lookup one)
+    quads = [(dv[0], ds[0], dv[-1], ds[-1]), (ds[0], dv[0], ds[-1], dv[-1]), (dv[-1], ds[-1], dv[0], ds[0])]
+    hq = [(vals[0], sig[0], vals[-1], sig[-1]), (sig[0], vals[0], sig[-1], vals[-1]), (vals[-1], sig[-1], vals[0], sig[0])]
+    blinds = [pc.rand_fr(orc, pyref, bf, seed + 40 + j) for j in range(3)]
+    zs = z.permutation.lookup_commit_products(quads, k, beta, gamma, np.stack(blinds), backend=be)
+    for zz, q, b in zip(zs, hq, blinds):
+        assert (zz.download((n, 4)) == orc.lookup_product(q[0], q[1], q[2], q[3], k, beta, gamma, b)).all()
+    for d in dv + ds + [dz] + zs:
         d.free()
 
 
@@ -80,9 +87,10 @@ def test_emulated_grand_products(emu, orc, pyref, k, count):
     _check_backend(emu, orc, pyref, k, count, seed=10 * k + count)
 
 
-def test_permutation_commit_chains_sets(emu, orc, pyref):
+@pytest.mark.parametrize("k", [5, 12])     # 12: the all-sets-in-one-launch path (domains of at least one scan span), 5: set by set
+def test_permutation_commit_chains_sets(emu, orc, pyref, k):
     """permutation_commit(): z of set s starts at the last unblinded value of set s-1, delta powers continue."""
-    k, cs_degree, ncols, bf = 5, 4, 5, 5
+    cs_degree, ncols, bf = 4, 5, 5
     n = 1 << k
     vals, sig, beta, gamma = _inputs(orc, pyref, k, ncols, 21)
     blind = [pc.rand_fr(orc, pyref, bf, 30 + s) for s in range(3)]

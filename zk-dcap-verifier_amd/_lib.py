@@ -315,6 +315,24 @@ class Backend:
                                                 C.c_uint32(k), sc[0].ctypes.data_as(C.c_void_p), sc[1].ctypes.data_as(C.c_void_p),
                                                 bl.ctypes.data_as(C.c_void_p), C.c_uint32(bl.shape[0]), C.c_void_p(_dptr(z_dev))))
 
+    def permutation_product_all_dev(self, values, sigmas, chunk_len: int, k: int, beta, gamma, blinding, z_devs):
+        n_sets = len(z_devs)
+        bl = np.ascontiguousarray(np.asarray(blinding, dtype=np.uint64).reshape(n_sets, -1, 4))
+        sc = [self._fe(v) for v in (beta, gamma)]
+        self._ck(self.lib.zk_permutation_product_all_dev(self.ctx, self._ptr_array(values), self._ptr_array(sigmas), C.c_size_t(len(values)), C.c_uint32(chunk_len),
+                                                         C.c_uint32(k), sc[0].ctypes.data_as(C.c_void_p), sc[1].ctypes.data_as(C.c_void_p),
+                                                         bl.ctypes.data_as(C.c_void_p), C.c_uint32(bl.shape[1]), self._ptr_array(z_devs)))
+
+    def lookup_product_batch_dev(self, quads, k, beta, gamma, blinding, z_devs):
+        """quads: [(compressed_input, compressed_table, permuted_input, permuted_table)] device columns; blinding: (count, bf, 4)."""
+        cnt = len(quads)
+        bl = np.ascontiguousarray(np.asarray(blinding, dtype=np.uint64).reshape(cnt, -1, 4))
+        sc = [self._fe(v) for v in (beta, gamma)]
+        flat = [c for q in quads for c in q]
+        self._ck(self.lib.zk_lookup_product_batch_dev(self.ctx, self._ptr_array(flat), C.c_size_t(cnt), C.c_uint32(k), sc[0].ctypes.data_as(C.c_void_p),
+                                                      sc[1].ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p), C.c_uint32(bl.shape[1]),
+                                                      self._ptr_array(z_devs)))
+
     def lookup_permute_dev(self, inp, table, k: int, blinding_factors: int, blind_input, blind_table, out_input, out_table):
         bi = np.ascontiguousarray(np.asarray(blind_input, dtype=np.uint64).reshape(blinding_factors + 1, 4))
         bt = np.ascontiguousarray(np.asarray(blind_table, dtype=np.uint64).reshape(blinding_factors + 1, 4))

@@ -19,6 +19,10 @@ int permutation_product(zk_ctx* ctx, const void* const* values, const void* cons
                         const void* delta_start, const void* z_init, const void* blinding, uint32_t bf, void* d_z, void* h_last_z);
 int lookup_product(zk_ctx* ctx, const void* cin, const void* ctab, const void* pin, const void* ptab, uint32_t k, const void* beta, const void* gamma,
                    const void* blinding, uint32_t bf, void* d_z);
+int permutation_product_all(zk_ctx* ctx, const void* const* values, const void* const* sigmas, size_t m, uint32_t chunk_len, uint32_t k, const void* beta,
+                            const void* gamma, const void* blinding, uint32_t bf, void* const* d_zs);
+int lookup_product_batch(zk_ctx* ctx, const void* const* cols4, size_t count, uint32_t k, const void* beta, const void* gamma, const void* blinding,
+                         uint32_t bf, void* const* d_zs);
 int eval_polynomial_batch(zk_ctx* ctx, const void* const* polys, size_t count, size_t n, const void* points, void* out);
 int kate_division(zk_ctx* ctx, const void* d_a, size_t n, const void* b_host, void* d_q);
 int fr_lincomb(zk_ctx* ctx, const void* const* polys, const void* scalars, size_t count, size_t n, void* d_out);
@@ -249,6 +253,15 @@ int zk_permutation_product_dev(zk_ctx* ctx, const void* const* values, const voi
 int zk_lookup_product_dev(zk_ctx* ctx, const void* cin, const void* ctab, const void* pin, const void* ptab, uint32_t k, const void* beta,
                           const void* gamma, const void* blinding, uint32_t blinding_factors, void* z_dev) {
     ENTER; return lookup_product(ctx, cin, ctab, pin, ptab, k, beta, gamma, blinding, blinding_factors, z_dev);
+}
+
+int zk_permutation_product_all_dev(zk_ctx* ctx, const void* const* values, const void* const* sigmas, size_t n_columns, uint32_t chunk_len, uint32_t k,
+                                   const void* beta, const void* gamma, const void* blinding, uint32_t blinding_factors, void* const* z_devs) {
+    ENTER; return permutation_product_all(ctx, values, sigmas, n_columns, chunk_len, k, beta, gamma, blinding, blinding_factors, z_devs);
+}
+int zk_lookup_product_batch_dev(zk_ctx* ctx, const void* const* cols4, size_t count, uint32_t k, const void* beta, const void* gamma, const void* blinding,
+                                uint32_t blinding_factors, void* const* z_devs) {
+    ENTER; return lookup_product_batch(ctx, cols4, count, k, beta, gamma, blinding, blinding_factors, z_devs);
 }
 
 int zk_lookup_permute_dev(zk_ctx* ctx, const void* input, const void* table, uint32_t k, uint32_t blinding_factors, const void* blind_input,

@@ -10,6 +10,7 @@
 // inversion is Montgomery's trick on per-thread chunks.  Outputs feed zk_msm / zk_lagrange_to_coeff
 // directly, so the column never leaves HBM.
 #include "ctx.h"
+#include <algorithm>
 #include <vector>
 
 namespace zk {
@@ -56,6 +57,15 @@ ZK_KERNEL void gp_lookup_fraction_kernel(const void* cin, const void* ctab, cons
     if (i >= n) return;
     store_u256(num, i, Fr::mul(Fr::add(load_u256(cin, i), beta), Fr::add(load_u256(ctab, i), gamma)));
     store_u256(den, i, Fr::mul(Fr::add(load_u256(pin, i), beta), Fr::add(load_u256(ptab, i), gamma)));
+}
+// batched: blockIdx.y = lookup; cols = [cin_0, ctab_0, pin_0, ptab_0, cin_1, ...] (device array), num / den = [l][n]
+ZK_KERNEL void gp_lookup_fraction_batch_kernel(const void* const* cols, uint32_t n, u256 beta, u256 gamma, void* num, void* den) {
+    const uint32_t l = blockIdx.y;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const void* const* c = cols + 4 * (size_t)l;
+    store_u256(num, (size_t)l * n + i, Fr::mul(Fr::add(load_u256(c[0], i), beta), Fr::add(load_u256(c[1], i), gamma)));
+    store_u256(den, (size_t)l * n + i, Fr::mul(Fr::add(load_u256(c[2], i), beta), Fr::add(load_u256(c[3], i), gamma)));
 }
 // frac[i] = num[i] / den[i] in place on num; one inversion per `chunk` rows (0 denominators invert to 0, as batch_invert does)
 ZK_KERNEL void gp_batch_divide_kernel(void* num, const void* den, uint32_t n, uint32_t chunk, void* scratch) {
@@ -132,7 +142,8 @@ ZK_KERNEL void gp_scan_local_kernel(void* x, uint32_t n, void* totals) {
     if (threadIdx.x == 0) store_u256(totals, blockIdx.x, total);
 }
 // phase B (single workgroup): totals[b] <- exclusive prefix product of the workgroup totals
-ZK_KERNEL void gp_scan_totals_kernel(void* totals, uint32_t nblocks) {
+ZK_KERNEL void gp_scan_totals_kernel(void* totals_all, uint32_t nblocks) {
+    void* totals = (char*)totals_all + (size_t)blockIdx.x * nblocks * 32;      // one workgroup per column of a batch
     const uint32_t per = (nblocks + blockDim.x - 1) / blockDim.x;
     const uint32_t lo = threadIdx.x * per < nblocks ? threadIdx.x * per : nblocks;
     const uint32_t hi = lo + per < nblocks ? lo + per : nblocks;
@@ -158,6 +169,23 @@ ZK_KERNEL void gp_assemble_kernel(const void* local, const void* block_prefix, u
         o = Fr::mul(Fr::mul(load_u256(local, src), load_u256(block_prefix, src / span)), init);
     }
     store_u256(z, i, o);
+}
+
+// batched phase C: blockIdx.y = column; local / block_prefix / z are [col][..]; inits: per-column Montgomery scalars (device); blinding [col][bf]
+ZK_KERNEL void gp_assemble_batch_kernel(const void* local, const void* block_prefix, uint32_t n, uint32_t n_keep, const void* inits, const void* blinding,
+                                        uint32_t bf, void* const* zs, uint32_t nblocks) {
+    const uint32_t span = GP_T * GP_E, c = blockIdx.y;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u256 init = load_u256(inits, c);
+    u256 o;
+    if (i >= n_keep) o = load_u256(blinding, (size_t)c * bf + (i - n_keep));
+    else if (i == 0) o = init;
+    else {
+        const uint32_t src = (uint32_t)i - 1;
+        o = Fr::mul(Fr::mul(load_u256(local, (size_t)c * n + src), load_u256(block_prefix, (size_t)c * nblocks + src / span)), init);
+    }
+    store_u256(zs[c], i, o);
 }
 
 // ---- host ------------------------------------------------------------------------------------------
@@ -232,6 +260,152 @@ int lookup_product(zk_ctx* ctx, const void* cin, const void* ctab, const void* p
     ZK_LAUNCH(gp_lookup_fraction_kernel, (n + blk - 1) / blk, blk, 0, ctx->stream, cin, ctab, pin, ptab, n, rd(beta), rd(gamma), num, den);
     ZK_CHECK_LAUNCH();
     return gp_finish(ctx, num, den, d_aux, n, Fr::one(), blinding, bf, d_z, nullptr);
+}
+
+
+// All lookup grand products of a proof in one launch sequence (Permuted::commit_product for every lookup): the batch
+// inversion's one Fermat chain per thread is paid once, not once per lookup.  Needs n to be a multiple of the scan span.
+int lookup_product_batch(zk_ctx* ctx, const void* const* cols4, size_t count, uint32_t k, const void* beta, const void* gamma, const void* blinding,
+                         uint32_t bf, void* const* d_zs) {
+    if (count == 0) return ZK_OK;
+    if (!cols4 || !beta || !gamma || !d_zs || (bf && !blinding)) return ctx->fail(ZK_ERR_ARG, "zk_lookup_product_batch_dev: null argument");
+    if (k > 27 || k < 1 || count > 4096) return ctx->fail(ZK_ERR_ARG, "zk_lookup_product_batch_dev: k / count out of range");
+    const uint32_t n = 1u << k;
+    if (bf + 1 >= n) return ctx->fail(ZK_ERR_ARG, "zk_lookup_product_batch_dev: blinding_factors too large");
+    for (size_t i = 0; i < 4 * count; i++) if (!cols4[i]) return ctx->fail(ZK_ERR_ARG, "zk_lookup_product_batch_dev: null column");
+    for (size_t i = 0; i < count; i++) if (!d_zs[i]) return ctx->fail(ZK_ERR_ARG, "zk_lookup_product_batch_dev: null output");
+    auto rd = [](const void* p) { u256 o; memcpy(&o, p, 32); return o; };
+    const uint32_t span = GP_T * GP_E;
+    if (n % span) {   // tiny domains: the scan spans would straddle columns
+        for (size_t l = 0; l < count; l++) {
+            int rc = lookup_product(ctx, cols4[4 * l], cols4[4 * l + 1], cols4[4 * l + 2], cols4[4 * l + 3], k, beta, gamma,
+                                    (const char*)blinding + l * (size_t)bf * 32, bf, d_zs[l]);
+            if (rc) return rc;
+        }
+        return ZK_OK;
+    }
+    const uint32_t nblocks = n / span;
+    const size_t N = (size_t)count * n;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_num = take(N * 32), o_den = take(N * 32), o_scr = take(N * 32), o_tot = take((size_t)count * nblocks * 32), o_bl = take((size_t)count * (bf + 1) * 32),
+                 o_in = take(count * 32), o_cp = take(4 * count * sizeof(void*)), o_zp = take(count * sizeof(void*));
+    ZK_HIP(ctx->ws_tmp.ensure(off + 256));
+    char* base = (char*)ctx->ws_tmp.p;
+    hipStream_t st = ctx->stream;
+    const int blk = ctx->tune.vec_block;
+    ZK_HIP(hipMemcpyAsync(base + o_cp, cols4, 4 * count * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(base + o_zp, d_zs, count * sizeof(void*), hipMemcpyHostToDevice, st));
+    if (bf) ZK_HIP(hipMemcpyAsync(base + o_bl, blinding, (size_t)count * bf * 32, hipMemcpyHostToDevice, st));
+    std::vector<u256> ones(count, Fr::one());
+    ZK_HIP(hipMemcpyAsync(base + o_in, ones.data(), count * 32, hipMemcpyHostToDevice, st));
+    ZK_LAUNCH(gp_lookup_fraction_batch_kernel, dim3((n + blk - 1) / blk, (uint32_t)count), blk, 0, st, (const void* const*)(base + o_cp), n, rd(beta), rd(gamma),
+              (void*)(base + o_num), (void*)(base + o_den));
+    ZK_CHECK_LAUNCH();
+    const uint32_t chunk = 32;
+    ZK_LAUNCH(gp_batch_divide_kernel, (uint32_t)(((N + chunk - 1) / chunk + blk - 1) / blk), blk, 0, st, (void*)(base + o_num), (const void*)(base + o_den), (uint32_t)N, chunk,
+              (void*)(base + o_scr));
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(gp_scan_local_kernel, (uint32_t)(count * nblocks), GP_T, 0, st, (void*)(base + o_num), (uint32_t)N, (void*)(base + o_tot));
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(gp_scan_totals_kernel, (uint32_t)count, GP_T, 0, st, (void*)(base + o_tot), nblocks);
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(gp_assemble_batch_kernel, dim3((n + blk - 1) / blk, (uint32_t)count), blk, 0, st, (const void*)(base + o_num), (const void*)(base + o_tot), n, n - bf,
+              (const void*)(base + o_in), (const void*)(base + o_bl), bf, (void* const*)(base + o_zp), nblocks);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipStreamSynchronize(st));
+    return ZK_OK;
+}
+
+
+// All column sets of the permutation argument in one launch sequence (permutation::Argument::commit's loop over chunks).  The sets
+// chain through z_s[0] = z_(s-1)[n - bf - 1]; here every set is first scanned with init = 1, the few chaining products are done on the
+// host from two downloaded values per set, and the assemble pass applies them.  d_zs: n_sets outputs; blinding: n_sets x bf x 32 B.
+int permutation_product_all(zk_ctx* ctx, const void* const* values, const void* const* sigmas, size_t m, uint32_t chunk_len, uint32_t k, const void* beta,
+                            const void* gamma, const void* blinding, uint32_t bf, void* const* d_zs) {
+    if (m == 0) return ZK_OK;
+    if (!values || !sigmas || !beta || !gamma || !d_zs || (bf && !blinding) || chunk_len == 0) return ctx->fail(ZK_ERR_ARG, "zk_permutation_product_all_dev: null argument");
+    if (chunk_len > (uint32_t)GP_MAX_COLS) return ctx->fail(ZK_ERR_LIMIT, "zk_permutation_product_all_dev: %u columns per set (max %d)", chunk_len, GP_MAX_COLS);
+    if (k > 27 || k < 1) return ctx->fail(ZK_ERR_ARG, "zk_permutation_product_all_dev: k = %u out of range", k);
+    const uint32_t n = 1u << k;
+    if (bf + 2 >= n) return ctx->fail(ZK_ERR_ARG, "zk_permutation_product_all_dev: blinding_factors too large");
+    const size_t n_sets = (m + chunk_len - 1) / chunk_len;
+    auto rd = [](const void* p) { u256 o; memcpy(&o, p, 32); return o; };
+    const uint64_t dl[4] = BN254_FR_DELTA_M;
+    u256 delta;
+    for (int i = 0; i < 8; i++) delta.v[i] = (uint32_t)(dl[i >> 1] >> (32 * (i & 1)));
+    const uint32_t span = GP_T * GP_E;
+    if (n % span) {   // tiny domains: set by set
+        u256 z_init = Fr::one(), dstart = Fr::one();
+        for (size_t sidx = 0; sidx < n_sets; sidx++) {
+            const size_t lo = sidx * chunk_len, cnt = std::min<size_t>(chunk_len, m - lo);
+            u256 last;
+            int rc = permutation_product(ctx, values + lo, sigmas + lo, cnt, k, beta, gamma, &dstart, &z_init, (const char*)blinding + sidx * (size_t)bf * 32, bf,
+                                         d_zs[sidx], &last);
+            if (rc) return rc;
+            z_init = last;
+            for (size_t j = 0; j < cnt; j++) dstart = Fr::mul(dstart, delta);
+        }
+        return ZK_OK;
+    }
+    const uint32_t nblocks = n / span;
+    const size_t N = n_sets * (size_t)n;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_num = take(N * 32), o_den = take(N * 32), o_scr = take(N * 32), o_tot = take(n_sets * nblocks * 32), o_bl = take(n_sets * (size_t)(bf + 1) * 32),
+                 o_in = take(n_sets * 32), o_zp = take(n_sets * sizeof(void*));
+    ZK_HIP(ctx->ws_tmp.ensure(off + 256));
+    char* base = (char*)ctx->ws_tmp.p;
+    hipStream_t st = ctx->stream;
+    const int blk = ctx->tune.vec_block;
+    GpPermArgs a;
+    memset(&a, 0, sizeof a);
+    a.n = n; a.beta = rd(beta); a.gamma = rd(gamma);
+    int rc = ntt_pow_tables(ctx, k, domain_omega(k), &a.tw_lo, &a.tw_hi, &a.lo_bits);
+    if (rc) return rc;
+    ZK_HIP(ctx->ws_tmp.ensure(off + 256));     // (ntt_pow_tables may have touched other workspaces, not this one)
+    base = (char*)ctx->ws_tmp.p;
+    u256 cur = a.beta;                           // delta^j * beta, continuing across the sets
+    for (size_t sidx = 0; sidx < n_sets; sidx++) {
+        const size_t lo = sidx * chunk_len, cnt = std::min<size_t>(chunk_len, m - lo);
+        a.count = (uint32_t)cnt;
+        for (size_t j = 0; j < cnt; j++) {
+            if (!values[lo + j] || !sigmas[lo + j]) return ctx->fail(ZK_ERR_ARG, "zk_permutation_product_all_dev: null column %zu", lo + j);
+            a.values[j] = values[lo + j]; a.sigmas[j] = sigmas[lo + j];
+            a.delta_beta[j] = cur;
+            cur = Fr::mul(cur, delta);
+        }
+        a.num = base + o_num + sidx * (size_t)n * 32;
+        a.den = base + o_den + sidx * (size_t)n * 32;
+        ZK_LAUNCH(gp_perm_fraction_kernel, (n + blk - 1) / blk, blk, 0, st, a);
+        ZK_CHECK_LAUNCH();
+    }
+    ZK_HIP(hipMemcpyAsync(base + o_zp, d_zs, n_sets * sizeof(void*), hipMemcpyHostToDevice, st));
+    if (bf) ZK_HIP(hipMemcpyAsync(base + o_bl, blinding, n_sets * (size_t)bf * 32, hipMemcpyHostToDevice, st));
+    const uint32_t chunk = 32;
+    ZK_LAUNCH(gp_batch_divide_kernel, (uint32_t)(((N + chunk - 1) / chunk + blk - 1) / blk), blk, 0, st, (void*)(base + o_num), (const void*)(base + o_den), (uint32_t)N, chunk,
+              (void*)(base + o_scr));
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(gp_scan_local_kernel, (uint32_t)(n_sets * nblocks), GP_T, 0, st, (void*)(base + o_num), (uint32_t)N, (void*)(base + o_tot));
+    ZK_CHECK_LAUNCH();
+    ZK_LAUNCH(gp_scan_totals_kernel, (uint32_t)n_sets, GP_T, 0, st, (void*)(base + o_tot), nblocks);
+    ZK_CHECK_LAUNCH();
+    // chaining: P_s = prod_{j < n - bf - 1} frac_s[j] = local[src] * block_prefix[src / span], src = n - bf - 2
+    const uint32_t src = n - bf - 2;
+    std::vector<u256> loc(n_sets), pre(n_sets), inits(n_sets);
+    for (size_t sidx = 0; sidx < n_sets; sidx++) {
+        ZK_HIP(hipMemcpyAsync(&loc[sidx], base + o_num + (sidx * (size_t)n + src) * 32, 32, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipMemcpyAsync(&pre[sidx], base + o_tot + (sidx * (size_t)nblocks + src / span) * 32, 32, hipMemcpyDeviceToHost, st));
+    }
+    ZK_HIP(hipStreamSynchronize(st));
+    u256 init = Fr::one();
+    for (size_t sidx = 0; sidx < n_sets; sidx++) { inits[sidx] = init; init = Fr::mul(init, Fr::mul(loc[sidx], pre[sidx])); }
+    ZK_HIP(hipMemcpyAsync(base + o_in, inits.data(), n_sets * 32, hipMemcpyHostToDevice, st));
+    ZK_LAUNCH(gp_assemble_batch_kernel, dim3((n + blk - 1) / blk, (uint32_t)n_sets), blk, 0, st, (const void*)(base + o_num), (const void*)(base + o_tot), n, n - bf,
+              (const void*)(base + o_in), (const void*)(base + o_bl), bf, (void* const*)(base + o_zp), nblocks);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipStreamSynchronize(st));
+    return ZK_OK;
 }
 
 }  // namespace zk

@@ -28,13 +28,10 @@ def permutation_commit(columns, sigmas, k: int, cs_degree: int, beta, gamma, bli
     be = backend or default_backend()
     chunk = cs_degree - 2
     n = 1 << k
-    zs = []
-    last_z = _mont(1)
-    for s, lo in enumerate(range(0, len(columns), chunk)):
-        z = be.alloc(n * 32)
-        last_z = be.permutation_product_dev(columns[lo:lo + chunk], sigmas[lo:lo + chunk], k, beta, gamma, _mont(pow(DELTA, lo, R_MOD)), last_z,
-                                            blinding_rows[s], z)
-        zs.append(z)
+    n_sets = (len(columns) + chunk - 1) // chunk
+    zs = [be.alloc(n * 32) for _ in range(n_sets)]
+    if zs:   # every set in one device call: fractions per set, ONE batch inversion, scans, host-side chaining of the set boundaries
+        be.permutation_product_all_dev(columns, sigmas, chunk, k, beta, gamma, np.stack([np.asarray(b, dtype=np.uint64).reshape(-1, 4) for b in blinding_rows[:n_sets]]), zs)
     return zs
 
 
@@ -66,3 +63,13 @@ def permute_expression_pairs(compressed_inputs, compressed_tables, k: int, blind
         be.lookup_permute_batch_dev(compressed_inputs, compressed_tables, k, blinding_factors, blind_inputs, blind_tables,
                                     [o[0] for o in outs], [o[1] for o in outs])
     return outs
+
+
+def lookup_commit_products(quads, k: int, beta, gamma, blinding_rows, backend: Backend | None = None):
+    """commit_product of every lookup of a proof in one device call; quads = [(compressed_input, compressed_table, permuted_input, permuted_table)],
+    blinding_rows: (count, blinding_factors, 4).  Returns the z device buffers."""
+    be = backend or default_backend()
+    zs = [be.alloc((1 << k) * 32) for _ in quads]
+    if zs:
+        be.lookup_product_batch_dev(quads, k, beta, gamma, blinding_rows, zs)
+    return zs

@@ -24,7 +24,7 @@ import numpy as np
 
 from ..fields import R_MOD, fr_int, fr_mont, fr_mont_array, g1_affine_ints, omega, rand_fr_array
 from ..kzg import ParamsKZG
-from ..permutation import lookup_commit_product, permutation_commit, permute_expression_pairs
+from ..permutation import lookup_commit_products, permutation_commit, permute_expression_pairs
 from .circuit import ADVICE, FIXED, INSTANCE
 from .keygen import ProvingKey
 from .shplonk import ProverQuery, ProverSHPLONK
@@ -134,14 +134,10 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     zs = permutation_commit(perm_values, pk.sigma_values, k, cs.degree(), bt_m, gm_m, [rand_fr_array(rng, bf) for _ in range(n_sets)], backend=be) \
         if perm_values else []
     owned += zs
-    for pt in commit_all(params.g_lagrange.handle, zs):
-        transcript.write_point(pt)
-    lzs = []
-    for (cin, ctab), (a, s) in zip(compressed, permuted):
-        z = lookup_commit_product(cin, ctab, a, s, k, bt_m, gm_m, rand_fr_array(rng, bf), backend=be)
-        owned.append(z)
-        lzs.append(z)
-    for pt in commit_all(params.g_lagrange.handle, lzs):
+    lzs = lookup_commit_products([(c[0], c[1], p_[0], p_[1]) for c, p_ in zip(compressed, permuted)], k, bt_m, gm_m,
+                                 np.stack([rand_fr_array(rng, bf) for _ in compressed]) if compressed else np.zeros((0, bf, 4), np.uint64), backend=be)
+    owned += lzs
+    for pt in commit_all(params.g_lagrange.handle, zs + lzs):      # permutation products, then lookup products: one MSM batch, transcript order kept
         transcript.write_point(pt)
 
     lap("4_grand_products")

@@ -308,7 +308,7 @@ def main(argv=None):
     ap.add_argument("--perm-columns", type=int, default=16)
     ap.add_argument("--degree", type=int, default=5)
     ap.add_argument("--mode", choices=("prove", "opmix"), default="prove", help="prove: real create_proof over the sgx-shaped circuit (default); opmix: the hot-path call list over synthetic columns")
-    ap.add_argument("--inflight", type=int, default=2, help="proofs processed concurrently per step on one GPU (one context + HIP stream each)")
+    ap.add_argument("--inflight", type=int, default=3, help="proofs processed concurrently per step on one GPU (one context + HIP stream each)")
     ap.add_argument("--no-extras", action="store_true", help="skip the MSM 2^24 / NTT 2^22 microbenchmarks and the CPU baseline")
     args = ap.parse_args(argv)
 

@@ -181,10 +181,11 @@ TAU = 0x1C59A59B6CFF4308740943526ADE1D8C09F71B337A67269CC89586BCDD6DFCBA   # SRS
 class ProverWorkload:
     """keygen once, then one create_proof per step on a copy of the resident witness."""
 
-    def __init__(self, z, be, k, circuit):
+    def __init__(self, z, be, k, circuit, srs=None):
         self.z, self.be, self.k, self.n = z, be, k, 1 << k
         cs, fixed, asm, advice = circuit
-        self.params = z.kzg.ParamsKZG.setup(k, TAU, backend=be)
+        # one SRS for the process: the first context runs ParamsKZG::setup (fixed-base powers + EC-NTT), the others register the same points
+        self.params = z.kzg.ParamsKZG.setup(k, TAU, backend=be) if srs is None else z.kzg.ParamsKZG(k, srs.g_host, srs.g_lagrange_host, backend=be)
         self.pk = z.plonk.keygen(self.params, cs, fixed, asm)
         self.master = [be.to_device(a) for a in advice]
         self.work = [be.alloc(self.n * 32) for _ in advice]
@@ -342,7 +343,9 @@ def main(argv=None):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import sgx_shaped_circuit as sgx
         circuit = sgx.build(z, be, args.k)                      # one satisfying witness, shared by the contexts
-        wls = [ProverWorkload(z, b, args.k, circuit) for b in bes]
+        wls = []
+        for b in bes:
+            wls.append(ProverWorkload(z, b, args.k, circuit, srs=wls[0].params if wls else None))
     else:
         wls = [ProofWorkload(z, b, args.k, args.advice, args.fixed, args.lookups, args.perm_columns, args.degree) for b in bes]
     wl = wls[0]

@@ -160,3 +160,26 @@ def test_sgx_shaped_circuit_proof_verifies_gpu(gpu, orc, k):
     assert verifier.verify_proof(pk.vk, TAU, [], bytes(bad)) is False
     pk.release()
     params.release()
+
+
+GOLDEN_PROOF = "toy_proof_k6_seed7.bin"      # tools/gen_golden_proof.py (emulator run of this very prover; see tests/golden/README.md)
+
+
+def _golden():
+    import os
+    from conftest import ROOT
+    return open(os.path.join(ROOT, "tests", "golden", GOLDEN_PROOF), "rb").read()
+
+
+def test_golden_proof_is_accepted_and_reproduced_on_the_emulator(emu, orc):
+    import verifier
+    vk, instances, proof, _ = prove(emu, 6, seed=7)
+    assert proof == _golden()
+    assert verifier.verify_proof(vk, TAU, instances, _golden()) is True
+
+
+@pytest.mark.gpu
+def test_gpu_emits_the_golden_proof_bytes(gpu, orc):
+    """Same SRS, same witness, same seeded RNG, same transcript => the GPU kernels must emit byte-for-byte the proof the CPU-emulated
+    kernels emitted (every MSM / NTT / quotient / sort result is a canonical value): the north star's bit-exactness claim, end to end."""
+    assert prove(gpu, 6, seed=7)[2] == _golden()

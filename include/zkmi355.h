@@ -98,6 +98,13 @@ int zk_g1_fixed_base_mul_dev(zk_ctx* ctx, const void* scalars_dev, size_t n, voi
  * and out (DEVICE, 2^log_n x 64 B); omega, scale: HOST 32 B Montgomery, scale may be NULL.  One-time setup work. */
 int zk_g1_ntt_dev(zk_ctx* ctx, const void* g1_affine_in_dev, uint32_t log_n, const void* omega, const void* scale, void* g1_affine_out_dev);
 
+/* G1Affine::{from_bytes, to_bytes} in bulk — the point encoding of ParamsKZG::{read, write} (halo2_proofs src/poly/kzg/commitment.rs), i.e. of the SRS file
+ * params/kzg_bn254_{k}.srs that gen_srs caches (sgx_dcap_verifier.rs:799; bin/src/main.rs:227-231).  32 bytes per point: little-endian canonical x, y parity in
+ * bit `sign_bit`: 255 = halo2curves 0.3.1 (stack A; identity = all zero), 254 = halo2curves-axiom 0.5.2 (stack B; bit 255 = identity).  Decompression costs one
+ * square root per point ((x^3 + 3)^((p+1)/4)); *n_invalid counts encodings that are not curve points (then the call returns ZK_ERR_ARG). */
+int zk_g1_decompress_dev(zk_ctx* ctx, const void* bytes_dev, size_t n, uint32_t sign_bit, void* out_affine_dev, uint32_t* n_invalid);
+int zk_g1_compress_dev(zk_ctx* ctx, const void* affine_dev, size_t n, uint32_t sign_bit, void* bytes_dev);
+
 /* ---- NTT: replaces arithmetic::best_fft (G = Fr) and the EvaluationDomain wrappers --------- *
  * halo2_proofs src/arithmetic.rs best_fft(a, omega, log_n): in place, natural order in and out,
  * out[j] = sum_i a[i] * omega^(i*j).  omega: 32 B Montgomery.                                   */

@@ -237,6 +237,13 @@ class Backend:
     def g1_fixed_base_mul(self, scalars_dev, n: int, out_dev):
         self._ck(self.lib.zk_g1_fixed_base_mul_dev(self.ctx, C.c_void_p(_dptr(scalars_dev)), C.c_size_t(n), C.c_void_p(_dptr(out_dev))))
 
+    def g1_decompress_dev(self, bytes_dev, n: int, sign_bit: int, out_affine_dev) -> None:
+        bad = C.c_uint32()
+        self._ck(self.lib.zk_g1_decompress_dev(self.ctx, C.c_void_p(_dptr(bytes_dev)), C.c_size_t(n), C.c_uint32(sign_bit), C.c_void_p(_dptr(out_affine_dev)), C.byref(bad)))
+
+    def g1_compress_dev(self, affine_dev, n: int, sign_bit: int, bytes_dev) -> None:
+        self._ck(self.lib.zk_g1_compress_dev(self.ctx, C.c_void_p(_dptr(affine_dev)), C.c_size_t(n), C.c_uint32(sign_bit), C.c_void_p(_dptr(bytes_dev))))
+
     def g1_ntt_dev(self, in_dev, log_n: int, omega, scale, out_dev):
         w = self._fe(omega)
         sc = self._fe(scale) if scale is not None else None

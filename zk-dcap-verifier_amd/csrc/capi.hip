@@ -37,6 +37,8 @@ int lookup_permute(zk_ctx* ctx, const void* d_input, const void* d_table, uint32
                    const void* h_blind_table, void* d_out_input, void* d_out_table);
 int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* const* d_tables, size_t count, uint32_t k, uint32_t blinding_factors,
                          const void* h_blind_inputs, const void* h_blind_tables, void* const* d_out_inputs, void* const* d_out_tables);
+int g1_decompress(zk_ctx* ctx, const void* d_bytes, size_t n, uint32_t sign_bit, void* d_out_affine, uint32_t* n_bad_host);
+int g1_compress(zk_ctx* ctx, const void* d_affine, size_t n, uint32_t sign_bit, void* d_bytes);
 int g1_ntt(zk_ctx* ctx, const void* d_affine_in, uint32_t log_n, const void* omega_host, const void* scale_host, void* d_affine_out);
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
@@ -163,6 +165,9 @@ int zk_g1_sum_xyzz(const void* xyzz, size_t count, void* out) { if (!xyzz || !ou
 int zk_g1_fixed_base_mul_dev(zk_ctx* ctx, const void* s, size_t n, void* out) { ENTER; return g1_fixed_base_mul(ctx, s, n, out); }
 
 int zk_g1_ntt_dev(zk_ctx* ctx, const void* in, uint32_t log_n, const void* omega, const void* scale, void* out) { ENTER; return g1_ntt(ctx, in, log_n, omega, scale, out); }
+
+int zk_g1_decompress_dev(zk_ctx* ctx, const void* bytes_dev, size_t n, uint32_t sign_bit, void* out_affine_dev, uint32_t* n_invalid) { ENTER; return g1_decompress(ctx, bytes_dev, n, sign_bit, out_affine_dev, n_invalid); }
+int zk_g1_compress_dev(zk_ctx* ctx, const void* affine_dev, size_t n, uint32_t sign_bit, void* bytes_dev) { ENTER; return g1_compress(ctx, affine_dev, n, sign_bit, bytes_dev); }
 
 // ---- NTT / domain -------------------------------------------------------------------------------
 static int with_host_buffer(zk_ctx* ctx, void* host_in_out, size_t in_bytes, size_t buf_bytes, size_t out_bytes, void** dbuf) {

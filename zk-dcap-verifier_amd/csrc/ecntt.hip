@@ -100,3 +100,94 @@ int g1_ntt(zk_ctx* ctx, const void* d_affine_in, uint32_t log_n, const void* ome
 }
 
 }  // namespace zk
+
+// ---- G1 point encoding (ParamsKZG::{read, write}: the on-disk SRS params/kzg_bn254_{k}.srs) ---------------
+// halo2curves G1Affine::{to_bytes, from_bytes}: 32-byte little-endian canonical x with the parity of y in a flag bit —
+//   sign_bit = 255: halo2curves 0.3.1 (stack A, pasta-style; identity = all zero bytes)            [3P-MEM]
+//   sign_bit = 254: halo2curves-axiom 0.5.2 (stack B; bit 255 flags the identity) — the convention bin/assets/proof.bin shows (App. B)
+// from_bytes needs a square root per point: y = (x^3 + 3)^((p+1)/4) (p = 3 mod 4), 2^k of them per table when an SRS file is loaded.
+namespace zk {
+
+ZK_KERNEL void g1_decompress_kernel(const void* bytes, uint32_t n, uint32_t sign_bit, void* out_affine, uint32_t* n_bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u256 xc = load_u256(bytes, i);                       // canonical little-endian words
+    const uint32_t top = xc.v[7];
+    const bool sign = (top >> (sign_bit - 224)) & 1u;
+    const bool id_flag = sign_bit == 254 ? (top >> 31) & 1u : false;
+    xc.v[7] &= sign_bit == 254 ? 0x3fffffffu : 0x7fffffffu;
+    Affine o;
+    o.x = Fq::zero(); o.y = Fq::zero();
+    bool zero = true;
+#pragma unroll
+    for (int w = 0; w < 8; w++) zero = zero && xc.v[w] == 0;
+    if (id_flag || (zero && !sign && sign_bit == 255)) { store_affine(out_affine, i, o); return; }   // identity
+    bool lt = false;                                     // canonical: x < p
+    for (int w = 7; w >= 0; w--) { if (xc.v[w] != Fq::p(w)) { lt = xc.v[w] < Fq::p(w); break; } }
+    if (!lt) { atomicAdd(n_bad, 1u); store_affine(out_affine, i, o); return; }
+    const u256 x = Fq::to_mont(xc);
+    const uint64_t three[4] = BN254_FQ_THREE_M;
+    u256 b3;
+#pragma unroll
+    for (int w = 0; w < 8; w++) b3.v[w] = (uint32_t)(three[w >> 1] >> (32 * (w & 1)));
+    const u256 rhs = Fq::add(Fq::mul(Fq::sqr(x), x), b3);
+    u256 e;                                              // (p + 1) / 4
+    {
+        uint32_t carry = 1;
+        u256 t;
+        for (int w = 0; w < 8; w++) { const uint64_t sum = (uint64_t)Fq::p(w) + carry; t.v[w] = (uint32_t)sum; carry = (uint32_t)(sum >> 32); }
+        for (int w = 0; w < 8; w++) e.v[w] = (t.v[w] >> 2) | (w < 7 ? t.v[w + 1] << 30 : 0u);
+    }
+    u256 y = Fq::pow(rhs, e);
+    if (!Fq::eq(Fq::sqr(y), rhs)) { atomicAdd(n_bad, 1u); store_affine(out_affine, i, o); return; }   // x is not on the curve
+    const u256 yc = Fq::from_mont(y);
+    if ((bool)(yc.v[0] & 1u) != sign) y = Fq::neg(y);
+    o.x = x; o.y = y;
+    store_affine(out_affine, i, o);
+}
+ZK_KERNEL void g1_compress_kernel(const void* affine, uint32_t n, uint32_t sign_bit, void* bytes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Affine p = load_affine(affine, i);
+    u256 o = Fq::zero();
+    if (affine_is_identity(p)) {
+        if (sign_bit == 254) o.v[7] = 0x80000000u;
+    } else {
+        o = Fq::from_mont(p.x);
+        const u256 yc = Fq::from_mont(p.y);
+        o.v[7] |= (yc.v[0] & 1u) << (sign_bit - 224);
+    }
+    store_u256(bytes, i, o);
+}
+
+int g1_decompress(zk_ctx* ctx, const void* d_bytes, size_t n, uint32_t sign_bit, void* d_out_affine, uint32_t* n_bad_host) {
+    if (!d_bytes || !d_out_affine) return ctx->fail(ZK_ERR_ARG, "zk_g1_decompress_dev: null pointer");
+    if (sign_bit != 255 && sign_bit != 254) return ctx->fail(ZK_ERR_ARG, "zk_g1_decompress_dev: sign_bit must be 255 (halo2curves 0.3) or 254 (halo2curves-axiom 0.5)");
+    if (n == 0) { if (n_bad_host) *n_bad_host = 0; return ZK_OK; }
+    if (n >= (1ull << 31)) return ctx->fail(ZK_ERR_LIMIT, "zk_g1_decompress_dev: n too large");
+    ZK_HIP(ctx->ws_tmp.ensure(64));
+    uint32_t* d_bad = (uint32_t*)ctx->ws_tmp.p;
+    ZK_HIP(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    const int blk = ctx->tune.msm_block;
+    ZK_LAUNCH(g1_decompress_kernel, (uint32_t)((n + blk - 1) / blk), blk, 0, ctx->stream, d_bytes, (uint32_t)n, sign_bit, d_out_affine, d_bad);
+    ZK_CHECK_LAUNCH();
+    uint32_t bad = 0;
+    ZK_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_bad_host) *n_bad_host = bad;
+    if (bad) return ctx->fail(ZK_ERR_ARG, "zk_g1_decompress_dev: %u encodings are not points of y^2 = x^3 + 3 (non-canonical x or no square root)", bad);
+    return ZK_OK;
+}
+int g1_compress(zk_ctx* ctx, const void* d_affine, size_t n, uint32_t sign_bit, void* d_bytes) {
+    if (!d_bytes || !d_affine) return ctx->fail(ZK_ERR_ARG, "zk_g1_compress_dev: null pointer");
+    if (sign_bit != 255 && sign_bit != 254) return ctx->fail(ZK_ERR_ARG, "zk_g1_compress_dev: sign_bit must be 255 or 254");
+    if (n == 0) return ZK_OK;
+    if (n >= (1ull << 31)) return ctx->fail(ZK_ERR_LIMIT, "zk_g1_compress_dev: n too large");
+    const int blk = ctx->tune.msm_block;
+    ZK_LAUNCH(g1_compress_kernel, (uint32_t)((n + blk - 1) / blk), blk, 0, ctx->stream, d_affine, (uint32_t)n, sign_bit, d_bytes);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+}  // namespace zk

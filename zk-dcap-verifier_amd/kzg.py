@@ -22,6 +22,7 @@ class ParamsKZG:
         g = np.ascontiguousarray(g, dtype=np.uint64).reshape(-1, 8)
         g_lagrange = np.ascontiguousarray(g_lagrange, dtype=np.uint64).reshape(-1, 8)
         assert g.shape[0] == self.n and g_lagrange.shape[0] == self.n
+        self.g_host, self.g_lagrange_host = g, g_lagrange
         self.g = BasesHandle(self.backend, g)
         self.g_lagrange = BasesHandle(self.backend, g_lagrange)
 
@@ -48,6 +49,40 @@ class ParamsKZG:
         self.g, self.g_lagrange = BasesHandle(be, (dg, n)), BasesHandle(be, (dl, n))
         for d in (ds, dg, dl):
             d.free()
+        return self
+
+    # -- ParamsKZG::{write, read}: k (u32 LE) | n compressed g | n compressed g_lagrange | g2 | s_g2  [3P-MEM: SURVEY §8f n3, App. C.7] ----------
+    def write(self, g2: bytes = bytes(64), s_g2: bytes = bytes(64), sign_bit: int = 255) -> bytes:
+        """The params/kzg_bn254_{k}.srs byte stream.  The G2 points are opaque 64-byte blobs here (the prover never touches them)."""
+        be, n = self.backend, self.n
+        out = [int(self.k).to_bytes(4, "little")]
+        for host in (self.g_host, self.g_lagrange_host):
+            d, b = be.to_device(np.ascontiguousarray(host, dtype=np.uint64)), be.alloc(n * 32)
+            be.g1_compress_dev(d, n, sign_bit, b)
+            out.append(b.download((n, 4)).tobytes())
+            d.free(); b.free()
+        assert len(g2) == 64 and len(s_g2) == 64
+        return b"".join(out) + bytes(g2) + bytes(s_g2)
+
+    @classmethod
+    def read(cls, data: bytes, backend: Backend | None = None, sign_bit: int = 255) -> "ParamsKZG":
+        """ParamsKZG::read: decompress both tables on the GPU (one square root per point) and register them.  Raises ZkError when an
+        encoding is not a curve point.  `.g2` / `.s_g2` keep the 64-byte tails untouched."""
+        be = backend or default_backend()
+        k = int.from_bytes(data[:4], "little")
+        n = 1 << k
+        if k > 27 or len(data) != 4 + 2 * n * 32 + 128:
+            raise ValueError("not a kzg_bn254 SRS stream (k out of range or length mismatch)")
+        hosts = []
+        for t in range(2):
+            raw = np.frombuffer(data, dtype=np.uint64, count=n * 4, offset=4 + t * n * 32).reshape(n, 4)
+            b, d = be.to_device(raw), be.alloc(n * 64)
+            be.g1_decompress_dev(b, n, sign_bit, d)
+            hosts.append(d.download((n, 8)))
+            b.free(); d.free()
+        self = cls(k, hosts[0], hosts[1], backend=be)
+        self.g_host, self.g_lagrange_host = hosts
+        self.g2, self.s_g2 = data[-128:-64], data[-64:]
         return self
 
     def commit(self, poly: np.ndarray) -> np.ndarray:

@@ -183,3 +183,79 @@ def test_gpu_emits_the_golden_proof_bytes(gpu, orc):
     """Same SRS, same witness, same seeded RNG, same transcript => the GPU kernels must emit byte-for-byte the proof the CPU-emulated
     kernels emitted (every MSM / NTT / quotient / sort result is a canonical value): the north star's bit-exactness claim, end to end."""
     assert prove(gpu, 6, seed=7)[2] == _golden()
+
+
+def p256_shaped_circuit(k):
+    """The census SURVEY App. B reads off the reference's bin/assets/proof.bin (stack B, crates/p256-ecdsa at k = 18): 2 gate advice
+    columns (halo2-lib's vertical gate q * (a + b*c - d) over rotations 0..3) + 1 lookup advice column with a single-expression range
+    lookup, fixed = 2 selectors + 1 constants column + 1 table, ONE instance column carrying 15 public limbs (lib.rs:79-89), equality
+    on 2 advice + lookup advice + constants + instance => degree 4, 3 permutation sets, 3 h pieces."""
+    n = 1 << k
+    cs = plonk.ConstraintSystem(num_fixed_columns=4, num_advice_columns=3, num_instance_columns=1)
+    for c in (0, 1):
+        cs.create_gate(Fixed(c) * (Advice(c, 0) + Advice(c, 1) * Advice(c, 2) - Advice(c, 3)))
+    cs.lookup([(Advice(2), Fixed(3))])
+    for col in ((ADVICE, 0), (ADVICE, 1), (ADVICE, 2), (plonk.FIXED, 2), (INSTANCE, 0)):
+        cs.enable_equality(*col)
+    assert cs.degree() == 4
+    u = cs.usable_rows(k)
+    nblk = u // 4
+    cols = []
+    for c in (0, 1):
+        col = [0] * n
+        for t in range(nblk):
+            a, b, cc = 3 * t + c + 1, t + 2, 5 * t + 7
+            col[4 * t:4 * t + 4] = [a, b, cc, (a + b * cc) % R_MOD]
+        cols.append(col)
+    T = min(1 << 8, u)
+    look = [(7 * i + 3) % T for i in range(n)]
+    inst = [look[i] for i in range(15)]                              # 15 public values, each copied from the lookup advice column
+    q = [[1 if (i % 4 == 0 and i // 4 < nblk) else 0 for i in range(n)] for _ in range(2)]
+    const = [cols[0][1]] + [0] * (n - 1)                             # one constant, copied to the cell that must equal it
+    table = [i if i < T else 0 for i in range(n)]
+    asm = plonk.Assembly(cs, k)
+    for i in range(15):
+        asm.copy((INSTANCE, 0, i), (ADVICE, 2, i))
+    asm.copy((plonk.FIXED, 2, 0), (ADVICE, 0, 1))
+    asm.copy((ADVICE, 0, 5), (ADVICE, 1, 1))                         # b of block 1 in column 0 (= 3) ... must equal b of block 0 in column 1
+    cols[1][1] = cols[0][5]
+    cols[1][3] = (cols[1][0] + cols[1][1] * cols[1][2]) % R_MOD
+    return cs, q + [const, table], asm, [fr_mont_array(cols[0]), fr_mont_array(cols[1]), fr_mont_array(look)], [inst]
+
+
+def _p256_shape(be, k):
+    """configs[0] of BASELINE.json (crates/p256-ecdsa, CPU plumbing case) as a parity case: our prover, given a circuit with that census,
+    emits a proof with EXACTLY the layout of the reference's golden proof.bin — 13 G1 points, 32 scalars, 2 G1 points = 1504 bytes
+     — and verify_proof accepts it with the 15 instances (and rejects it with one of them changed)."""
+    import os
+    import verifier
+    from conftest import ROOT
+    cs, fixed, asm, advice, instances = p256_shaped_circuit(k)
+    params = z.kzg.ParamsKZG.setup(k, TAU, backend=be)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    tr = Blake2bWrite()
+    info = plonk.create_proof(params, pk, advice, instances, np.random.default_rng(18), tr)
+    proof = tr.finalize()
+    ref = bytes.fromhex(open(os.path.join(ROOT, "tests", "golden", "proof.bin")).read().strip()[2:])
+    assert len(proof) == len(ref) == 1504 and info["commitments"] == 13 + 2 and info["evals"] == 32
+    assert verifier.verify_proof(pk.vk, TAU, instances, proof) is True
+    wrong = [list(instances[0])]
+    wrong[0][14] = (wrong[0][14] + 1) % R_MOD
+    assert verifier.verify_proof(pk.vk, TAU, wrong, proof) is False
+    # same word classes as proof.bin: words 0-12 and 45-46 are curve points, words 13-44 canonical scalars
+    from zk_dcap_verifier_amd.transcript import point_from_bytes
+    for w in list(range(13)) + [45, 46]:
+        assert point_from_bytes(proof[32 * w:32 * w + 32]) is not None
+    for w in range(13, 45):
+        assert int.from_bytes(proof[32 * w:32 * w + 32], "little") < R_MOD
+    pk.release()
+    params.release()
+
+
+def test_p256_ecdsa_shaped_proof_has_the_layout_of_proof_bin_emulated(emu, orc):
+    _p256_shape(emu, 7)
+
+
+@pytest.mark.gpu
+def test_p256_ecdsa_shaped_proof_has_the_layout_of_proof_bin_gpu(gpu, orc):
+    _p256_shape(gpu, 12)

@@ -505,21 +505,14 @@ ZK_KERNEL void lpb_hist_kernel(const uint2* keys, uint32_t u, uint32_t pass, uin
     __syncthreads();
     ghist[((size_t)s * nwg + blockIdx.x) * 256 + tid] = lh[tid];
 }
-ZK_KERNEL void lpb_scatter_kernel(const uint2* keys_in, const uint32_t* idx_in, uint2* keys_out, uint32_t* idx_out, uint32_t u, uint32_t pass,
-                                  const uint32_t* ghist, uint32_t nwg) {
-    __shared__ uint16_t cnt[FS_T * FS_PAD];
-    __shared__ uint32_t gbase[256];
+// gbase[s][wg][bin] <- pairs of sort s with a smaller digit anywhere + pairs with this digit in earlier tiles (in place on ghist):
+// one workgroup per sort, thread = bin, so the scatter workgroups read their 256 bases instead of each summing nwg histogram rows
+ZK_KERNEL void lpb_offsets_kernel(uint32_t* ghist, uint32_t nwg) {
     __shared__ uint32_t scan[256];
-    const uint32_t s = blockIdx.y, tid = threadIdx.x, wg = blockIdx.x, base = wg * FS_TILE;
-    keys_in += (size_t)s * u; idx_in += (size_t)s * u; keys_out += (size_t)s * u; idx_out += (size_t)s * u;
-    ghist += (size_t)s * nwg * 256;
-    for (uint32_t d = 0; d < 256; d++) cnt[tid * FS_PAD + d] = 0;
-    uint32_t before = 0, total = 0;
-    for (uint32_t w = 0; w < nwg; w++) {
-        const uint32_t c = ghist[(size_t)w * 256 + tid];
-        if (w < wg) before += c;
-        total += c;
-    }
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    uint32_t* h = ghist + (size_t)s * nwg * 256;
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < nwg; w++) total += h[(size_t)w * 256 + tid];
     scan[tid] = total;
     __syncthreads();
     for (uint32_t d = 1; d < 256; d <<= 1) {
@@ -528,7 +521,26 @@ ZK_KERNEL void lpb_scatter_kernel(const uint2* keys_in, const uint32_t* idx_in, 
         scan[tid] += add;
         __syncthreads();
     }
-    gbase[tid] = scan[tid] - total + before;
+    uint32_t run = scan[tid] - total;
+    for (uint32_t w = 0; w < nwg; w++) {
+        const uint32_t c = h[(size_t)w * 256 + tid];
+        h[(size_t)w * 256 + tid] = run;
+        run += c;
+    }
+}
+ZK_KERNEL void lpb_scatter_kernel(const uint2* keys_in, const uint32_t* idx_in, uint2* keys_out, uint32_t* idx_out, uint32_t u, uint32_t pass,
+                                  const uint32_t* gbase_all, uint32_t nwg) {
+    __shared__ __attribute__((aligned(16))) uint16_t cnt[FS_T * FS_PAD];
+    __shared__ uint32_t gbase[256];
+    const uint32_t s = blockIdx.y, tid = threadIdx.x, wg = blockIdx.x, base = wg * FS_TILE;
+    keys_in += (size_t)s * u; idx_in += (size_t)s * u; keys_out += (size_t)s * u; idx_out += (size_t)s * u;
+    {   // clear the count matrix with 16-byte stores (FS_T * FS_PAD * 2 bytes = a whole number of uint4)
+        uint4* c4 = reinterpret_cast<uint4*>(cnt);
+        constexpr uint32_t n4 = FS_T * FS_PAD * 2 / 16;
+        for (uint32_t q = tid; q < n4; q += FS_T) c4[q] = make_uint4(0, 0, 0, 0);
+    }
+    gbase[tid] = gbase_all[((size_t)s * nwg + wg) * 256 + tid];
+    __syncthreads();
     uint2 k[FS_E];
     uint32_t v[FS_E];
     uint16_t rl[FS_E];
@@ -745,6 +757,8 @@ int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* c
     uint32_t *iin = a.idx_a, *iout = a.idx_b;
     for (uint32_t p = 0; p < passes; p++) {
         ZK_LAUNCH(lpb_hist_kernel, dim3(nwg, S), FS_T, 0, st, (const uint2*)kin, u, p, a.ghist, nwg);
+        ZK_CHECK_LAUNCH();
+        ZK_LAUNCH(lpb_offsets_kernel, S, 256, 0, st, a.ghist, nwg);
         ZK_CHECK_LAUNCH();
         ZK_LAUNCH(lpb_scatter_kernel, dim3(nwg, S), FS_T, 0, st, (const uint2*)kin, (const uint32_t*)iin, kout, iout, u, p, (const uint32_t*)a.ghist, nwg);
         ZK_CHECK_LAUNCH();

@@ -63,16 +63,12 @@ def _srs_roundtrip(be, k):
         poly = np.ascontiguousarray(params.g_host[:, :4] & np.uint64((1 << 60) - 1))
         assert (back.commit_lagrange(poly) == params.commit_lagrange(poly)).all()
         back.release()
+    # a stream whose FIRST point is replaced by an evaluation word of proof.bin that is not an x coordinate must be refused
+    bad_x = [w for w in _proof_bin_words()[13:45] if pow((int.from_bytes(w, "little") ** 3 + 3) % P_MOD, (P_MOD - 1) // 2, P_MOD) != 1][0]
     tampered = bytearray(params.write())
-    tampered[4 + 32 * 2] ^= 1                                        # another x: on the curve with probability 1/2 only ...
-    tampered[4 + 32 * 3 + 5] ^= 0x10
-    tampered[4 + 32 * 5 + 9] ^= 0x44                                 # ... so three flips are refused except with probability 1/8
-    try:
+    tampered[4:36] = bad_x
+    with pytest.raises(z.ZkError):
         z.kzg.ParamsKZG.read(bytes(tampered), backend=be)
-        accepted = True
-    except z.ZkError:
-        accepted = False
-    assert not accepted or True                                      # (statistical: recorded, not asserted)
     with pytest.raises(ValueError):
         z.kzg.ParamsKZG.read(params.write()[:-1], backend=be)
     params.release()

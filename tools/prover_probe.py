@@ -17,7 +17,10 @@ def main():
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 19
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     be = z.Backend(0)
-    out = {"k": k}
+    tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("ZK_TUNE", "").split(",") if kv}
+    if tune:
+        be.tune(**tune)
+    out = {"k": k, "tune": tune}
     t = time.time(); cs, fixed, asm, advice = sc.build(z, be, k); out["build_witness_s"] = round(time.time() - t, 3)
     t = time.time(); params = z.kzg.ParamsKZG.setup(k, TAU, backend=be); out["srs_setup_s"] = round(time.time() - t, 3)
     t = time.time(); pk = z.plonk.keygen(params, cs, fixed, asm); out["keygen_s"] = round(time.time() - t, 3)

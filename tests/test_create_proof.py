@@ -148,7 +148,7 @@ def test_create_proof_negative_controls_gpu(gpu, orc, what):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [8, 12])
+@pytest.mark.parametrize("k", [8, 12, 17])
 def test_sgx_shaped_circuit_proof_verifies_gpu(gpu, orc, k):
     """The circuit shape bench.py proves at k = 19 (25 advice, 18 fixed, 11 lookups of 4-5 expressions, 16 equality columns,
     24 gates, degree 5; tools/sgx_shaped_circuit.py) at a size the Python verifier handles in a second."""

@@ -52,3 +52,34 @@ def test_emulated_eval_phase(emu, orc, pyref, n, count):
 @pytest.mark.parametrize("n,count", [(1, 1), (3, 2), (1 << 12, 5), (100003, 7), (1 << 19, 4), ((1 << 20) + 4099, 2)])   # the last one: kate_division carries over two rounds of workgroups
 def test_gpu_eval_phase(gpu, orc, pyref, n, count):
     _check(gpu, orc, pyref, n, count, seed=n)
+
+
+def _check_lincomb(be, orc, pyref, n, count, seed):
+    """zk_fr_lincomb_dev (SHPLONK's polynomial combinations): out = sum_j s_j * p_j, a scalar equal to one (skips its product), output aliasing an input"""
+    R = pyref.R
+    polys = [pc.rand_fr(orc, pyref, n, seed + i) for i in range(count)]
+    sc = pc.rand_fr(orc, pyref, count, seed + 50)
+    sc[0] = orc.fr_from_ints([1])[0]
+    want_ints = [0] * n
+    si = orc.fr_to_ints(sc)
+    for pj, s_ in zip(polys, si):
+        want_ints = [(w + s_ * v) % R for w, v in zip(want_ints, orc.fr_to_ints(pj))]
+    want = orc.fr_from_ints(want_ints)
+    d = [be.to_device(c) for c in polys]
+    out = be.alloc(n * 32)
+    be.fr_lincomb_dev(d, sc, n, out)
+    assert (out.download((n, 4)) == want).all()
+    be.fr_lincomb_dev(d, sc, n, d[-1])                                   # in place on the last input
+    assert (d[-1].download((n, 4)) == want).all()
+    for dd in d + [out]:
+        dd.free()
+
+
+def test_emulated_lincomb(emu, orc, pyref):
+    _check_lincomb(emu, orc, pyref, 777, 4, seed=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,count", [(1, 1), (100003, 3), (1 << 18, 9)])
+def test_gpu_lincomb(gpu, orc, pyref, n, count):
+    _check_lincomb(gpu, orc, pyref, n, count, seed=n % 1000)

@@ -18,6 +18,7 @@ Single circuit instance per proof (the reference passes `&[circuit]`); no user c
 """
 from __future__ import annotations
 
+import time
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -39,8 +40,19 @@ def rotate_omega(x: int, rot: int, k: int) -> int:
 def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances: Sequence[Sequence[int]], rng: np.random.Generator, transcript,
                  timings: Optional[dict] = None) -> dict:
     """advice: cs.num_advice_columns columns of n rows — (n, 4) uint64 Montgomery host arrays or device buffers; rows past
-    `usable_rows` are overwritten with blinding (device buffers are modified in place).  instances: canonical ints per instance
-    column.  Writes the proof into `transcript`; returns phase timings-free bookkeeping (commitment count etc.) for tests."""
+    `usable_rows` are overwritten with blinding and device buffers are consumed (they hold coefficients afterwards).  instances:
+    canonical ints per instance column.  Writes the proof into `transcript` and returns bookkeeping for tests / benches
+    ({"commitments", "evals", "h_eval"}); `timings`, when given, receives wall milliseconds per phase.  Device buffers allocated
+    along the way are released (back to the backend's pool) on success and on failure alike."""
+    owned: List = []
+    try:
+        return _create_proof(params, pk, advice, instances, rng, transcript, timings, owned)
+    finally:
+        for d in owned:
+            d.free()
+
+
+def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned) -> dict:
     be, cs, k, n = pk.backend, pk.vk.cs, params.k, params.n
     dom = pk.domain
     ek, en = dom.extended_k, dom.extended_n
@@ -48,15 +60,13 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     usable = n - (bf + 1)
     L = len(cs.lookups)
     assert len(advice) == cs.num_advice_columns and len(instances) == cs.num_instance_columns
-    owned = []                                                   # device buffers this proof allocated
-    import time as _time
-    _t = [_time.perf_counter()]
+    clock = [time.perf_counter()]
 
     def lap(name):
         if timings is not None:
-            now = _time.perf_counter()
-            timings[name] = timings.get(name, 0.0) + (now - _t[0]) * 1e3
-            _t[0] = now
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (now - clock[0]) * 1e3
+            clock[0] = now
 
     def dev(nbytes):
         d = be.alloc(nbytes)
@@ -233,7 +243,4 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     queries = q_adv + q_perm_a + list(reversed(q_perm_last)) + q_lk + q_fix + q_sigma + [q_h, q_rand]
     ProverSHPLONK(params).create_proof(transcript, queries)
     lap("9_shplonk")
-    info = {"commitments": nA + 2 * L + nZ + L + 1 + n_pieces + 2, "evals": len(evals) - 1, "h_eval": evals[-1]}
-    for d in owned:
-        d.free()
-    return info
+    return {"commitments": nA + 2 * L + nZ + L + 1 + n_pieces + 2, "evals": len(evals) - 1, "h_eval": evals[-1]}

@@ -28,14 +28,15 @@ def _golden():
 
 
 def toy_circuit(k, with_lookup=True, tamper=None):
-    """2 gates (one with a rotation), copy constraints over 3 advice + 1 instance column (2 permutation sets at degree 5),
+    """3 gates (one with a rotation, one querying the instance column), copy constraints over 3 advice + 1 instance column (2 permutation sets at degree 5),
     one lookup whose input is a product expression.  Returns (cs, fixed columns, assembly, advice columns, instances)."""
     n = 1 << k
-    cs = plonk.ConstraintSystem(num_fixed_columns=3, num_advice_columns=3, num_instance_columns=1)
+    cs = plonk.ConstraintSystem(num_fixed_columns=4, num_advice_columns=3, num_instance_columns=1)
     a, b, c = Advice(0), Advice(1), Advice(2)
     q, q2, t = Fixed(0), Fixed(1), Fixed(2)
     cs.create_gate(q * (a * b - c))
     cs.create_gate(q2 * (Advice(0, 1) - a - 1))
+    cs.create_gate(Fixed(3) * (c - Instance(0)))                     # an instance QUERY inside a gate (the verifier evaluates it itself)
     if with_lookup:
         cs.lookup([(q * a, t)])
     for col in ((ADVICE, 0), (ADVICE, 1), (ADVICE, 2), (INSTANCE, 0)):
@@ -65,7 +66,8 @@ def toy_circuit(k, with_lookup=True, tamper=None):
         Q2[8] = Q2[9] = Q2[10] = 0
     elif tamper == "instance":
         inst = [C[0], (C[3] + 1) % R_MOD]
-    return cs, [Q, Q2, T], asm, [fr_mont_array(A), fr_mont_array(B), fr_mont_array(C)], [inst]
+    QI = [1] + [0] * (n - 1)                                         # row 0: c[0] == instance[0]
+    return cs, [Q, Q2, T, QI], asm, [fr_mont_array(A), fr_mont_array(B), fr_mont_array(C)], [inst]
 
 
 def prove(be, k, seed=1, **kw):

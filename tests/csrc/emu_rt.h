@@ -1,8 +1,11 @@
 // TEST-ONLY kernel emulator: just enough of the HIP surface to run the product's kernel sources
-// on CPU threads (one pthread per work-item of a workgroup, workgroups run one after another).
+// on the CPU: every work-item of a workgroup is a user-level context (ucontext fiber) on the calling OS
+// thread, __syncthreads() yields to a round-robin scheduler, workgroups run one after another.
+// (One pthread per work-item with pthread barriers spent the whole test time in futex calls.)
 // Used by tests/csrc/libzkmi355_emu.so for `pytest -m "not gpu"`; never part of the product.
 #pragma once
 #include <pthread.h>
+#include <ucontext.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,9 +31,20 @@ static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 #define ZK_KERNEL
 
 inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
-inline thread_local pthread_barrier_t* emu_barrier = nullptr;
 inline thread_local unsigned char* emu_smem = nullptr;
-static inline void __syncthreads() { pthread_barrier_wait(emu_barrier); }
+struct EmuSched {
+    ucontext_t main;
+    std::vector<ucontext_t> ctx;
+    std::vector<char> done;
+    std::vector<char> stack_mem;     // nt stacks, grow-only
+    unsigned cur = 0;
+    void (*run)(void*) = nullptr;
+    void* arg = nullptr;
+    dim3 grid;
+};
+inline thread_local EmuSched* emu_sched = nullptr;
+// barrier = hand the OS thread back to the scheduler; it resumes this work-item after every other one has run up to its own barrier
+static inline void __syncthreads() { EmuSched* s = emu_sched; swapcontext(&s->ctx[s->cur], &s->main); }
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 template <class T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
@@ -72,50 +86,57 @@ static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return 0; }
 static inline hipError_t hipHostUnregister(void*) { return 0; }
 
 // ---- launcher ------------------------------------------------------------------------------
-template <class F>
-struct EmuJob {
-    F* f;
-    dim3 grid, block;
-    unsigned tid;
-    pthread_barrier_t* bar;
-    unsigned char* smem;
-};
-template <class F>
-static void* emu_thread(void* arg) {
-    EmuJob<F>* j = static_cast<EmuJob<F>*>(arg);
-    blockDim = j->block; gridDim = j->grid; emu_barrier = j->bar; emu_smem = j->smem;
-    threadIdx = dim3(j->tid % j->block.x, j->tid / j->block.x, 0);
-    for (unsigned by = 0; by < j->grid.y; by++)
-        for (unsigned bx = 0; bx < j->grid.x; bx++) {
+static void emu_fiber_main() {
+    EmuSched* s = emu_sched;
+    const unsigned me = s->cur;
+    for (unsigned by = 0; by < s->grid.y; by++)
+        for (unsigned bx = 0; bx < s->grid.x; bx++) {
             blockIdx = dim3(bx, by, 0);
-            (*j->f)();
-            pthread_barrier_wait(j->bar);  // workgroups run one after another (static __shared__ reuse)
+            s->run(s->arg);
+            __syncthreads();                      // workgroups run one after another (static __shared__ reuse)
         }
-    return nullptr;
+    s->done[me] = 1;
+    swapcontext(&s->ctx[me], &s->main);           // never resumed
 }
 inline std::mutex& emu_launch_mutex() { static std::mutex m; return m; }
 template <class F>
 static inline void emu_launch(dim3 grid, dim3 block, size_t smem_bytes, F f) {
-    unsigned nt = block.x * block.y;
+    const unsigned nt = block.x * block.y;
     if (nt == 0 || grid.x == 0 || grid.y == 0) return;
     // `__shared__` is a process-wide static here, so kernels of different contexts must not overlap
     std::lock_guard<std::mutex> serialise(emu_launch_mutex());
-    pthread_barrier_t bar;
-    pthread_barrier_init(&bar, nullptr, nt);
+    static thread_local EmuSched sched;
+    EmuSched* s = &sched;
+    constexpr size_t STACK = 256 * 1024;
+    if (s->stack_mem.size() < (size_t)nt * STACK) s->stack_mem.resize((size_t)nt * STACK);
+    s->ctx.resize(nt);
+    s->done.assign(nt, 0);
+    s->run = [](void* c) { (*static_cast<F*>(c))(); };
+    s->arg = &f;
+    s->grid = grid;
     void* smem = nullptr;
     if (posix_memalign(&smem, 256, smem_bytes ? smem_bytes : 256)) abort();
-    std::vector<pthread_t> th(nt);
-    std::vector<EmuJob<F>> jobs(nt);
-    pthread_attr_t at;
-    pthread_attr_init(&at);
-    pthread_attr_setstacksize(&at, 256 * 1024);
+    emu_sched = s;
+    emu_smem = static_cast<unsigned char*>(smem);
+    blockDim = block; gridDim = grid;
     for (unsigned t = 0; t < nt; t++) {
-        jobs[t] = EmuJob<F>{&f, grid, block, t, &bar, static_cast<unsigned char*>(smem)};
-        if (pthread_create(&th[t], &at, emu_thread<F>, &jobs[t])) abort();
+        getcontext(&s->ctx[t]);
+        s->ctx[t].uc_stack.ss_sp = s->stack_mem.data() + (size_t)t * STACK;
+        s->ctx[t].uc_stack.ss_size = STACK;
+        s->ctx[t].uc_link = nullptr;
+        makecontext(&s->ctx[t], emu_fiber_main, 0);
     }
-    for (unsigned t = 0; t < nt; t++) pthread_join(th[t], nullptr);
-    pthread_attr_destroy(&at);
-    pthread_barrier_destroy(&bar);
+    unsigned remaining = nt;
+    while (remaining) {
+        for (unsigned t = 0; t < nt; t++) {
+            if (s->done[t]) continue;
+            s->cur = t;
+            threadIdx = dim3(t % block.x, t / block.x, 0);
+            swapcontext(&s->main, &s->ctx[t]);
+            if (s->done[t]) remaining--;
+        }
+    }
+    emu_sched = nullptr;
     free(smem);
 }
 #define ZK_LAUNCH(kern, grid, block, smem, stream, ...) \

@@ -149,9 +149,7 @@ def test_create_proof_negative_controls_gpu(gpu, orc, what):
     _rejects(gpu, 9, what)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("k", [8, 12, 17])
-def test_sgx_shaped_circuit_proof_verifies_gpu(gpu, orc, k):
+def _sgx_shaped(be, k):
     """The circuit shape bench.py proves at k = 19 (25 advice, 18 fixed, 11 lookups of 4-5 expressions, 16 equality columns,
     24 gates, degree 5; tools/sgx_shaped_circuit.py) at a size the Python verifier handles in a second."""
     import os, sys
@@ -159,6 +157,7 @@ def test_sgx_shaped_circuit_proof_verifies_gpu(gpu, orc, k):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import sgx_shaped_circuit as sc
     import verifier
+    gpu = be
     cs, fixed, asm, advice = sc.build(z, gpu, k)
     params = z.kzg.ParamsKZG.setup(k, TAU, backend=gpu)
     pk = plonk.keygen(params, cs, fixed, asm)
@@ -172,6 +171,16 @@ def test_sgx_shaped_circuit_proof_verifies_gpu(gpu, orc, k):
     assert verifier.verify_proof(pk.vk, TAU, [], bytes(bad)) is False
     pk.release()
     params.release()
+
+
+def test_sgx_shaped_circuit_proof_verifies_emulated(emu, orc):
+    _sgx_shaped(emu, 6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [8, 12, 17])
+def test_sgx_shaped_circuit_proof_verifies_gpu(gpu, orc, k):
+    _sgx_shaped(gpu, k)
 
 
 def test_golden_proof_is_accepted_and_reproduced_on_the_emulator(emu, orc):

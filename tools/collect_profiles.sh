@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun): one profiling session of the default bench.  usage: tools/collect_profiles.sh <tag>   e.g. run32
+# Counter passes are separate rocprofv3 runs (FETCH_SIZE and WRITE_SIZE do not fit one pass; PMC never together with trace domains other than --kernel-trace).
+set -u
+TAG=$1
+export TMPDIR=/tmp
+O=gpurun_out/$TAG
+mkdir -p $O
+python bench.py > $O/${TAG}_bench_default.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --steps 3 --warmup 1 --no-extras > $O/${TAG}_bench_under_rocprofv3.json 2>> $O/bench.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $O/lds -o l -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
+python tools/prover_probe.py 19 3 > $O/${TAG}_prover_probe_k19.json 2>> $O/bench.err
+python tools/prover_probe.py 21 1 > $O/${TAG}_prover_probe_k21.json 2>> $O/bench.err
+grep -h '^{' $O/${TAG}_bench_default.json | cut -c1-330

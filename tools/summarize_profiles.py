@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Turn one profiling session's rocprofv3 CSVs (gpurun_out/<dir>) into the summaries committed under profiles/r01/.
+Session layout (see tools/collect_profiles.sh): <dir>/runNN_bench_default.json, runNN_bench_under_rocprofv3.json,
+stats/s_kernel_{stats,trace}.csv, fetch/f_counter_collection.csv, write/w_counter_collection.csv, lds/l_counter_collection.csv"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+
+def short(n):
+    return re.sub(r"\(.*", "", n).replace("zk::", "")
+
+
+def last_json_line(path):
+    return json.loads([l for l in open(path) if l.startswith("{")][-1])
+
+
+def main():
+    O, tag = sys.argv[1], sys.argv[2]
+    P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01")
+    b = last_json_line(f"{O}/{tag}_bench_under_rocprofv3.json")
+    rows = list(csv.DictReader(open(f"{O}/stats/s_kernel_trace.csv")))
+    acc = sorted((r for r in rows if "msm_accumulate" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+    nl = b["roofline"]["launches"]
+    timed = acc[-nl:]
+    avg = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in timed) / len(timed) / 1e6
+    inflight = b["extra"]["proofs_in_flight"]
+    with open(f"{P}/{tag}_rocprofv3_kernel_stats_bench_steps3_warmup1_noextras_inflight{inflight}.csv", "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-extras   (default mode: real create_proof)\n")
+        f.write(f"# the table covers the WHOLE process (SRS setup with the EC-NTT, keygen, warm-up step, 3 timed steps); msm_accumulate_kernel: {len(acc)} launches in the process,\n")
+        f.write(f"# the last {nl} of them are the timed region: average {avg:.4f} ms per launch from this trace vs {b['roofline']['avg_launch_ms']:.4f} ms from the in-bench HIP events of the same run ({tag}_bench_under_rocprofv3.json)\n")
+        f.write(open(f"{O}/stats/s_kernel_stats.csv").read())
+    print("msm_accumulate timed-region avg (trace) %.4f ms vs HIP events %.4f ms" % (avg, b["roofline"]["avg_launch_ms"]))
+
+    def agg(path, counter):
+        d = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                k = short(r["Kernel_Name"])
+                d[k][0] += 1
+                d[k][1] += float(r["Counter_Value"])
+        return d
+    fe, wr = agg(f"{O}/fetch/f_counter_collection.csv", "FETCH_SIZE"), agg(f"{O}/write/w_counter_collection.csv", "WRITE_SIZE")
+    keep = ["msm_accumulate_kernel", "quotient_kernel", "ntt_strided_pass_kernel", "ntt_final_pass_kernel", "msm_hist_kernel", "msm_scatter_kernel", "lpb_scatter_kernel",
+            "lpb_hist_kernel", "msm_merge_kernel", "msm_rowcol_kernel", "pe_eval_partial_kernel", "pe_lincomb_kernel", "gp_batch_divide_kernel"]
+    traffic = {}
+    with open(f"{P}/{tag}_rocprofv3_pmc_hbm_traffic.csv", "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras  (one real proof + setup/keygen)\n")
+        f.write("# bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024: the gfx950 correction of MI355X_MICROARCH.md (HBM section); launches include keygen launches of the same kernel\n")
+        f.write("kernel,launches,FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,hbm_bytes_per_launch\n")
+        for k in keep:
+            if k in fe:
+                n = fe[k][0]
+                by = (2 * fe[k][1] + wr.get(k, [0, 0])[1]) * 1024 / n
+                traffic[k] = by
+                f.write(f"{k},{n},{fe[k][1]:.1f},{wr.get(k, [0, 0])[1]:.1f},{by:.0f}\n")
+    tj = {"source": f"profiles/r01/{tag}_rocprofv3_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 --inflight 1 --no-extras; "
+                    "bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 per the gfx950 correction of MI355X_MICROARCH.md HBM section)",
+          "msm_accumulate_bytes_per_launch": round(traffic["msm_accumulate_kernel"]), "quotient_bytes_per_launch": round(traffic["quotient_kernel"]),
+          "ntt_strided_pass_bytes_per_launch": round(traffic["ntt_strided_pass_kernel"]), "ntt_final_pass_bytes_per_launch": round(traffic["ntt_final_pass_kernel"])}
+    json.dump(tj, open(os.path.join(os.path.dirname(P), "traffic.json"), "w"), indent=1)
+    d = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    for r in csv.DictReader(open(f"{O}/lds/l_counter_collection.csv")):
+        k = short(r["Kernel_Name"])
+        d[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_WAVE_CYCLES":
+            cnt[k] += 1
+    with open(f"{P}/{tag}_rocprofv3_pmc_lds_bucket_pass.csv", "w") as f:
+        f.write("# rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras\n")
+        f.write("# LDS has no hit rate; what the counters give for the LDS-staged bucket pass (msm_hist / msm_scatter: counting sort of (scalar, window) pairs on LDS atomics) and for the\n")
+        f.write("# lookup radix sort is the share of LDS cycles lost to bank conflicts: conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (both in LDS-array cycles), and LDS busy share of wave cycles\n")
+        f.write("kernel,launches,SQ_INSTS_LDS,SQ_LDS_IDX_ACTIVE,SQ_LDS_BANK_CONFLICT,conflict_frac,lds_active_over_wave_cycles\n")
+        for k in ["msm_hist_kernel", "msm_scatter_kernel", "msm_rowcol_kernel", "lpb_hist_kernel", "lpb_scatter_kernel", "ntt_strided_pass_kernel", "ntt_final_pass_kernel", "quotient_kernel"]:
+            if k in d:
+                v = d[k]
+                act = v["SQ_LDS_IDX_ACTIVE"] or 1
+                f.write(f"{k},{cnt[k]},{v['SQ_INSTS_LDS']:.0f},{v['SQ_LDS_IDX_ACTIVE']:.0f},{v['SQ_LDS_BANK_CONFLICT']:.0f},{v['SQ_LDS_BANK_CONFLICT'] / act:.4f},"
+                        f"{v['SQ_LDS_IDX_ACTIVE'] / (v['SQ_WAVE_CYCLES'] or 1):.4f}\n")
+    for name in (f"{tag}_bench_default.json", f"{tag}_bench_under_rocprofv3.json"):
+        open(f"{P}/{name}", "w").write(json.dumps(last_json_line(f"{O}/{name}")) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ def main():
     tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("ZK_TUNE", "").split(",") if kv}
     if tune:
         be.tune(**tune)
-    out = {"k": k, "tune": tune}
+    out = {"k": k, "tune": tune, "host_witness": os.environ.get("ZK_HOST_WITNESS") == "1"}
     t = time.time(); cs, fixed, asm, advice = sc.build(z, be, k); out["build_witness_s"] = round(time.time() - t, 3)
     t = time.time(); params = z.kzg.ParamsKZG.setup(k, TAU, backend=be); out["srs_setup_s"] = round(time.time() - t, 3)
     t = time.time(); pk = z.plonk.keygen(params, cs, fixed, asm); out["keygen_s"] = round(time.time() - t, 3)
@@ -30,13 +30,15 @@ def main():
     work = [be.alloc(n * 32) for _ in advice]
     times, proof = [], None
     for r in range(reps + 1):
-        for w, m in zip(work, master):
-            w.copy_from(m)
+        host_witness = os.environ.get("ZK_HOST_WITNESS") == "1"      # PCIe-inclusive: hand create_proof the host columns (as the Rust boundary would)
+        if not host_witness:
+            for w, m in zip(work, master):
+                w.copy_from(m)
         be.sync()
         t = time.time()
         tr = Blake2bWrite()
         tm = {}
-        info = z.plonk.create_proof(params, pk, work, [], np.random.default_rng(r), tr, timings=tm)
+        info = z.plonk.create_proof(params, pk, advice if host_witness else work, [], np.random.default_rng(r), tr, timings=tm)
         proof = tr.finalize()
         times.append(time.time() - t)
     out["create_proof_ms"] = [round(x * 1e3, 2) for x in times]

@@ -178,7 +178,7 @@ def test_sgx_shaped_circuit_proof_verifies_emulated(emu, orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [8, 12, 17])
+@pytest.mark.parametrize("k", [8, 12, 17, 19, 21])      # 19: BASELINE configs[1] at full size; 21: the size of configs[4]
 def test_sgx_shaped_circuit_proof_verifies_gpu(gpu, orc, k):
     _sgx_shaped(gpu, k)
 

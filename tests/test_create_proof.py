@@ -70,8 +70,23 @@ def toy_circuit(k, with_lookup=True, tamper=None):
     return cs, [Q, Q2, T, QI], asm, [fr_mont_array(A), fr_mont_array(B), fr_mont_array(C)], [inst]
 
 
+def test_mock_prover_mirrors_the_first_step_of_the_reference_test():
+    """`MockProver::run(k, &circuit, vec![]).unwrap().assert_satisfied()` (sgx_dcap_verifier.rs:790-794): the witness of the toy circuit
+    satisfies every gate, lookup and copy constraint; each tampered witness is reported for the right reason."""
+    cs, fixed, asm, advice, instances = toy_circuit(5)
+    plonk.MockProver.run(5, cs, fixed, advice, instances, asm).assert_satisfied()
+    for what, needle in (("gate", "gate 0"), ("copy", "copy constraint"), ("lookup", "lookup 0"), ("instance", "copy constraint")):
+        cs, fixed, asm, advice, instances = toy_circuit(5, tamper=what)
+        with pytest.raises(plonk.VerifyFailure) as e:
+            plonk.MockProver.run(5, cs, fixed, advice, instances, asm).assert_satisfied()
+        assert needle in str(e.value), (what, str(e.value))
+
+
 def prove(be, k, seed=1, **kw):
+    """the reference test's sequence (sgx_dcap_verifier.rs:790-823): MockProver, gen_srs, keygen_vk/pk, create_proof"""
     cs, fixed, asm, advice, instances = toy_circuit(k, **kw)
+    if k <= 10 and not kw.get("tamper"):
+        plonk.MockProver.run(k, cs, fixed, advice, instances, asm).assert_satisfied()
     params = z.kzg.ParamsKZG.setup(k, TAU, backend=be)
     pk = plonk.keygen(params, cs, fixed, asm)
     tr = Blake2bWrite()

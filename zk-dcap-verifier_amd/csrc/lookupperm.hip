@@ -108,103 +108,7 @@ ZK_KERNEL void lp_scatter_kernel(const void* canon, const uint32_t* idx_in, uint
 // across tiles from the workgroup-major global histogram (each workgroup sums the rows of the workgroups before it).
 constexpr uint32_t FS_T = 256, FS_E = 16, FS_TILE = FS_T * FS_E, FS_PAD = 258;
 
-ZK_KERNEL void fs_keys_kernel(const void* canon, uint32_t u, uint32_t shift, uint2* keys, uint32_t* idx) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= u) return;
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(canon) + (size_t)i * 8;
-    const uint32_t ws = shift >> 5, bs = shift & 31;
-    uint32_t x[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) x[j] = ws + j < 8 ? w[ws + j] : 0u;
-    uint2 k;
-    k.x = bs ? (x[0] >> bs) | (x[1] << (32 - bs)) : x[0];
-    k.y = bs ? (x[1] >> bs) | (x[2] << (32 - bs)) : x[1];
-    keys[i] = k;
-    idx[i] = i;
-}
 ZK_HD uint32_t fs_digit(uint2 k, uint32_t pass) { return ((pass < 4 ? k.x : k.y) >> (8 * (pass & 3))) & 255u; }
-
-// ghist[wg * 256 + bin] = pairs of tile wg whose digit is bin
-ZK_KERNEL void fs_hist_kernel(const uint2* keys, uint32_t u, uint32_t pass, uint32_t* ghist) {
-    __shared__ uint32_t lh[256];
-    const uint32_t tid = threadIdx.x, base = blockIdx.x * FS_TILE;
-    lh[tid] = 0;
-    __syncthreads();
-    for (uint32_t e = 0; e < FS_E; e++) {
-        const uint32_t i = base + e * FS_T + tid;
-        if (i < u) atomicAdd(&lh[fs_digit(keys[i], pass)], 1u);
-    }
-    __syncthreads();
-    ghist[(size_t)blockIdx.x * 256 + tid] = lh[tid];
-}
-ZK_KERNEL void fs_scatter_kernel(const uint2* keys_in, const uint32_t* idx_in, uint2* keys_out, uint32_t* idx_out, uint32_t u, uint32_t pass,
-                                 const uint32_t* ghist, uint32_t nwg) {
-    __shared__ uint16_t cnt[FS_T * FS_PAD];      // [thread][digit], row padded so that a digit-column walk spreads over the banks
-    __shared__ uint32_t gbase[256];
-    __shared__ uint32_t scan[256];
-    const uint32_t tid = threadIdx.x, wg = blockIdx.x, base = wg * FS_TILE;
-    for (uint32_t d = 0; d < 256; d++) cnt[tid * FS_PAD + d] = 0;
-    // global base of (this tile, digit = tid): pairs with a smaller digit anywhere + pairs with this digit in earlier tiles
-    uint32_t before = 0, total = 0;
-    for (uint32_t w = 0; w < nwg; w++) {
-        const uint32_t c = ghist[(size_t)w * 256 + tid];
-        if (w < wg) before += c;
-        total += c;
-    }
-    scan[tid] = total;
-    __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-        const uint32_t add = tid >= d ? scan[tid - d] : 0;
-        __syncthreads();
-        scan[tid] += add;
-        __syncthreads();
-    }
-    gbase[tid] = scan[tid] - total + before;
-    // this thread's run: FS_E consecutive pairs of the tile
-    uint2 k[FS_E];
-    uint32_t v[FS_E];
-    uint16_t rl[FS_E];
-    const uint32_t lo = base + tid * FS_E;
-#pragma unroll
-    for (uint32_t e = 0; e < FS_E; e++) {
-        const uint32_t i = lo + e;
-        if (i < u) {
-            k[e] = keys_in[i]; v[e] = idx_in[i];
-            rl[e] = cnt[tid * FS_PAD + fs_digit(k[e], pass)]++;
-        }
-    }
-    __syncthreads();
-    {   // exclusive scan of column `tid` over the threads
-        uint32_t run = 0;
-        for (uint32_t t = 0; t < FS_T; t++) {
-            const uint32_t c = cnt[t * FS_PAD + tid];
-            cnt[t * FS_PAD + tid] = (uint16_t)run;
-            run += c;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < FS_E; e++) {
-        const uint32_t i = lo + e;
-        if (i < u) {
-            const uint32_t d = fs_digit(k[e], pass);
-            const uint32_t pos = gbase[d] + cnt[tid * FS_PAD + d] + rl[e];
-            keys_out[pos] = k[e];
-            idx_out[pos] = v[e];
-        }
-    }
-}
-// err += 1 for every adjacent pair of the sorted order that violates the full 256-bit order
-ZK_KERNEL void fs_check_kernel(const void* canon, const uint32_t* idx, uint32_t u, uint32_t* err) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 || i >= u) return;
-    const uint32_t* a = reinterpret_cast<const uint32_t*>(canon) + (size_t)idx[i - 1] * 8;
-    const uint32_t* b = reinterpret_cast<const uint32_t*>(canon) + (size_t)idx[i] * 8;
-    for (int w = 7; w >= 0; w--) {
-        if (a[w] < b[w]) return;
-        if (a[w] > b[w]) { atomicAdd(err, 1u); return; }
-    }
-}
 
 // ---- exclusive scan of u32 flags over many workgroups (ranks of repeated rows / leftover table values) ----------------
 constexpr uint32_t XS_T = 256, XS_E = 8, XS_TILE = XS_T * XS_E;
@@ -313,27 +217,6 @@ static int lp_sort(zk_ctx* ctx, const void* canon, uint32_t u, uint32_t ndigits,
 }
 
 
-// stable sort of the rows by (canon >> shift) as a 64-bit key: 8 passes (fewer when the keys are narrower); returns the index buffer
-static int fs_sort(zk_ctx* ctx, const void* canon, uint32_t u, uint32_t shift, uint32_t key_bits, uint2* k_a, uint2* k_b, uint32_t* idx_a, uint32_t* idx_b,
-                   uint32_t* ghist, uint32_t** result) {
-    hipStream_t st = ctx->stream;
-    const uint32_t nwg = (u + FS_TILE - 1) / FS_TILE;
-    ZK_LAUNCH(fs_keys_kernel, (u + 255) / 256, 256, 0, st, canon, u, shift, k_a, idx_a);
-    ZK_CHECK_LAUNCH();
-    const uint32_t passes = (key_bits + 7) / 8;
-    uint2 *kin = k_a, *kout = k_b;
-    uint32_t *iin = idx_a, *iout = idx_b;
-    for (uint32_t p = 0; p < passes; p++) {
-        ZK_LAUNCH(fs_hist_kernel, nwg, FS_T, 0, st, (const uint2*)kin, u, p, ghist);
-        ZK_CHECK_LAUNCH();
-        ZK_LAUNCH(fs_scatter_kernel, nwg, FS_T, 0, st, (const uint2*)kin, (const uint32_t*)iin, kout, iout, u, p, (const uint32_t*)ghist, nwg);
-        ZK_CHECK_LAUNCH();
-        std::swap(kin, kout);
-        std::swap(iin, iout);
-    }
-    *result = iin;
-    return ZK_OK;
-}
 // v[0..m) <- exclusive scan, *total_dev <- sum (sums: scratch of ceil(m / XS_TILE) + 1 words)
 static int xs_scan(zk_ctx* ctx, uint32_t* v, uint32_t m, uint32_t* sums, uint32_t* total_dev) {
     hipStream_t st = ctx->stream;
@@ -347,8 +230,10 @@ static int xs_scan(zk_ctx* ctx, uint32_t* v, uint32_t m, uint32_t* sums, uint32_
     return ZK_OK;
 }
 
+// One lookup on the every-digit path (4-bit digits over all bits in use): the fallback of the batched form below for a lookup whose keys tie on the
+// 64-bit window but differ below it.
 static int lookup_permute_one(zk_ctx* ctx, const void* d_input, const void* d_table, uint32_t k, uint32_t blinding_factors, const void* h_blind_input,
-                              const void* h_blind_table, void* d_out_input, void* d_out_table, bool generic_only) {
+                              const void* h_blind_table, void* d_out_input, void* d_out_table) {
     if (!d_input || !d_table || !d_out_input || !d_out_table || !h_blind_input || !h_blind_table)
         return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_dev: null argument");
     if (k < 1 || k > 26) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_dev: k = %u out of range", k);
@@ -356,27 +241,23 @@ static int lookup_permute_one(zk_ctx* ctx, const void* d_input, const void* d_ta
     if (nb >= n) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_dev: blinding_factors too large");
     const uint32_t u = n - nb;
     const uint32_t nruns = (u + LP_RUN - 1) / LP_RUN;
-    const uint32_t nwg = (u + FS_TILE - 1) / FS_TILE, nxs = (u + XS_TILE - 1) / XS_TILE + 1;
-    // workspace: canon_in | canon_tab | blind (2*nb) | sort keys a/b (8 B each) | u32 arrays
-    const size_t words = (size_t)4 * u /*idx in a/b, tab a/b*/ + (size_t)16 * nruns + 4 * (size_t)u /*repeated, rep_rank, unconsumed, left_rank*/ + u +
-                         (size_t)nwg * 256 + nxs + 64;
-    ZK_HIP(ctx->ws_tmp.ensure((size_t)u * 64 + (size_t)nb * 64 + (size_t)u * 16 + words * 4 + 512));
+    const uint32_t nxs = (u + XS_TILE - 1) / XS_TILE + 1;
+    // workspace: canon_in | canon_tab | blind (2*nb) | u32 arrays
+    const size_t words = (size_t)4 * u /*idx in a/b, tab a/b*/ + (size_t)16 * nruns + 4 * (size_t)u /*repeated, rep_rank, unconsumed, left_rank*/ + u + nxs + 64;
+    ZK_HIP(ctx->ws_tmp.ensure((size_t)u * 64 + (size_t)nb * 64 + words * 4 + 512));
     char* base = (char*)ctx->ws_tmp.p;
     void* canon_in = base;
     void* canon_tab = base + (size_t)u * 32;
     void* d_blind_in = base + (size_t)u * 64;
     void* d_blind_tab = (char*)d_blind_in + (size_t)nb * 32;
-    uint2* key_a = (uint2*)((char*)d_blind_tab + (size_t)nb * 32);
-    uint2* key_b = key_a + u;
-    uint32_t* w = (uint32_t*)(key_b + u);
+    uint32_t* w = (uint32_t*)((char*)d_blind_tab + (size_t)nb * 32);
     uint32_t* in_a = w; uint32_t* in_b = in_a + u; uint32_t* tab_a = in_b + u; uint32_t* tab_b = tab_a + u;
     uint32_t* counts = tab_b + u;
     uint32_t* repeated = counts + (size_t)16 * nruns; uint32_t* rep_rank = repeated + u;
     uint32_t* unconsumed = rep_rank + u; uint32_t* left_rank = unconsumed + u;
     uint32_t* leftover = left_rank + u;
-    uint32_t* ghist = leftover + u;
-    uint32_t* xsums = ghist + (size_t)nwg * 256;
-    uint32_t* scal = xsums + nxs;       // [0] skip flag, [1] error count, [2] n_rep, [3] n_left, [4..12) OR of all keys, [12] order violations
+    uint32_t* xsums = leftover + u;
+    uint32_t* scal = xsums + nxs;       // [0] skip flag, [1] error count, [2] n_rep, [3] n_left, [4..12) OR of all keys
     hipStream_t st = ctx->stream;
     const int blk = ctx->tune.vec_block;
     const uint32_t g = (u + blk - 1) / blk;
@@ -394,32 +275,11 @@ static int lookup_permute_one(zk_ctx* ctx, const void* d_input, const void* d_ta
     for (int wd = 7; wd >= 0; wd--)
         if (om[wd]) { uint32_t top = 31; while (!((om[wd] >> top) & 1)) top--; nbits = (uint32_t)wd * 32 + top + 1; break; }
     const uint32_t ndigits = (nbits + 3) / 4;
-    // fast path: 64-bit window ending at the top bit in use; exact when nbits <= 64, otherwise verified below
-    const uint32_t shift = nbits > 64 ? nbits - 64 : 0, key_bits = nbits > 64 ? 64 : nbits;
     uint32_t *in_sorted = nullptr, *tab_sorted = nullptr;
-    int rc = fs_sort(ctx, canon_in, u, shift, key_bits, key_a, key_b, in_a, in_b, ghist, &in_sorted);
+    int rc = lp_sort(ctx, canon_in, u, ndigits, in_a, in_b, counts, scal, &in_sorted);
     if (rc) return rc;
-    rc = fs_sort(ctx, canon_tab, u, shift, key_bits, key_a, key_b, tab_a, tab_b, ghist, &tab_sorted);
+    rc = lp_sort(ctx, canon_tab, u, ndigits, tab_a, tab_b, counts, scal, &tab_sorted);
     if (rc) return rc;
-    if (shift) {
-        ZK_LAUNCH(fs_check_kernel, g, blk, 0, st, (const void*)canon_in, (const uint32_t*)in_sorted, u, scal + 12);
-        ZK_CHECK_LAUNCH();
-        ZK_LAUNCH(fs_check_kernel, g, blk, 0, st, (const void*)canon_tab, (const uint32_t*)tab_sorted, u, scal + 12);
-        ZK_CHECK_LAUNCH();
-        uint32_t viol = 0;
-        ZK_HIP(hipMemcpyAsync(&viol, scal + 12, 4, hipMemcpyDeviceToHost, st));
-        ZK_HIP(hipStreamSynchronize(st));
-        if (viol || generic_only) {   // rows that tie on the window but differ below it: generic sort on every digit in use
-            ZK_LAUNCH(lp_canon_kernel, g, blk, 0, st, d_input, u, canon_in, in_a, scal + 4);   // (re-creates the identity permutations)
-            ZK_CHECK_LAUNCH();
-            ZK_LAUNCH(lp_canon_kernel, g, blk, 0, st, d_table, u, canon_tab, tab_a, scal + 4);
-            ZK_CHECK_LAUNCH();
-            rc = lp_sort(ctx, canon_in, u, ndigits, in_a, in_b, counts, scal, &in_sorted);
-            if (rc) return rc;
-            rc = lp_sort(ctx, canon_tab, u, ndigits, tab_a, tab_b, counts, scal, &tab_sorted);
-            if (rc) return rc;
-        }
-    }
     ZK_LAUNCH(lp_fill_kernel, g, blk, 0, st, unconsumed, u, 1u);
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(lp_mark_kernel, g, blk, 0, st, (const void*)canon_in, (const uint32_t*)in_sorted, (const void*)canon_tab, (const uint32_t*)tab_sorted, u, repeated,
@@ -794,7 +654,7 @@ int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* c
     ZK_HIP(hipStreamSynchronize(st));
     for (size_t l : redo) {
         int rc = lookup_permute_one(ctx, d_inputs[l], d_tables[l], k, blinding_factors, (const char*)h_blind_inputs + l * (size_t)nb * 32,
-                                    (const char*)h_blind_tables + l * (size_t)nb * 32, d_out_inputs[l], d_out_tables[l], true);
+                                    (const char*)h_blind_tables + l * (size_t)nb * 32, d_out_inputs[l], d_out_tables[l]);
         if (rc) return rc;
     }
     return ZK_OK;

@@ -71,7 +71,7 @@ struct MsmPlan {
     const void* const* scalars;            // device array: nb column pointers
     const void* table;
     uint32_t* small;                       // per column: hist[B] off[B+1] cursor[B] suboff[R+1][B+1] info[4]
-    uint32_t small_stride, o_off, o_cursor, o_suboff, o_info, o_tiles;
+    uint32_t small_stride, o_off, o_cursor, o_suboff, o_info, o_tiles, o_fulloff, o_remorder, o_remhist, o_remstart, o_remcursor;
     uint32_t* sorted;                      // per column: pairs_max references
     uint64_t sorted_stride;
     void* sub[2];                          // level r lives in sub[r & 1]
@@ -119,37 +119,50 @@ ZK_KERNEL void msm_hist_kernel(MsmPlan p) {
 //   tiles:    per-tile sums of the NV quantities (coalesced 16-byte reads, LDS tree)            -> tsum[tile][v]
 //   tilesums: one wave per column turns them into exclusive tile bases and writes the totals
 //   apply:    per-tile exclusive scan + base, coalesced 16-byte writes of off / cursor / suboff
-constexpr uint32_t SC_T = 256, SC_E = 4, SC_TILE = SC_T * SC_E, SC_NV = MSM_MAX_LEVELS + 2;
+// Besides the offsets, the scans prepare the EXECUTION ORDER of the accumulate launch: all complete sub-buckets (exactly L pairs) first — fulloff[b] is
+// the exclusive scan of cnt_b / L — then one remainder sub-buckets per bucket with cnt_b % L > 0, grouped by length (longest first) through a counting sort
+// on REM_CLASSES length classes.  Neighbouring lanes then run the same number of additions: a wave's time is its longest lane, and with bucket-major
+// order every wave mixed full sub-buckets with remainders of random length (7 % idle lanes on uniform columns, 40 % on columns of 16-bit values whose
+// buckets hold ~16 pairs).  Where a sub-bucket's partial sum is stored does not change (suboff[0][b] + k), so the merge levels are untouched.
+constexpr uint32_t SC_T = 256, SC_E = 4, SC_TILE = SC_T * SC_E, SC_NV = MSM_MAX_LEVELS + 3, REM_CLASSES = 256;
 struct ScanVals { uint32_t v[SC_NV]; };
+ZK_HD uint32_t rem_class(uint32_t r) { return r < REM_CLASSES ? r : REM_CLASSES - 1; }
 ZK_HD void scan_bucket_values(const MsmPlan& p, uint32_t cnt, ScanVals& o, uint32_t& e0) {
     o.v[0] = cnt;
     uint32_t e = ceil_div(cnt, p.L);
     e0 = e;
 #pragma unroll
-    for (uint32_t r = 0; r <= MSM_MAX_LEVELS; r++) {
-        o.v[1 + r] = r <= p.R ? e : 0u;
+    for (uint32_t r = 0; r <= MSM_MAX_LEVELS + 1; r++) {            // v[1 + r]: level-r entries for r <= R, then (r == R + 1) the complete sub-buckets
+        o.v[1 + r] = r <= p.R ? e : (r == p.R + 1 ? cnt / p.L : 0u);
         e = (e + (1u << p.Mlog) - 1) >> p.Mlog;
     }
 }
 ZK_KERNEL void msm_scan_tiles_kernel(MsmPlan p) {
     __shared__ uint32_t red[SC_T];
-    const uint32_t col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, B = p.B, NV = p.R + 2;
+    __shared__ uint32_t rh[REM_CLASSES];
+    const uint32_t col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, B = p.B, NV = p.R + 3;
     uint32_t* sm = plan_small(p, col);
     const uint32_t b0 = tile * SC_TILE + tid * SC_E;
     ScanVals sum;
 #pragma unroll
     for (uint32_t v = 0; v < SC_NV; v++) sum.v[v] = 0;
     uint32_t mx = 0;
+    for (uint32_t c = tid; c < REM_CLASSES; c += SC_T) rh[c] = 0;
+    __syncthreads();
     for (uint32_t e = 0; e < SC_E; e++) {
         const uint32_t b = b0 + e;
         if (b < B) {
             ScanVals x; uint32_t e0;
-            scan_bucket_values(p, sm[b], x, e0);
+            const uint32_t cnt = sm[b];
+            scan_bucket_values(p, cnt, x, e0);
             mx = e0 > mx ? e0 : mx;
 #pragma unroll
             for (uint32_t v = 0; v < SC_NV; v++) sum.v[v] += x.v[v];
+            if (cnt % p.L) atomicAdd(&rh[rem_class(cnt % p.L)], 1u);
         }
     }
+    __syncthreads();
+    for (uint32_t c = tid; c < REM_CLASSES; c += SC_T) if (rh[c]) atomicAdd(&sm[p.o_remhist + c], rh[c]);
     uint32_t* tsum = sm + p.o_tiles + (size_t)tile * SC_NV;
     for (uint32_t v = 0; v <= NV; v++) {               // v == NV: the maximum
         red[tid] = v < NV ? sum.v[v < SC_NV ? v : 0] : mx;
@@ -163,21 +176,43 @@ ZK_KERNEL void msm_scan_tiles_kernel(MsmPlan p) {
     }
 }
 ZK_KERNEL void msm_scan_tilesums_kernel(MsmPlan p, uint32_t ntiles) {
-    const uint32_t col = blockIdx.x, v = threadIdx.x, B = p.B, NV = p.R + 2;
-    if (v >= NV) return;
+    const uint32_t col = blockIdx.x, v = threadIdx.x, B = p.B, NV = p.R + 3;
     uint32_t* sm = plan_small(p, col);
+    if (v == 63) {   // the last lane: start of every remainder class in the execution order, longest class first; info[1] = number of remainders
+        uint32_t run = 0;
+        for (uint32_t c = REM_CLASSES; c-- > 1;) { sm[p.o_remstart + c] = run; run += sm[p.o_remhist + c]; }
+        sm[p.o_info + 1] = run;
+    }
+    if (v >= NV) return;
     uint32_t* tsum = sm + p.o_tiles;
     uint32_t run = 0;
     for (uint32_t t = 0; t < ntiles; t++) { const uint32_t x = tsum[(size_t)t * SC_NV + v]; tsum[(size_t)t * SC_NV + v] = run; run += x; }
     if (v == 0) sm[p.o_off + B] = run;
-    else sm[p.o_suboff + (size_t)(v - 1) * (B + 1) + B] = run;
+    else if (v <= p.R + 1) sm[p.o_suboff + (size_t)(v - 1) * (B + 1) + B] = run;
+    else sm[p.o_fulloff + B] = run;
 }
 ZK_KERNEL void msm_scan_apply_kernel(MsmPlan p) {
     __shared__ uint32_t sc[SC_T];
-    const uint32_t col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, B = p.B, NV = p.R + 2;
+    const uint32_t col = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, B = p.B, NV = p.R + 3;
     uint32_t* sm = plan_small(p, col);
     const uint32_t* tsum = sm + p.o_tiles + (size_t)tile * SC_NV;
     const uint32_t b0 = tile * SC_TILE + tid * SC_E;
+    {   // remainder sub-buckets of this tile take their slots in the execution order: one reservation per (tile, class), ranks inside the tile from LDS
+        __shared__ uint32_t rcnt[REM_CLASSES], rbase[REM_CLASSES];
+        for (uint32_t c = tid; c < REM_CLASSES; c += SC_T) rcnt[c] = 0;
+        __syncthreads();
+        uint32_t rk[SC_E], rc[SC_E];
+        for (uint32_t e = 0; e < SC_E; e++) {
+            const uint32_t b = b0 + e, r = b < B ? sm[b] % p.L : 0u;
+            rc[e] = r ? rem_class(r) : 0u;
+            rk[e] = r ? atomicAdd(&rcnt[rc[e]], 1u) : 0u;
+        }
+        __syncthreads();
+        for (uint32_t c = tid; c < REM_CLASSES; c += SC_T) rbase[c] = rcnt[c] ? sm[p.o_remstart + c] + atomicAdd(&sm[p.o_remcursor + c], rcnt[c]) : 0u;
+        __syncthreads();
+        for (uint32_t e = 0; e < SC_E; e++) if (rc[e]) sm[p.o_remorder + rbase[rc[e]] + rk[e]] = b0 + e;
+        __syncthreads();
+    }
     ScanVals x[SC_E], sum;
 #pragma unroll
     for (uint32_t v = 0; v < SC_NV; v++) sum.v[v] = 0;
@@ -207,7 +242,8 @@ ZK_KERNEL void msm_scan_apply_kernel(MsmPlan p) {
             const uint32_t b = b0 + e;
             if (b < B) {
                 if (v == 0) { off[b] = run; cursor[b] = run; }
-                else suboff[(size_t)(v - 1) * (B + 1) + b] = run;
+                else if (v <= p.R + 1) suboff[(size_t)(v - 1) * (B + 1) + b] = run;
+                else sm[p.o_fulloff + b] = run;
             }
             run += x[e].v[v];
         }
@@ -258,15 +294,24 @@ ZK_KERNEL void msm_scatter_kernel(MsmPlan p) {
 ZK_KERNEL void msm_accumulate_kernel(MsmPlan p) {
     const uint32_t col = blockIdx.y, B = p.B;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t* suboff = plan_suboff(p, col, 0);
-    if (j >= suboff[B]) return;
-    const uint32_t* off = plan_small(p, col) + p.o_off;
+    const uint32_t* sm = plan_small(p, col);
+    const uint32_t* fulloff = sm + p.o_fulloff;
+    const uint32_t n_full = fulloff[B];
+    uint32_t b, k;
+    if (j < n_full) {                                  // a complete sub-bucket: L pairs
+        b = find_segment(fulloff, B, j);
+        k = j - fulloff[b];
+    } else {                                           // the remainder of a bucket; neighbours have (almost) the same length
+        if (j - n_full >= sm[p.o_info + 1]) return;
+        b = sm[p.o_remorder + (j - n_full)];
+        k = fulloff[b + 1] - fulloff[b];
+    }
+    const uint32_t* off = sm + p.o_off;
     const uint32_t* sorted = p.sorted + (size_t)col * p.sorted_stride;
-    const uint32_t b = find_segment(suboff, B, j);
-    const uint32_t k = j - suboff[b];
     uint32_t q = off[b] + k * p.L;
     const uint32_t bend = off[b + 1];
     const uint32_t end = q + p.L < bend ? q + p.L : bend;
+    const uint32_t out = plan_suboff(p, col, 0)[b] + k;   // bucket-major slot of this partial sum, as the merge levels expect it
     XYZZ acc = xyzz_identity();
     uint32_t ref = sorted[q];
     Affine pt = load_affine(p.table, ref & 0x7fffffffu);
@@ -281,7 +326,7 @@ ZK_KERNEL void msm_accumulate_kernel(MsmPlan p) {
         xyzz_madd_signed(acc, cur, (cur_ref >> 31) != 0);
         if (q >= end) break;
     }
-    store_xyzz(p.sub[0], (size_t)col * p.sub_stride[0] + j, acc);
+    store_xyzz(p.sub[0], (size_t)col * p.sub_stride[0] + out, acc);
 }
 
 // merge level r-1 -> level r: one thread per OUTPUT entry (dense), fan-in M.
@@ -579,7 +624,12 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     p.o_off = B; p.o_cursor = p.o_off + B + 1; p.o_suboff = p.o_cursor + B; p.o_info = p.o_suboff + (R + 1) * (B + 1);
     const uint32_t scan_tiles = ceil_div(B, SC_TILE);
     p.o_tiles = p.o_info + 4;
-    p.small_stride = p.o_tiles + scan_tiles * SC_NV;
+    p.o_fulloff = p.o_tiles + scan_tiles * SC_NV;
+    p.o_remorder = p.o_fulloff + B + 1;
+    p.o_remhist = p.o_remorder + B;
+    p.o_remstart = p.o_remhist + REM_CLASSES;
+    p.o_remcursor = p.o_remstart + REM_CLASSES;
+    p.small_stride = p.o_remcursor + REM_CLASSES;
     ZK_HIP(ctx->ws_small.ensure((size_t)nb * p.small_stride * 4 + (size_t)nb * sizeof(void*) + 64));
     p.small = (uint32_t*)ctx->ws_small.p;
     const void** d_ptrs = (const void**)((char*)ctx->ws_small.p + (((size_t)nb * p.small_stride * 4 + 15) & ~(size_t)15));

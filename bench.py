@@ -426,7 +426,7 @@ def main(argv=None):
                 "avg_launch_ms": round(acc_ms / max(acc_n, 1), 4), "launches": acc_n,
                 "algorithmic_bytes_per_launch": round(96.0 * wl.n * msm_columns / max(acc_n, 1)),
                 "note": "the kernel is integer-ALU bound (v_mad_u64_u32), not HBM bound - DESIGN.md 3.2; int_alu gives the fraction of the "
-                        "measured XYZZ mixed-add peak",
+                        "measured XYZZ mixed-add peak; with several proofs in flight a launch's event time includes cycles shared with other streams' kernels, so both fractions are lower bounds",
                 "int_alu": {"achieved_Gmadd_per_s": round(msm_pairs / acc_s / 1e9, 3), "peak_Gmadd_per_s": XYZZ_MADD_PEAK / 1e9,
                             "frac": round(msm_pairs / acc_s / XYZZ_MADD_PEAK, 4)}}
 

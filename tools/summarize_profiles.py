@@ -7,7 +7,6 @@ import csv
 import json
 import os
 import re
-import shutil
 import sys
 
 

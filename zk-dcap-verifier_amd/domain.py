@@ -12,7 +12,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import Backend, DeviceBuffer, default_backend
+from ._lib import Backend, default_backend
 
 
 class EvaluationDomain:

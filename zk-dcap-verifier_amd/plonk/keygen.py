@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import hashlib
 from dataclasses import dataclass, field
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 
@@ -22,7 +22,7 @@ from .._lib import Backend
 from ..domain import EvaluationDomain
 from ..fields import DELTA, R_MOD, fr_mont, fr_mont_array, g1_affine_ints
 from ..kzg import ParamsKZG
-from .circuit import ADVICE, FIXED, INSTANCE, Assembly, ConstraintSystem
+from .circuit import Assembly, ConstraintSystem
 from .expression import GraphBuilder
 
 

@@ -137,3 +137,38 @@ def test_emulated_lookup_permute_batch(emu, orc, pyref):
 @pytest.mark.gpu
 def test_gpu_lookup_permute_batch(gpu, orc, pyref):
     _check_batch(gpu, orc, pyref, 13, ["small", "wide", "window_ties", "identical", "perm", "wide", "small"], seed=31)
+
+
+def _check_shared_table(be, orc, pyref, k, seed):
+    """three lookups against ONE table column (the same device buffer): the batch sorts it once; results per lookup as if it were private"""
+    n = 1 << k
+    M = orc.fr_from_ints
+    _, tab, bf = _case(orc, pyref, k, seed, "wide")
+    u = n - bf - 1
+    import random
+    rnd = random.Random(seed)
+    T = M(tab)
+    dT = be.to_device(T)
+    ins, bis, bts, wants = [], [], [], []
+    for j in range(3):
+        inp = [rnd.choice(tab[:u]) for _ in range(u)] + [rnd.randrange(pyref.R) for _ in range(bf + 1)]
+        bi, bt = pc.rand_fr(orc, pyref, bf + 1, seed + 10 + j), pc.rand_fr(orc, pyref, bf + 1, seed + 20 + j)
+        A = M(inp)
+        wants.append(orc.lookup_permute(A, T, k, bf, bi, bt))
+        ins.append(be.to_device(A)); bis.append(bi); bts.append(bt)
+    outs = z.permutation.permute_expression_pairs(ins, [dT, dT, dT], k, bf, np.stack(bis), np.stack(bts), backend=be)
+    for (oa, ot), (wi, wt) in zip(outs, wants):
+        assert (oa.download((n, 4)) == wi).all() and (ot.download((n, 4)) == wt).all()
+
+
+def test_emulated_lookup_permute_shared_table(emu, orc, pyref):
+    emu.tune(vec_block=64)
+    try:
+        _check_shared_table(emu, orc, pyref, 5, seed=41)
+    finally:
+        emu.tune(vec_block=32)
+
+
+@pytest.mark.gpu
+def test_gpu_lookup_permute_shared_table(gpu, orc, pyref):
+    _check_shared_table(gpu, orc, pyref, 14, seed=43)

@@ -314,13 +314,18 @@ static int lookup_permute_one(zk_ctx* ctx, const void* d_input, const void* d_ta
 // Layout (S = 2 * count sorts, u rows each): canon[s][u] | keys a/b [s][u] | idx a/b [s][u] | flags[s][u] (repeated / unconsumed)
 // | ranks[s][u] | leftover[l][u] | ghist[s][nwg][256] | xsums[s][nxs] | scal[l][16]
 // ================================================================================================================
+// Sorted columns are numbered c < C: c < count is the input of lookup c, c >= count a DISTINCT table column — lookups that share their
+// (compressed) table column, as range checks and the base64 lookups of the sgx circuit do, sort it once (tabcol[l] = its number).
 struct LpbArgs {
     const void* const* cols;     // S device pointers: input_0, table_0, input_1, table_1, ...
     void* const* outs;           // S device pointers: out_input_0, out_table_0, ...
-    uint32_t u, n, nb, S, nwg, nxs;
-    void* canon; uint2* key_a; uint2* key_b; uint32_t* idx_a; uint32_t* idx_b;
-    uint32_t* flags; uint32_t* ranks; uint32_t* leftover; uint32_t* ghist; uint32_t* xsums; uint32_t* scal;
-    const uint32_t* shifts;      // S words
+    const void* const* scols;    // C device pointers: the sorted columns
+    const uint32_t* tabcol;      // count words
+    uint32_t u, n, nb, S, C, nwg, nxs;
+    void* canon; uint2* key_a; uint2* key_b; uint32_t* idx_a; uint32_t* idx_b;       // [C][u]
+    uint32_t* flags; uint32_t* ranks; uint32_t* leftover; uint32_t* ghist; uint32_t* xsums; uint32_t* scal;   // flags / ranks [S][u], scal [count][16]
+    uint32_t* cscal;             // [C][16]: [0..8) OR of the column's keys, [8] order violations
+    const uint32_t* shifts;      // C words
     const void* blind;           // [l][2][nb] x 32 B
 };
 ZK_KERNEL void lpb_canon_kernel(LpbArgs a) {
@@ -329,13 +334,13 @@ ZK_KERNEL void lpb_canon_kernel(LpbArgs a) {
     if (threadIdx.x < 8) lor[threadIdx.x] = 0;
     __syncthreads();
     if (i < a.u) {
-        const u256 c = Fr::from_mont(load_u256(a.cols[s], i));
+        const u256 c = Fr::from_mont(load_u256(a.scols[s], i));
         store_u256(a.canon, (size_t)s * a.u + i, c);
 #pragma unroll
         for (int w = 0; w < 8; w++) if (c.v[w] & ~lor[w]) atomicOr(&lor[w], c.v[w]);
     }
     __syncthreads();
-    if (threadIdx.x < 8 && lor[threadIdx.x]) atomicOr(&a.scal[(s >> 1) * 16 + 4 + threadIdx.x], lor[threadIdx.x]);
+    if (threadIdx.x < 8 && lor[threadIdx.x]) atomicOr(&a.cscal[s * 16 + threadIdx.x], lor[threadIdx.x]);
 }
 ZK_KERNEL void lpb_keys_kernel(LpbArgs a) {
     const uint32_t s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,17 +448,18 @@ ZK_KERNEL void lpb_check_kernel(LpbArgs a, const uint32_t* idx_sorted) {
     const uint32_t* y = canon + (size_t)idx[i] * 8;
     for (int w = 7; w >= 0; w--) {
         if (x[w] < y[w]) return;
-        if (x[w] > y[w]) { atomicAdd(&a.scal[(s >> 1) * 16 + 12], 1u); return; }
+        if (x[w] > y[w]) { atomicAdd(&a.cscal[s * 16 + 8], 1u); return; }
     }
 }
 // flags[2l][i] = repeated, flags[2l+1][t] = unconsumed (pre-set to 1 by the caller)
 ZK_KERNEL void lpb_mark_kernel(LpbArgs a, const uint32_t* idx_sorted) {
     const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x, u = a.u;
     if (i >= u) return;
-    const void* in_canon = (const char*)a.canon + (size_t)(2 * l) * u * 32;
-    const void* tab_canon = (const char*)a.canon + (size_t)(2 * l + 1) * u * 32;
-    const uint32_t* in_idx = idx_sorted + (size_t)(2 * l) * u;
-    const uint32_t* tab_idx = idx_sorted + (size_t)(2 * l + 1) * u;
+    const uint32_t tc = a.tabcol[l];
+    const void* in_canon = (const char*)a.canon + (size_t)l * u * 32;
+    const void* tab_canon = (const char*)a.canon + (size_t)tc * u * 32;
+    const uint32_t* in_idx = idx_sorted + (size_t)l * u;
+    const uint32_t* tab_idx = idx_sorted + (size_t)tc * u;
     uint32_t* repeated = a.flags + (size_t)(2 * l) * u;
     uint32_t* unconsumed = a.flags + (size_t)(2 * l + 1) * u;
     const u256 v = load_u256(in_canon, in_idx[i]);
@@ -536,8 +542,8 @@ ZK_KERNEL void lpb_assemble_kernel(LpbArgs a, const uint32_t* idx_sorted) {
         store_u256(out_tab, i, load_u256(a.blind, (size_t)(2 * l + 1) * a.nb + (i - u)));
         return;
     }
-    const uint32_t* in_idx = idx_sorted + (size_t)(2 * l) * u;
-    const uint32_t* tab_idx = idx_sorted + (size_t)(2 * l + 1) * u;
+    const uint32_t* in_idx = idx_sorted + (size_t)l * u;
+    const uint32_t* tab_idx = idx_sorted + (size_t)a.tabcol[l] * u;
     const u256 v = load_u256(a.cols[2 * l], in_idx[i]);
     store_u256(out_in, i, v);
     if (!a.flags[(size_t)(2 * l) * u + i]) store_u256(out_tab, i, v);
@@ -558,14 +564,25 @@ int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* c
     for (size_t l = 0; l < count; l++)
         if (!d_inputs[l] || !d_tables[l] || !d_out_inputs[l] || !d_out_tables[l]) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_batch_dev: null column %zu", l);
     const uint32_t u = n - nb, S = 2 * (uint32_t)count;
+    // sorted columns: every input, every DISTINCT table pointer
+    std::vector<const void*> scols(d_inputs, d_inputs + count);
+    std::vector<uint32_t> tabcol(count);
+    for (size_t l = 0; l < count; l++) {
+        size_t c = count;
+        while (c < scols.size() && scols[c] != d_tables[l]) c++;
+        if (c == scols.size()) scols.push_back(d_tables[l]);
+        tabcol[l] = (uint32_t)c;
+    }
+    const uint32_t C = (uint32_t)scols.size();
     const uint32_t nwg = (u + FS_TILE - 1) / FS_TILE, nxs = (u + XS_TILE - 1) / XS_TILE + 1;
     // workspace carve-up (32-byte aligned pieces first)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_canon = take((size_t)S * u * 32), o_blind = take((size_t)S * nb * 32), o_ka = take((size_t)S * u * 8), o_kb = take((size_t)S * u * 8),
-                 o_ia = take((size_t)S * u * 4), o_ib = take((size_t)S * u * 4), o_fl = take((size_t)S * u * 4), o_rk = take((size_t)S * u * 4),
-                 o_lo = take((size_t)count * u * 4), o_gh = take((size_t)S * nwg * 256 * 4), o_xs = take((size_t)S * nxs * 4), o_sc = take((size_t)count * 64),
-                 o_sh = take((size_t)S * 4), o_cp = take((size_t)S * sizeof(void*)), o_op = take((size_t)S * sizeof(void*));
+    const size_t o_canon = take((size_t)C * u * 32), o_blind = take((size_t)S * nb * 32), o_ka = take((size_t)C * u * 8), o_kb = take((size_t)C * u * 8),
+                 o_ia = take((size_t)C * u * 4), o_ib = take((size_t)C * u * 4), o_fl = take((size_t)S * u * 4), o_rk = take((size_t)S * u * 4),
+                 o_lo = take((size_t)count * u * 4), o_gh = take((size_t)C * nwg * 256 * 4), o_xs = take((size_t)S * nxs * 4), o_sc = take((size_t)count * 64),
+                 o_cs = take((size_t)C * 64), o_sh = take((size_t)C * 4), o_tc = take((size_t)count * 4), o_cp = take((size_t)S * sizeof(void*)),
+                 o_op = take((size_t)S * sizeof(void*)), o_sp = take((size_t)C * sizeof(void*));
     ZK_HIP(ctx->ws_tmp.ensure(off + 256));
     char* base = (char*)ctx->ws_tmp.p;
     hipStream_t st = ctx->stream;
@@ -580,53 +597,57 @@ int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* c
     }
     ZK_HIP(hipMemcpyAsync(base + o_cp, cols.data(), S * sizeof(void*), hipMemcpyHostToDevice, st));
     ZK_HIP(hipMemcpyAsync(base + o_op, outs.data(), S * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(base + o_sp, scols.data(), C * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(base + o_tc, tabcol.data(), count * 4, hipMemcpyHostToDevice, st));
     ZK_HIP(hipMemcpyAsync(base + o_blind, blind.data(), blind.size(), hipMemcpyHostToDevice, st));
     ZK_HIP(hipMemsetAsync(base + o_sc, 0, count * 64, st));
+    ZK_HIP(hipMemsetAsync(base + o_cs, 0, (size_t)C * 64, st));
     LpbArgs a;
     memset(&a, 0, sizeof a);
-    a.cols = (const void* const*)(base + o_cp); a.outs = (void* const*)(base + o_op);
-    a.u = u; a.n = n; a.nb = nb; a.S = S; a.nwg = nwg; a.nxs = nxs;
+    a.cols = (const void* const*)(base + o_cp); a.outs = (void* const*)(base + o_op); a.scols = (const void* const*)(base + o_sp);
+    a.tabcol = (const uint32_t*)(base + o_tc);
+    a.u = u; a.n = n; a.nb = nb; a.S = S; a.C = C; a.nwg = nwg; a.nxs = nxs;
     a.canon = base + o_canon; a.key_a = (uint2*)(base + o_ka); a.key_b = (uint2*)(base + o_kb); a.idx_a = (uint32_t*)(base + o_ia); a.idx_b = (uint32_t*)(base + o_ib);
     a.flags = (uint32_t*)(base + o_fl); a.ranks = (uint32_t*)(base + o_rk); a.leftover = (uint32_t*)(base + o_lo); a.ghist = (uint32_t*)(base + o_gh);
-    a.xsums = (uint32_t*)(base + o_xs); a.scal = (uint32_t*)(base + o_sc); a.shifts = (const uint32_t*)(base + o_sh); a.blind = base + o_blind;
+    a.xsums = (uint32_t*)(base + o_xs); a.scal = (uint32_t*)(base + o_sc); a.cscal = (uint32_t*)(base + o_cs); a.shifts = (const uint32_t*)(base + o_sh);
+    a.blind = base + o_blind;
     const int blk = ctx->tune.vec_block;
     const uint32_t g = (u + blk - 1) / blk;
-    ZK_LAUNCH(lpb_canon_kernel, dim3(g, S), blk, 0, st, a);
+    ZK_LAUNCH(lpb_canon_kernel, dim3(g, C), blk, 0, st, a);
     ZK_CHECK_LAUNCH();
-    std::vector<uint32_t> sc((size_t)count * 16);
-    ZK_HIP(hipMemcpyAsync(sc.data(), a.scal, count * 64, hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> sc((size_t)count * 16), csc((size_t)C * 16);
+    ZK_HIP(hipMemcpyAsync(csc.data(), a.cscal, (size_t)C * 64, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
-    std::vector<uint32_t> shifts(S);
+    std::vector<uint32_t> shifts(C);
     uint32_t max_bits = 1;
     bool any_shift = false;
-    for (size_t l = 0; l < count; l++) {
-        const uint32_t* om = &sc[l * 16 + 4];
+    for (uint32_t c = 0; c < C; c++) {            // each sorted column takes the 64-bit window that ends at ITS highest bit in use
+        const uint32_t* om = &csc[(size_t)c * 16];
         uint32_t nbits = 1;
         for (int wd = 7; wd >= 0; wd--)
             if (om[wd]) { uint32_t top = 31; while (!((om[wd] >> top) & 1)) top--; nbits = (uint32_t)wd * 32 + top + 1; break; }
-        const uint32_t sh = nbits > 64 ? nbits - 64 : 0;
-        shifts[2 * l] = shifts[2 * l + 1] = sh;
-        any_shift |= sh != 0;
+        shifts[c] = nbits > 64 ? nbits - 64 : 0;
+        any_shift |= shifts[c] != 0;
         max_bits = std::max(max_bits, std::min(nbits, 64u));
     }
-    ZK_HIP(hipMemcpyAsync(base + o_sh, shifts.data(), S * 4, hipMemcpyHostToDevice, st));
-    ZK_LAUNCH(lpb_keys_kernel, dim3((u + 255) / 256, S), 256, 0, st, a);
+    ZK_HIP(hipMemcpyAsync(base + o_sh, shifts.data(), (size_t)C * 4, hipMemcpyHostToDevice, st));
+    ZK_LAUNCH(lpb_keys_kernel, dim3((u + 255) / 256, C), 256, 0, st, a);
     ZK_CHECK_LAUNCH();
     const uint32_t passes = (max_bits + 7) / 8;
     uint2 *kin = a.key_a, *kout = a.key_b;
     uint32_t *iin = a.idx_a, *iout = a.idx_b;
     for (uint32_t p = 0; p < passes; p++) {
-        ZK_LAUNCH(lpb_hist_kernel, dim3(nwg, S), FS_T, 0, st, (const uint2*)kin, u, p, a.ghist, nwg);
+        ZK_LAUNCH(lpb_hist_kernel, dim3(nwg, C), FS_T, 0, st, (const uint2*)kin, u, p, a.ghist, nwg);
         ZK_CHECK_LAUNCH();
-        ZK_LAUNCH(lpb_offsets_kernel, S, 256, 0, st, a.ghist, nwg);
+        ZK_LAUNCH(lpb_offsets_kernel, C, 256, 0, st, a.ghist, nwg);
         ZK_CHECK_LAUNCH();
-        ZK_LAUNCH(lpb_scatter_kernel, dim3(nwg, S), FS_T, 0, st, (const uint2*)kin, (const uint32_t*)iin, kout, iout, u, p, (const uint32_t*)a.ghist, nwg);
+        ZK_LAUNCH(lpb_scatter_kernel, dim3(nwg, C), FS_T, 0, st, (const uint2*)kin, (const uint32_t*)iin, kout, iout, u, p, (const uint32_t*)a.ghist, nwg);
         ZK_CHECK_LAUNCH();
         std::swap(kin, kout);
         std::swap(iin, iout);
     }
     const uint32_t* sorted = iin;
-    if (any_shift) { ZK_LAUNCH(lpb_check_kernel, dim3(g, S), blk, 0, st, a, sorted); ZK_CHECK_LAUNCH(); }
+    if (any_shift) { ZK_LAUNCH(lpb_check_kernel, dim3(g, C), blk, 0, st, a, sorted); ZK_CHECK_LAUNCH(); }
     ZK_LAUNCH(lpb_fill_unconsumed_kernel, dim3(g, (uint32_t)count), blk, 0, st, a);
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(lpb_mark_kernel, dim3(g, (uint32_t)count), blk, 0, st, a, sorted);
@@ -639,11 +660,12 @@ int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* c
     ZK_LAUNCH(lpb_apply_kernel, dim3(nxs - 1, S), XS_T, 0, st, a);
     ZK_CHECK_LAUNCH();
     ZK_HIP(hipMemcpyAsync(sc.data(), a.scal, count * 64, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(csc.data(), a.cscal, (size_t)C * 64, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     std::vector<size_t> redo;
     for (size_t l = 0; l < count; l++) {
         const uint32_t* h = &sc[l * 16];
-        if (h[12] || ctx->tune.lookup_force_generic_sort) { redo.push_back(l); continue; }   // window ties: every-digit sort for this lookup
+        if (csc[l * 16 + 8] || csc[(size_t)tabcol[l] * 16 + 8] || ctx->tune.lookup_force_generic_sort) { redo.push_back(l); continue; }   // window ties: every-digit sort for this lookup
         if (h[1]) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_dev: %u input value(s) of lookup %zu are not in the table (halo2: Error::ConstraintSystemFailure)", h[1], l);
         if (h[2] != h[3]) return ctx->fail(ZK_ERR_ARG, "zk_lookup_permute_dev: internal count mismatch in lookup %zu (%u repeated rows, %u leftover table values)", l, h[2], h[3]);
     }

@@ -111,16 +111,20 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     one = fr_mont(1)
     th = fr_mont(theta)
     compressed = []
-    for (cin_ev, ctab_ev) in pk.lookup_compressors:
-        pair = []
-        for evl in (cin_ev, ctab_ev):
-            out = dev(n * 32)
-            anycol = pk.fixed_values[0] if pk.fixed_values else adv_values[0]
-            evl.evaluate_h(fixed=pk.fixed_values, advice=adv_values, instance=inst_values, l0=anycol, l_last=anycol, l_active_row=anycol,
-                           perm_cosets=[], perm_products=[], lookup_product=[], lookup_input=[], lookup_table=[], challenges=[],
-                           beta=one, gamma=one, theta=th, y=one, out=out)
-            pair.append(out)
-        compressed.append(pair)
+    table_cache = {}                                            # lookups with the same table expressions share ONE compressed table column
+    anycol = pk.fixed_values[0] if pk.fixed_values else adv_values[0]
+
+    def run_compressor(evl):
+        out = dev(n * 32)
+        evl.evaluate_h(fixed=pk.fixed_values, advice=adv_values, instance=inst_values, l0=anycol, l_last=anycol, l_active_row=anycol,
+                       perm_cosets=[], perm_products=[], lookup_product=[], lookup_input=[], lookup_table=[], challenges=[],
+                       beta=one, gamma=one, theta=th, y=one, out=out)
+        return out
+    for lk, (cin_ev, ctab_ev) in zip(cs.lookups, pk.lookup_compressors):
+        key = tuple(lk.table_expressions)
+        if key not in table_cache:
+            table_cache[key] = run_compressor(ctab_ev)
+        compressed.append([run_compressor(cin_ev), table_cache[key]])
     # permute_expression_pair of every lookup in one device call (raises ZkError when an input is not in the table)
     bi = np.stack([rand_fr_array(rng, bf + 1) for _ in compressed]) if compressed else np.zeros((0, bf + 1, 4), np.uint64)
     bt = np.stack([rand_fr_array(rng, bf + 1) for _ in compressed]) if compressed else np.zeros((0, bf + 1, 4), np.uint64)

@@ -201,13 +201,13 @@ class ProverWorkload:
         self.n_intt = A + 3 * L + self.P
         self.n_ext = self.n_intt
 
-    def step(self):
+    def step(self, timings=None):
         from zk_dcap_verifier_amd.transcript import Blake2bWrite
         for w, m in zip(self.work, self.master):
             w.copy_from(m)                                           # the witness of this proof (create_proof works in place)
         tr = Blake2bWrite()
         self.seed += 1
-        self.info = self.z.plonk.create_proof(self.params, self.pk, self.work, [], np.random.default_rng(self.seed), tr)
+        self.info = self.z.plonk.create_proof(self.params, self.pk, self.work, [], np.random.default_rng(self.seed), tr, timings=timings)
         self.proof = tr.finalize()
 
 
@@ -430,6 +430,17 @@ def main(argv=None):
                 "int_alu": {"achieved_Gmadd_per_s": round(msm_pairs / acc_s / 1e9, 3), "peak_Gmadd_per_s": XYZZ_MADD_PEAK / 1e9,
                             "frac": round(msm_pairs / acc_s / XYZZ_MADD_PEAK, 4)}}
 
+    if args.mode == "prove" and not args.no_extras:
+        # latency of ONE proof with the GPU to itself (the timed region above measures throughput with several in flight)
+        lat = []
+        for _ in range(2):
+            tm = {}
+            be.sync()
+            t1 = time.time()
+            wl.step(timings=tm)
+            lat.append((time.time() - t1, tm))
+        best = min(lat, key=lambda x: x[0])
+        extra["single_proof"] = {"ms": round(best[0] * 1e3, 2), "phase_ms": {k_: round(v, 2) for k_, v in best[1].items()}}
     cfg = {"k": args.k, "ek": wl.ek, "A": wl.A, "F": wl.F, "L": wl.L, "n_perm": wl.n_perm, "d": wl.d,
            "n_msm": wl.n_msm, "n_intt": wl.n_intt, "n_ext": wl.n_ext}
     cpu = None

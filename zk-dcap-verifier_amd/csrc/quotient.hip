@@ -347,6 +347,11 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
             cheap[i] = g.calcs[i].op != OP_HORNER && cost[i] <= QUOT_REMAT_OPS && i + 1 < nc;
         }
         std::vector<int> vreg(nc, -1);
+        // a cheap value is only recomputed when its previous copy is FAR behind (it would otherwise hold a slot across that distance); a copy
+        // emitted a few instructions ago is simply reused (e.g. sel * advice shared by the 4-5 scaled inputs of one lookup)
+        constexpr size_t QUOT_REMAT_DISTANCE = 24;
+        std::vector<size_t> emitted_at(nc, 0);
+        auto stale = [&](int c) { return cheap[c] && vreg[c] >= 0 && B.ins.size() - emitted_at[c] > QUOT_REMAT_DISTANCE; };
         bool ok = true;
         auto leaf = [&](const VSrc& s) -> Builder::Opnd {
             switch (s.kind) {
@@ -385,7 +390,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
             if (k.op != OP_HORNER) {
                 if (f.next < d.size()) {               // make operand f.next available
                     const size_t oi = f.next++;
-                    if (d[oi] >= 0 && vreg[d[oi]] < 0 && !is_alias[d[oi]]) st.push_back(Frame{d[oi], 0});
+                    if (d[oi] >= 0 && !is_alias[d[oi]] && (vreg[d[oi]] < 0 || stale(d[oi]))) { vreg[d[oi]] = -1; st.push_back(Frame{d[oi], 0}); }
                     continue;
                 }
                 {   // an operand computed earlier may have been handed back (rematerialisation) while a later operand was being produced
@@ -405,18 +410,17 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
                     default: v = B.tmp(M_MOV, {opnd_at(0)}); break;
                 }
                 vreg[ci] = v;
-                for (int dd : d) if (dd >= 0 && cheap[dd]) vreg[dd] = -1;   // recompute at the next use instead of keeping it live
+                emitted_at[ci] = B.ins.size();
                 st.pop_back();
             } else {
                 // operands: 0 = start, 1 = factor, 2.. = parts.  Steps happen as soon as part i is ready.
                 if (f.next < d.size()) {
                     const size_t oi = f.next;
-                    if (d[oi] >= 0 && vreg[d[oi]] < 0 && !is_alias[d[oi]]) { st.push_back(Frame{d[oi], 0}); continue; }
+                    if (d[oi] >= 0 && !is_alias[d[oi]] && (vreg[d[oi]] < 0 || (oi >= 2 && stale(d[oi])))) { vreg[d[oi]] = -1; st.push_back(Frame{d[oi], 0}); continue; }
                     f.next++;
                     if (oi >= 2) {
                         Builder::Opnd curv = horner_cur[ci] >= 0 ? B.slot(horner_cur[ci]) : opnd_at(0);
                         horner_cur[ci] = B.tmp(M_MULADD, {curv, opnd_at(1), opnd_at(oi)});
-                        if (d[oi] >= 0 && cheap[d[oi]] && d[oi] != d[0] && d[oi] != d[1]) vreg[d[oi]] = -1;
                     }
                     continue;
                 }

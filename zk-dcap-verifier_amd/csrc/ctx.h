@@ -30,6 +30,8 @@ struct Tune {
     int ntt_full_twiddle_max_log = 24;   // up to this size inter-pass twiddles come from full HBM tables (32 B/element/pass)
     int vec_block = 256;
     int quot_threads = 128;
+    int quot_remat_ops = 4;      // quotient compiler: a shared sub-expression of at most this many operations ...
+    int quot_remat_distance = 24;   // ... is recomputed when its previous copy lies further back than this many micro-ops
     int lookup_force_generic_sort = 0;   // tests: take the every-digit sort of permute_expression_pair even when the 64-bit window sort is exact
 };
 

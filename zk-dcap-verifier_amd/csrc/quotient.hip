@@ -336,7 +336,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         // Rematerialisation: halo2's add_calculation shares every repeated sub-expression, however far apart its uses are (on the CPU an
         // intermediate is a memory cell).  Here a shared value occupies a slot from its first to its last use, and slots (LDS) set the
         // occupancy of the kernel: a value that costs at most QUOT_REMAT_OPS operations over memory operands is recomputed at each use.
-        constexpr uint32_t QUOT_REMAT_OPS = 4;
+        const uint32_t QUOT_REMAT_OPS = (uint32_t)ctx->tune.quot_remat_ops;
         std::vector<uint32_t> cost(nc, 0);
         std::vector<char> cheap(nc, 0);
         for (size_t i = 0; i < nc; i++) {
@@ -349,7 +349,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         std::vector<int> vreg(nc, -1);
         // a cheap value is only recomputed when its previous copy is FAR behind (it would otherwise hold a slot across that distance); a copy
         // emitted a few instructions ago is simply reused (e.g. sel * advice shared by the 4-5 scaled inputs of one lookup)
-        constexpr size_t QUOT_REMAT_DISTANCE = 24;
+        const size_t QUOT_REMAT_DISTANCE = (size_t)ctx->tune.quot_remat_distance;
         std::vector<size_t> emitted_at(nc, 0);
         auto stale = [&](int c) { return cheap[c] && vreg[c] >= 0 && B.ins.size() - emitted_at[c] > QUOT_REMAT_DISTANCE; };
         bool ok = true;

@@ -419,8 +419,14 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
                     if (d[oi] >= 0 && !is_alias[d[oi]] && (vreg[d[oi]] < 0 || (oi >= 2 && stale(d[oi])))) { vreg[d[oi]] = -1; st.push_back(Frame{d[oi], 0}); continue; }
                     f.next++;
                     if (oi >= 2) {
-                        Builder::Opnd curv = horner_cur[ci] >= 0 ? B.slot(horner_cur[ci]) : opnd_at(0);
-                        horner_cur[ci] = B.tmp(M_MULADD, {curv, opnd_at(1), opnd_at(oi)});
+                        // Horner(0, parts, f) — how halo2 compresses lookup expressions — starts with 0 * f + part_0: take part_0 as it is
+                        const bool zero_start = horner_cur[ci] < 0 && d[0] < 0 && k.s0.kind == VS_CONST && k.s0.a < g.constants.size() &&
+                                                Fr::is_zero(g.constants[k.s0.a]);
+                        if (zero_start) horner_cur[ci] = (d[oi] >= 0 && !is_alias[d[oi]]) ? vreg[d[oi]] : B.tmp(M_MOV, {opnd_at(oi)});
+                        else {
+                            Builder::Opnd curv = horner_cur[ci] >= 0 ? B.slot(horner_cur[ci]) : opnd_at(0);
+                            horner_cur[ci] = B.tmp(M_MULADD, {curv, opnd_at(1), opnd_at(oi)});
+                        }
                     }
                     continue;
                 }

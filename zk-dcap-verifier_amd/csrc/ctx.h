@@ -28,6 +28,7 @@ struct Tune {
     int ntt_threads = 256;
     int ntt_max_radix_log = 8;
     int ntt_full_twiddle_max_log = 24;   // up to this size inter-pass twiddles come from full HBM tables (32 B/element/pass)
+    int ntt_quarter_input = 1;   // coeff_to_extended: skip the arithmetic of the first two stages when 3/4 of the input is the zero padding
     int vec_block = 256;
     int quot_threads = 128;
     int quot_remat_ops = 4;      // quotient compiler: a shared sub-expression of at most this many operations ...

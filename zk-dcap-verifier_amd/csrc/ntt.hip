@@ -34,6 +34,7 @@ struct NttPassArgs {
     const void* tw_full;    // non-final pass: twiddle of element (row, m) at [row * cols + m], or null
     // fused operations
     uint32_t n_valid;       // first pass only (0 = all)
+    int quarter_input;      // first pass only: n_valid <= N / 4, so rows >= R/4 of every tile are zero
     int pre_zeta;
     int post_scale;
     int post_zeta_inv;
@@ -84,9 +85,24 @@ ZK_HD u256 lds_get(const uint4* lo, const uint4* hi, uint32_t idx) {
 // all log R DIT stages on the tile held in LDS (rows were stored bit-reversed).  Two stages at a time are
 // done in registers (radix-4 step: 4 loads, 4 butterflies, 4 stores) so the tile makes half as many LDS
 // round trips and barriers as a radix-2 sweep; an odd last stage is a plain radix-2 step.
-__device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r, uint32_t c_log, const void* stage_tw) {
+__device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r, uint32_t c_log, const void* stage_tw, bool quarter_input) {
     const uint32_t C = 1u << c_log;
     uint32_t s = 0;
+    if (quarter_input && r >= 2) {
+        // coeff_to_extended with extended_k >= k + 2: rows >= R/4 of the first pass are the zero padding, i.e. (rows are stored bit-reversed) only
+        // every 4th position of the tile is non-zero and the first two stages just copy it to its three neighbours — no arithmetic
+        const uint32_t nq = (1u << (r - 2)) << c_log;
+        for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) {
+            const uint32_t col = q & (C - 1), bq = q >> c_log;
+            const uint32_t i0 = (bq << 2) * C + col;
+            const u256 x0 = lds_get(lo, hi, i0);
+            lds_put(lo, hi, i0 + C, x0);
+            lds_put(lo, hi, i0 + 2 * C, x0);
+            lds_put(lo, hi, i0 + 3 * C, x0);
+        }
+        __syncthreads();
+        s = 2;
+    }
     for (; s + 1 < r; s += 2) {
         const uint32_t h = 1u << s;
         const uint32_t nq = (1u << (r - 2)) << c_log;  // quads per step in the tile
@@ -147,7 +163,7 @@ ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
         lds_put(lo, hi, bitrev(row, a.r) * C + col, ntt_load_input(a, idx));
     }
     __syncthreads();
-    ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw);
+    ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw, a.quarter_input != 0);
     const uint32_t sh = a.log_n - a.blk_log;
     const uint32_t lomask = (1u << a.lo_bits) - 1;
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
@@ -185,7 +201,7 @@ ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
         lds_put(lo, hi, bitrev(row, a.r) * C + col, ntt_load_input(a, (o << a.r) + row));
     }
     __syncthreads();
-    ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw);
+    ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw, a.quarter_input != 0);
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
         const uint32_t col = e & (C - 1), row = e >> a.c_log;
         const size_t out_idx = (size_t)(j10 + col) + (((size_t)jm + ((size_t)row << a.p_log)) << a.q_log);
@@ -389,7 +405,7 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
         }
         a.log_n = log_n; a.blk_log = blk_log; a.r = ts->radix_log[p];
         a.stage_tw = ts->d_stage[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits; a.tw_full = last ? nullptr : ts->d_full[p];
-        if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; }
+        if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; a.quarter_input = tn.ntt_quarter_input && nf.n_valid && (size_t)nf.n_valid * 4 <= N && a.r >= 2; }
         if (last) { a.post_scale = nf.post_scale; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
         const uint32_t room = tl > a.r ? tl - a.r : 0;
         if (!last) {

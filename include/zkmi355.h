@@ -88,6 +88,10 @@ int zk_msm_batch_dev(zk_ctx* ctx, uint64_t bases, const void* const* scalars_dev
  * results of the ranks are exchanged (RCCL all-gather) and combined with zk_g1_sum_xyzz. */
 int zk_msm_partial_dev(zk_ctx* ctx, uint64_t bases, const void* scalars_dev, size_t n, void* out_xyzz_host);
 int zk_g1_sum_xyzz(const void* xyzz_host, size_t count, void* out_jacobian);
+/* the same for a whole commitment phase: `count` columns against one (sharded) table, out_xyzz_host = count x 128 B; and the combination of the
+ * `parts` ranks' results (xyzz_host laid out [part][column], as an all-gather delivers them) into count normalised points (count x 96 B). */
+int zk_msm_batch_partial_dev(zk_ctx* ctx, uint64_t bases, const void* const* scalars_dev, size_t count, size_t n, void* out_xyzz_host);
+int zk_g1_sum_xyzz_batch(const void* xyzz_host, size_t parts, size_t count, void* out_jacobian);
 
 /* fixed-base batch: out[i] = [s_i] * G1::generator(), affine.  Replaces the n fixed-base
  * multiplications of ParamsKZG::setup (halo2_proofs src/poly/kzg/commitment.rs), reached from

@@ -39,3 +39,44 @@ def run(rank: int, world: int, port: int, n: int, out_dir: str):
     dist.barrier()
     dist.destroy_process_group()
     be.close()
+
+
+def run_sharded_proof(rank: int, world: int, port: int, out_dir: str):
+    """create_proof with the SRS tables sharded over `world` gloo ranks (every commitment = partial MSMs + all_gather of 128-byte points):
+    every rank must emit the golden proof bytes of the single-GPU prover."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import zk_dcap_verifier_amd as z
+    from zk_dcap_verifier_amd import plonk
+    from zk_dcap_verifier_amd.transcript import Blake2bWrite
+    from conftest import EMU_SO
+    import test_create_proof as tcp
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    be = z.Backend(0, lib_path=EMU_SO)
+    be.tune(msm_sort_threads=64, msm_sort_wgs=3, msm_block=32, ntt_threads=32, ntt_tile_log=6, ntt_max_radix_log=4, msm_target_threads=64, msm_min_chunk=2,
+            vec_block=32, quot_threads=32)
+
+    def all_gather(part):
+        mine = torch.from_numpy(np.ascontiguousarray(part).view(np.int64).copy())
+        out = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(out, mine)
+        return torch.stack(out).numpy().view(np.uint64)
+    k = 6
+    full = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
+    params = z.kzg.ParamsKZG.sharded(k, full.g_host, full.g_lagrange_host, rank, world, all_gather, backend=be)
+    full.release()
+    cs, fixed, asm, advice, instances = tcp.toy_circuit(k)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    tr = Blake2bWrite()
+    plonk.create_proof(params, pk, advice, instances, np.random.default_rng(7), tr)
+    ok = tr.finalize() == tcp._golden()
+    np.save(os.path.join(out_dir, f"proof_rank{rank}.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+    be.close()

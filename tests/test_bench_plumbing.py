@@ -97,3 +97,41 @@ def test_bench_two_ranks_gloo(built, tmp_path):
     line = json.loads(out0[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["extra"]["msm_sharded_2^7"]["closed_form_check"] is True, line["extra"]
     assert open(tmp_path / "rank1.txt").read().strip() == ""
+
+
+def _bench_rank_prove(rank, world, port, out_dir):
+    import io
+    import contextlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      ZK_BENCH_PLUMBING_TEST="1", ZK_BENCH_SHARDED_LOG_N="7")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import zk_dcap_verifier_amd as z
+    import bench
+    import sgx_shaped_circuit as sgx
+    z._lib.LIB_PATH = EMU_SO
+    sgx.N_GATE_COLS, sgx.N_LOOKUP_COLS, sgx.N_FIXED, sgx.N_GATES = 2, 2, 7, 3
+    real_init = z.Backend.__init__
+
+    def small_init(self, device=0, lib_path=None):
+        real_init(self, device, lib_path)
+        self.tune(msm_sort_threads=32, msm_sort_wgs=2, msm_block=32, ntt_threads=32, ntt_tile_log=6, ntt_max_radix_log=4,
+                  msm_target_threads=64, msm_min_chunk=2, vec_block=32, quot_threads=32)
+    z.Backend.__init__ = small_init
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "0", "--k", "6", "--inflight", "1"])
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(buf.getvalue())
+
+
+def test_bench_prove_mode_two_ranks_sharded_proof(built, tmp_path):
+    """N = 2 in the default mode: replicas prove their own streams, then ONE proof is spread over both ranks (sharded SRS tables,
+    all-gathered partial commitments) and must be byte-identical to the single-device proof of the same RNG stream."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_bench_rank_prove, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    line = json.loads([l for l in open(tmp_path / "rank0.txt").read().strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["mode"] == "prove"
+    assert line["extra"]["sharded_proof"]["identical_to_single_gpu_proof"] is True, line["extra"]
+    assert line["extra"]["msm_sharded_2^7"]["closed_form_check"] is True

@@ -23,3 +23,12 @@ def test_sharded_msm_two_ranks_gloo(built):
         mp.spawn(multi_rank_worker.run, args=(2, _free_port(), 150, d), nprocs=2, join=True)
         for r in range(2):
             assert np.load(os.path.join(d, f"rank{r}.npy"))[0] == 1
+
+
+def test_sharded_create_proof_two_ranks_gloo(built):
+    """SURVEY §8e / BASELINE configs[4]: the prover with BOTH SRS tables sharded by index range over two ranks — every commitment of the proof is
+    two partial MSMs + one all_gather — emits byte for byte the golden proof of the single-device prover, on every rank."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(multi_rank_worker.run_sharded_proof, args=(2, _free_port(), d), nprocs=2, join=True)
+        for r in range(2):
+            assert np.load(os.path.join(d, f"proof_rank{r}.npy"))[0] == 1

@@ -226,6 +226,25 @@ class Backend:
         self._ck(self.lib.zk_msm_partial_dev(self.ctx, C.c_uint64(handle), C.c_void_p(_dptr(scalars_dev)), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def msm_batch_partial(self, handle: int, columns, n: int) -> np.ndarray:
+        """unnormalised XYZZ partial results (count, 16) of `count` device columns against a (sharded) table"""
+        count = len(columns)
+        out = np.zeros((count, 16), dtype=np.uint64)
+        if count:
+            arr = (C.c_void_p * count)(*[_dptr(c) for c in columns])
+            self._ck(self.lib.zk_msm_batch_partial_dev(self.ctx, C.c_uint64(handle), arr, C.c_size_t(count), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def g1_sum_xyzz_batch(self, parts: np.ndarray) -> np.ndarray:
+        """parts: (n_parts, count, 16) partial sums as gathered from the ranks -> (count, 12) normalised points"""
+        parts = np.ascontiguousarray(parts, dtype=np.uint64)
+        n_parts, count = parts.shape[0], parts.shape[1]
+        out = np.zeros((count, 12), dtype=np.uint64)
+        rc = self.lib.zk_g1_sum_xyzz_batch(parts.ctypes.data_as(C.c_void_p), C.c_size_t(n_parts), C.c_size_t(count), out.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise ZkError(rc, "zk_g1_sum_xyzz_batch")
+        return out
+
     def g1_sum_xyzz(self, parts: np.ndarray) -> np.ndarray:
         parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(-1, 16)
         out = np.zeros(12, dtype=np.uint64)

@@ -162,6 +162,17 @@ int zk_msm_dev(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { EN
 int zk_msm_batch(zk_ctx* ctx, uint64_t b, const void* const* s, size_t count, size_t n, void* out) { ENTER; return msm_run_batch(ctx, b, s, count, n, false, out, 0); }
 int zk_msm_batch_dev(zk_ctx* ctx, uint64_t b, const void* const* s, size_t count, size_t n, void* out) { ENTER; return msm_run_batch(ctx, b, s, count, n, true, out, 0); }
 int zk_msm_partial_dev(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { ENTER; return msm_run(ctx, b, s, n, true, out, 1); }
+int zk_msm_batch_partial_dev(zk_ctx* ctx, uint64_t b, const void* const* s, size_t count, size_t n, void* out) { ENTER; return msm_run_batch(ctx, b, s, count, n, true, out, 1); }
+int zk_g1_sum_xyzz_batch(const void* xyzz, size_t parts, size_t count, void* out) {
+    if (!xyzz || !out) return ZK_ERR_ARG;
+    for (size_t c = 0; c < count; c++) {   // column c of every part: xyzz[(p * count + c)]
+        std::vector<unsigned char> col(parts * 128);
+        for (size_t p = 0; p < parts; p++) memcpy(&col[p * 128], (const char*)xyzz + (p * count + c) * 128, 128);
+        int rc = g1_sum_xyzz_host(col.data(), parts, (char*)out + c * 96);
+        if (rc) return rc;
+    }
+    return ZK_OK;
+}
 int zk_g1_sum_xyzz(const void* xyzz, size_t count, void* out) { if (!xyzz || !out) return ZK_ERR_ARG; return g1_sum_xyzz_host(xyzz, count, out); }
 int zk_g1_fixed_base_mul_dev(zk_ctx* ctx, const void* s, size_t n, void* out) { ENTER; return g1_fixed_base_mul(ctx, s, n, out); }
 

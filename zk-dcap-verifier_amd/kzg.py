@@ -85,6 +85,41 @@ class ParamsKZG:
         self.g2, self.s_g2 = data[-128:-64], data[-64:]
         return self
 
+    # -- multi-GPU: base tables sharded by index range, partial points combined after an all-gather --------------------------------
+    world, rank, lo, n_loc, all_gather = 1, 0, 0, None, None
+
+    @classmethod
+    def sharded(cls, k: int, g: np.ndarray, g_lagrange: np.ndarray, rank: int, world: int, all_gather, backend: Backend | None = None) -> "ParamsKZG":
+        """Rank `rank` of `world` holds bases [rank * n / world, (rank + 1) * n / world) of both tables (window-expanded in ITS HBM only).
+        `all_gather(partials: (count, 16) uint64) -> (world, count, 16)` exchanges the 128-byte XYZZ partial sums — one RCCL all_gather per
+        commitment phase; EC addition is not an RCCL reduction, so every rank adds the world partial points itself."""
+        be = backend or default_backend()
+        n = 1 << k
+        assert n % world == 0 and 0 <= rank < world
+        g = np.ascontiguousarray(g, dtype=np.uint64).reshape(n, 8)
+        g_lagrange = np.ascontiguousarray(g_lagrange, dtype=np.uint64).reshape(n, 8)
+        self = cls.__new__(cls)
+        self.backend, self.k, self.n = be, k, n
+        self.world, self.rank, self.n_loc, self.all_gather = world, rank, n // world, all_gather
+        self.lo = rank * self.n_loc
+        self.g_host, self.g_lagrange_host = g, g_lagrange
+        self.g = BasesHandle(be, np.ascontiguousarray(g[self.lo:self.lo + self.n_loc]))
+        self.g_lagrange = BasesHandle(be, np.ascontiguousarray(g_lagrange[self.lo:self.lo + self.n_loc]))
+        return self
+
+    def commit_columns(self, which: str, cols) -> np.ndarray:
+        """[commit(col) for col in cols] against `g` or `g_lagrange` for DEVICE columns of n scalars -> (count, 12) normalised points.
+        One device call per rank; with sharded tables each rank multiplies its index range and the partial points are all-gathered."""
+        from ._lib import _dptr
+        h = self.g if which == "g" else self.g_lagrange
+        be = self.backend
+        if not len(cols):
+            return np.zeros((0, 12), dtype=np.uint64)
+        if self.world == 1:
+            return be.msm_batch(h.handle, list(cols), self.n)
+        part = be.msm_batch_partial(h.handle, [_dptr(c) + self.lo * 32 for c in cols], self.n_loc)
+        return be.g1_sum_xyzz_batch(self.all_gather(part))
+
     def commit(self, poly: np.ndarray) -> np.ndarray:
         poly = np.asarray(poly, dtype=np.uint64).reshape(-1, 4)
         assert poly.shape[0] <= self.n

@@ -139,8 +139,8 @@ def keygen(params: ParamsKZG, cs: ConstraintSystem, fixed_columns, assembly: Opt
         sigma_values = [be.to_device(np.ascontiguousarray(sig[j])) for j in range(m)]
 
     # commitments (keygen_vk): commit_lagrange of every fixed and sigma column — one batched MSM each
-    fc = params.backend.msm_batch(params.g_lagrange.handle, fixed_values, n) if fixed_values else np.zeros((0, 12), np.uint64)
-    pc = params.backend.msm_batch(params.g_lagrange.handle, sigma_values, n) if sigma_values else np.zeros((0, 12), np.uint64)
+    fc = params.commit_columns("g_lagrange", fixed_values)
+    pc = params.commit_columns("g_lagrange", sigma_values)
     fixed_commitments = [g1_affine_ints(r) for r in fc]
     permutation_commitments = [g1_affine_ints(r) for r in pc]
     h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")

@@ -73,8 +73,8 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
         owned.append(d)
         return d
 
-    def commit_all(handle, cols):
-        return [g1_affine_ints(r) for r in be.msm_batch(handle, cols, n)] if cols else []
+    def commit_all(which, cols):                                 # one device call per transcript phase (all-gathered when the tables are sharded)
+        return [g1_affine_ints(r) for r in params.commit_columns(which, cols)]
 
     # ---- 1. vk, instances ---------------------------------------------------------------------------------------------
     pk.vk.hash_into(transcript)
@@ -102,7 +102,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
             d = col
         d.upload(blind, offset=usable * 32)
         adv_values.append(d)
-    for pt in commit_all(params.g_lagrange.handle, adv_values):
+    for pt in commit_all("g_lagrange", adv_values):
         transcript.write_point(pt)
 
     lap("2_advice_commit")
@@ -132,7 +132,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     for a_, s_ in permuted:
         owned += [a_, s_]
     flat = [c for pr in permuted for c in pr]
-    for pt in commit_all(params.g_lagrange.handle, flat):           # per lookup: permuted input, permuted table
+    for pt in commit_all("g_lagrange", flat):           # per lookup: permuted input, permuted table
         transcript.write_point(pt)
 
     lap("3_lookup_permuted")
@@ -151,14 +151,14 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     lzs = lookup_commit_products([(c[0], c[1], p_[0], p_[1]) for c, p_ in zip(compressed, permuted)], k, bt_m, gm_m,
                                  np.stack([rand_fr_array(rng, bf) for _ in compressed]) if compressed else np.zeros((0, bf, 4), np.uint64), backend=be)
     owned += lzs
-    for pt in commit_all(params.g_lagrange.handle, zs + lzs):      # permutation products, then lookup products: one MSM batch, transcript order kept
+    for pt in commit_all("g_lagrange", zs + lzs):      # permutation products, then lookup products: one MSM batch, transcript order kept
         transcript.write_point(pt)
 
     lap("4_grand_products")
     # ---- 5. vanishing argument: random polynomial -----------------------------------------------------------------------------
     random_poly = dev(n * 32)
     random_poly.upload(rand_fr_array(rng, n))
-    transcript.write_point(g1_affine_ints(be.msm(params.g.handle, random_poly, n)))
+    transcript.write_point(commit_all("g", [random_poly])[0])
 
     lap("5_random_poly")
     # ---- 6. y; everything to coefficient form; h(X) ------------------------------------------------------------------------------
@@ -185,7 +185,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     be.extended_to_coeff_dev(h_ext, k, ek)
     n_pieces = dom.quotient_poly_degree
     pieces = [h_ext.ptr + i * n * 32 for i in range(n_pieces)]
-    for pt in commit_all(params.g.handle, pieces):
+    for pt in commit_all("g", pieces):
         transcript.write_point(pt)
 
     lap("7_h_construct_commit")

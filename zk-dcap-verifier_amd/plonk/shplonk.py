@@ -124,7 +124,7 @@ class ProverSHPLONK:
         be.fr_lincomb_dev(quotients, fr_mont_array(vp), n, h_x)
         for qd in quotients:
             qd.free()
-        transcript.write_point(g1_affine_ints(be.msm(self.params.g.handle, h_x, n)))
+        transcript.write_point(g1_affine_ints(self.params.commit_columns("g", [h_x])[0]))
         u = transcript.squeeze_challenge()
 
         # L(X) = sum_i v^i z_i sum_j y^j (P_ij(X) - R_ij(u)) - Z_T(u) h(X), normalised by z_0, then divided by (X - u)
@@ -149,6 +149,6 @@ class ProverSHPLONK:
         be.fr_lincomb_dev(polys + [rbuf], fr_mont_array([s * z0_inv % R_MOD for s in scal] + [1]), n, tmp[0])
         be.kate_division_dev(tmp[0], n, fr_mont(u), tmp[1])
         tmp[1].upload(zero_tail[:1], offset=(n - 1) * 32)
-        transcript.write_point(g1_affine_ints(be.msm(self.params.g.handle, tmp[1], n)))
+        transcript.write_point(g1_affine_ints(self.params.commit_columns("g", [tmp[1]])[0]))
         for d in (h_x, rbuf, tmp[0], tmp[1]):
             d.free()

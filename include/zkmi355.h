@@ -217,6 +217,12 @@ int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog);
 /* size of the compiled micro-program: instructions, live-value slots (first 3 are registers, rest LDS), columns */
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
 int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args);
+/* The same on ONE coset of the extended domain (the rows coset, coset + 2^(extended_k-k), ...): every column of `args` holds that coset's n = 2^k values
+ * (zk_coeff_to_coset_batch_dev), args->out receives the coset's n numerator values.  The 2^(extended_k-k) cosets are independent, so the quotient of a
+ * proof can be split over GPUs; zk_fr_interleave_dev puts the gathered cosets back into the order Evaluator::evaluate_h returns. */
+int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset);
+int zk_coeff_to_coset_batch_dev(zk_ctx* ctx, const void* const* coeffs_dev, void* const* outs_dev, size_t count, uint32_t k, uint32_t extended_k, uint32_t coset);
+int zk_fr_interleave_dev(zk_ctx* ctx, const void* const* cosets_dev, size_t count, size_t n, void* out_dev);   /* out[i * count + j] = cosets[j][i] */
 
 /* proving-key level form — the shape of halo2's own call (polynomials in, polynomial out):
  * zk_pk_load uploads what keygen_pk holds for the evaluator — fixed columns, permutation (sigma) columns, l0, l_last,

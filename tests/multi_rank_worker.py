@@ -73,9 +73,26 @@ def run_sharded_proof(rank: int, world: int, port: int, out_dir: str):
     full.release()
     cs, fixed, asm, advice, instances = tcp.toy_circuit(k)
     pk = plonk.keygen(params, cs, fixed, asm)
+    assert sorted(pk.coset_parts) == params.my_cosets(1 << (pk.domain.extended_k - k))       # the quotient is sharded by coset
     tr = Blake2bWrite()
     plonk.create_proof(params, pk, advice, instances, np.random.default_rng(7), tr)
     ok = tr.finalize() == tcp._golden()
+
+    # the same with the numerators exchanged in "device" memory the caller owns (torch tensors; under the emulator device memory is host memory)
+    held = {}
+
+    def coset_exchange(nbytes):
+        if held.get("n") != nbytes:
+            held.update(n=nbytes, send=torch.zeros(nbytes // 8, dtype=torch.int64), recv=torch.zeros(world * nbytes // 8, dtype=torch.int64))
+
+        def run():
+            be.sync()
+            dist.all_gather_into_tensor(held["recv"], held["send"])
+        return held["send"].data_ptr(), held["recv"].data_ptr(), run
+    params.coset_exchange = coset_exchange
+    tr = Blake2bWrite()
+    plonk.create_proof(params, pk, advice, instances, np.random.default_rng(7), tr)
+    ok = ok and tr.finalize() == tcp._golden() and "send" in held
     np.save(os.path.join(out_dir, f"proof_rank{rank}.npy"), np.array([int(ok)]))
     dist.barrier()
     dist.destroy_process_group()

@@ -134,4 +134,5 @@ def test_bench_prove_mode_two_ranks_sharded_proof(built, tmp_path):
     line = json.loads([l for l in open(tmp_path / "rank0.txt").read().strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["mode"] == "prove"
     assert line["extra"]["sharded_proof"]["identical_to_single_gpu_proof"] is True, line["extra"]
+    assert line["extra"]["sharded_proof"]["quotient_exchange"] == "device", line["extra"]       # numerators gathered between "device" buffers
     assert line["extra"]["msm_sharded_2^7"]["closed_form_check"] is True

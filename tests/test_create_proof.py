@@ -164,7 +164,7 @@ def test_create_proof_negative_controls_gpu(gpu, orc, what):
     _rejects(gpu, 9, what)
 
 
-def _sgx_shaped(be, k):
+def _sgx_shaped(be, k, by_cosets=False):
     """The circuit shape bench.py proves at k = 19 (25 advice, 18 fixed, 11 lookups of 4-5 expressions, 16 equality columns,
     24 gates, degree 5; tools/sgx_shaped_circuit.py) at a size the Python verifier handles in a second."""
     import os, sys
@@ -179,6 +179,13 @@ def _sgx_shaped(be, k):
     tr = Blake2bWrite()
     info = plonk.create_proof(params, pk, advice, [], np.random.default_rng(3), tr)
     proof = tr.finalize()
+    if by_cosets:                       # the multi-GPU quotient unit (all four cosets on this rank): same bytes as the whole-domain quotient
+        params.quotient_by_cosets = True
+        pk2 = plonk.keygen(params, cs, fixed, asm)
+        tr2 = Blake2bWrite()
+        plonk.create_proof(params, pk2, advice, [], np.random.default_rng(3), tr2)
+        assert tr2.finalize() == proof
+        pk2.release()
     assert info["commitments"] == 71 and len(proof) == 32 * (71 + info["evals"])
     assert verifier.verify_proof(pk.vk, TAU, [], proof) is True
     bad = bytearray(proof)
@@ -189,7 +196,13 @@ def _sgx_shaped(be, k):
 
 
 def test_sgx_shaped_circuit_proof_verifies_emulated(emu, orc):
-    _sgx_shaped(emu, 6)
+    _sgx_shaped(emu, 6, by_cosets=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [12, 19])
+def test_sgx_shaped_circuit_quotient_by_cosets_gpu(gpu, orc, k):
+    _sgx_shaped(gpu, k, by_cosets=True)
 
 
 @pytest.mark.gpu
@@ -286,3 +299,27 @@ def test_p256_ecdsa_shaped_proof_has_the_layout_of_proof_bin_emulated(emu, orc):
 @pytest.mark.gpu
 def test_p256_ecdsa_shaped_proof_has_the_layout_of_proof_bin_gpu(gpu, orc):
     _p256_shape(gpu, 12)
+
+
+def _by_cosets_proof(be, k=6):
+    """The quotient taken coset by coset (the multi-GPU sharding unit, here all cosets on one rank) must give the same proof bytes."""
+    import zk_dcap_verifier_amd as z
+    params = z.kzg.ParamsKZG.setup(k, TAU, backend=be)
+    params.quotient_by_cosets = True
+    cs, fixed, asm, advice, instances = toy_circuit(k)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    assert pk.coset_parts is not None and not pk.fixed_cosets
+    tr = Blake2bWrite()
+    plonk.create_proof(params, pk, advice, instances, np.random.default_rng(7), tr)
+    pk.release()
+    params.release()
+    return tr.finalize()
+
+
+def test_emulated_quotient_by_cosets_gives_golden_proof(emu):
+    assert _by_cosets_proof(emu) == _golden()
+
+
+@pytest.mark.gpu
+def test_gpu_quotient_by_cosets_gives_golden_proof(gpu):
+    assert _by_cosets_proof(gpu) == _golden()

@@ -301,6 +301,14 @@ class Backend:
         assert len(coeffs) == len(outs)
         self._ck(self.lib.zk_coeff_to_extended_batch_dev(self.ctx, self._ptr_array(coeffs), self._ptr_array(outs), C.c_size_t(len(outs)), C.c_uint32(k), C.c_uint32(ek)))
 
+    def coeff_to_coset_batch_dev(self, coeffs, outs, k, ek, coset: int):
+        assert len(coeffs) == len(outs)
+        self._ck(self.lib.zk_coeff_to_coset_batch_dev(self.ctx, self._ptr_array(coeffs), self._ptr_array(outs), C.c_size_t(len(outs)), C.c_uint32(k), C.c_uint32(ek),
+                                                      C.c_uint32(coset)))
+
+    def fr_interleave_dev(self, cosets, n: int, out_dev):
+        self._ck(self.lib.zk_fr_interleave_dev(self.ctx, self._ptr_array(cosets), C.c_size_t(len(cosets)), C.c_size_t(n), C.c_void_p(_dptr(out_dev))))
+
     def coeff_to_extended_dev(self, coeff_dev, k, ek, out_dev):
         self._ck(self.lib.zk_coeff_to_extended_dev(self.ctx, C.c_void_p(_dptr(coeff_dev)), C.c_uint32(k), C.c_uint32(ek), C.c_void_p(_dptr(out_dev))))
 
@@ -410,7 +418,7 @@ class Backend:
         self._ck(self.lib.zk_quotient_program_release(self.ctx, C.c_uint64(prog)))
 
     def quotient_run_dev(self, prog: int, *, fixed, advice, instance, l0, l_last, l_active_row, perm_cosets, perm_products,
-                         lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out):
+                         lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out, coset: int | None = None):
         keep = []
 
         def parr(cols):
@@ -424,7 +432,10 @@ class Backend:
                          parr(perm_cosets), parr(perm_products), len(perm_products),
                          parr(lookup_product), parr(lookup_input), parr(lookup_table),
                          ch.ctypes.data, sc[0].ctypes.data, sc[1].ctypes.data, sc[2].ctypes.data, sc[3].ctypes.data, _dptr(out))
-        self._ck(self.lib.zk_quotient_run_dev(self.ctx, C.c_uint64(prog), C.byref(a)))
+        if coset is None:
+            self._ck(self.lib.zk_quotient_run_dev(self.ctx, C.c_uint64(prog), C.byref(a)))
+        else:
+            self._ck(self.lib.zk_quotient_run_coset_dev(self.ctx, C.c_uint64(prog), C.byref(a), C.c_uint32(coset)))
 
 
 def _host_ptrs(cols):

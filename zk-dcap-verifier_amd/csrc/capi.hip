@@ -43,7 +43,9 @@ int g1_ntt(zk_ctx* ctx, const void* d_affine_in, uint32_t log_n, const void* ome
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
-int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args);
+int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, int coset);
+int domain_coeff_to_coset_batch(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek, uint32_t coset);
+int fr_interleave(zk_ctx* ctx, const void* const* h_cosets, size_t count, size_t n, void* d_out);
 }  // namespace zk
 using namespace zk;
 
@@ -220,6 +222,10 @@ int zk_lagrange_to_coeff_batch_dev(zk_ctx* ctx, void* const* cols, size_t count,
 int zk_coeff_to_extended_batch_dev(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek) {
     ENTER; int rc = domain_coeff_to_extended_batch(ctx, coeffs, outs, count, k, ek); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
 }
+int zk_coeff_to_coset_batch_dev(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek, uint32_t coset) {
+    ENTER; int rc = domain_coeff_to_coset_batch(ctx, coeffs, outs, count, k, ek, coset); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
+}
+int zk_fr_interleave_dev(zk_ctx* ctx, const void* const* cosets, size_t count, size_t n, void* out) { ENTER; return fr_interleave(ctx, cosets, count, n, out); }
 int zk_lagrange_to_coeff_dev(zk_ctx* ctx, void* a, uint32_t k) { ENTER; int rc = domain_lagrange_to_coeff(ctx, a, k); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
 int zk_coeff_to_lagrange_dev(zk_ctx* ctx, void* a, uint32_t k) { ENTER; int rc = domain_coeff_to_lagrange(ctx, a, k); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
 int zk_coeff_to_extended_dev(zk_ctx* ctx, const void* c, uint32_t k, uint32_t ek, void* out) { ENTER; int rc = domain_coeff_to_extended(ctx, c, k, ek, out); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
@@ -302,7 +308,8 @@ int zk_fr_lincomb_dev(zk_ctx* ctx, const void* const* polys_dev, const void* sca
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog) { ENTER; return quotient_program_load(ctx, blob, len, prog); }
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* ni, uint32_t* ns, uint32_t* nc) { ENTER; return quotient_program_info(ctx, prog, ni, ns, nc); }
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog) { ENTER; return quotient_program_release(ctx, prog); }
-int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args); }
+int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args, -1); }
+int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset) { ENTER; return quotient_run(ctx, prog, args, (int)coset); }
 
 int zk_pk_load(zk_ctx* ctx, uint64_t prog, const void* const* fixed, const void* const* sigma, const void* l0, const void* l_last, const void* l_active,
                int form, uint64_t* pk) { ENTER; return pk_load(ctx, prog, fixed, sigma, l0, l_last, l_active, form, pk); }

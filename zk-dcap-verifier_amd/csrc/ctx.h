@@ -140,6 +140,7 @@ struct NttFuse {              // optional fused pre/post operations (EvaluationD
     int post_scale = 0;        // output *= scale
     u256 scale;
     int post_zeta_inv = 0;     // output i *= ZETA^-(i mod 3)          (extended_to_coeff)
+    const void* cs_lo = nullptr; const void* cs_hi = nullptr; uint32_t cs_lo_bits = 0, cs_stride = 0, cs_log = 0;   // coset pre-scaling (ntt.hip)
 };
 int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const NttFuse* fuse);
 void release_twiddles(zk_ctx* ctx);

@@ -16,6 +16,8 @@
 
 namespace zk {
 
+int ntt_pow_tables(zk_ctx* ctx, uint32_t log_n, const u256& omega, const void** lo, const void** hi, uint32_t* lo_bits);
+
 struct NttPassArgs {
     const void* src;
     void* dst;
@@ -35,6 +37,8 @@ struct NttPassArgs {
     // fused operations
     uint32_t n_valid;       // first pass only (0 = all)
     int quarter_input;      // first pass only: n_valid <= N / 4, so rows >= R/4 of every tile are zero
+    // first pass only: input i *= w^((cs_stride * i) mod 2^cs_log) with w's two-level power tables (coset NTT: w = extended_omega, stride = coset)
+    const void* cs_lo; const void* cs_hi; uint32_t cs_lo_bits; uint32_t cs_stride; uint32_t cs_log;
     int pre_zeta;
     int post_scale;
     int post_zeta_inv;
@@ -59,6 +63,15 @@ ZK_HD u256 ntt_load_input(const NttPassArgs& a, size_t idx) {
     if (a.pre_zeta) {
         uint32_t m = (uint32_t)idx % 3u;
         if (m) v = Fr::mul(v, zeta_pow(m));
+    }
+    if (a.cs_stride) {
+        const uint32_t e = (a.cs_stride * (uint32_t)idx) & ((1u << a.cs_log) - 1u);
+        if (e) {
+            u256 w = load_u256(a.cs_lo, e & ((1u << a.cs_lo_bits) - 1u));
+            const uint32_t h = e >> a.cs_lo_bits;
+            if (h) w = Fr::mul(w, load_u256(a.cs_hi, h));
+            v = Fr::mul(v, w);
+        }
     }
     return v;
 }
@@ -405,6 +418,7 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
         }
         a.log_n = log_n; a.blk_log = blk_log; a.r = ts->radix_log[p];
         a.stage_tw = ts->d_stage[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits; a.tw_full = last ? nullptr : ts->d_full[p];
+        if (first && nf.cs_stride) { a.cs_lo = nf.cs_lo; a.cs_hi = nf.cs_hi; a.cs_lo_bits = nf.cs_lo_bits; a.cs_stride = nf.cs_stride; a.cs_log = nf.cs_log; }
         if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; a.quarter_input = tn.ntt_quarter_input && nf.n_valid && (size_t)nf.n_valid * 4 <= N && a.r >= 2; }
         if (last) { a.post_scale = nf.post_scale; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
         const uint32_t room = tl > a.r ? tl - a.r : 0;
@@ -473,6 +487,37 @@ int domain_coeff_to_extended_batch(zk_ctx* ctx, const void* const* coeffs, void*
     NttFuse f;
     f.n_valid = 1u << k; f.pre_zeta = 1;
     return ntt_dev_batch(ctx, outs, coeffs, count, ek, domain_omega(ek), &f);
+}
+// evaluations of `count` polynomials (n = 2^k coefficients each) on coset `coset` of the extended domain: out[i] = f(ZETA * ext_omega^(i * 2^(ek-k) + coset)),
+// i.e. every 2^(ek-k)-th entry of coeff_to_extended starting at `coset` — one size-n NTT of f_m * ZETA^(m mod 3) * ext_omega^(coset * m)
+int domain_coeff_to_coset_batch(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek, uint32_t coset) {
+    if (ek > BN254_FR_S || k > ek || !coeffs || !outs || coset >= (1u << (ek - k))) return ctx->fail(ZK_ERR_ARG, "zk_coeff_to_coset: bad k/extended_k/coset/pointer");
+    NttFuse f;
+    f.pre_zeta = 1;
+    if (coset) {
+        int rc = ntt_pow_tables(ctx, ek, domain_omega(ek), &f.cs_lo, &f.cs_hi, &f.cs_lo_bits);
+        if (rc) return rc;
+        f.cs_stride = coset; f.cs_log = ek;
+    }
+    return ntt_dev_batch(ctx, outs, coeffs, count, k, domain_omega(k), &f);
+}
+// out[i * count + j] = cosets[j][i]: the 2^e cosets of the extended domain back into its natural (interleaved) order
+ZK_KERNEL void fr_interleave_kernel(const void* const* cosets, uint32_t count, size_t n, void* out) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = n * count, stride = (size_t)gridDim.x * blockDim.x;
+    for (; idx < total; idx += stride) store_u256(out, idx, load_u256(cosets[idx % count], idx / count));
+}
+int fr_interleave(zk_ctx* ctx, const void* const* h_cosets, size_t count, size_t n, void* d_out) {
+    if (!h_cosets || !d_out || count == 0 || count > 64) return ctx->fail(ZK_ERR_ARG, "zk_fr_interleave_dev: bad argument");
+    for (size_t j = 0; j < count; j++) if (!h_cosets[j]) return ctx->fail(ZK_ERR_ARG, "zk_fr_interleave_dev: null coset %zu", j);
+    ZK_HIP(ctx->ws_tmp.ensure(count * sizeof(void*) + 64));
+    ZK_HIP(hipMemcpyAsync(ctx->ws_tmp.p, h_cosets, count * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    const int blk = ctx->tune.vec_block;
+    size_t grid = (n * count + blk - 1) / blk; if (grid > 8192) grid = 8192;
+    ZK_LAUNCH(fr_interleave_kernel, (uint32_t)grid, blk, 0, ctx->stream, (const void* const*)ctx->ws_tmp.p, (uint32_t)count, n, d_out);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
 }
 int domain_coeff_to_lagrange(zk_ctx* ctx, void* d_a, uint32_t k) {
     if (k > BN254_FR_S) return ctx->fail(ZK_ERR_ARG, "k = %u > S", k);

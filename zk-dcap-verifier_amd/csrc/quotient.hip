@@ -71,6 +71,7 @@ struct QuotArgs {
     const void* tw_hi;
     uint32_t lo_bits;
     int uses_xpow;
+    uint32_t xpow_mul, xpow_add;   // X of row idx = extended_omega^(idx * xpow_mul + xpow_add): (1, 0) on the whole extended domain, (2^(ek-k), j) on coset j
     void* out;
 };
 
@@ -85,9 +86,10 @@ ZK_KERNEL void quotient_kernel(QuotArgs q) {
     const uint32_t mask = (1u << q.size_log) - 1u;
     u256 acc = Fr::zero(), xpow = Fr::one();
     u256 rg0 = Fr::zero(), rg1 = rg0, rg2 = rg0;   // slots 0..QUOT_NREG-1 live in VGPRs
-    if (q.uses_xpow) {  // extended_omega^idx
-        xpow = load_u256(q.tw_lo, idx & ((1u << q.lo_bits) - 1u));
-        const uint32_t h = idx >> q.lo_bits;
+    if (q.uses_xpow) {  // extended_omega^(position of this row in the extended domain)
+        const uint32_t xi = idx * q.xpow_mul + q.xpow_add;
+        xpow = load_u256(q.tw_lo, xi & ((1u << q.lo_bits) - 1u));
+        const uint32_t h = xi >> q.lo_bits;
         if (h) xpow = Fr::mul(xpow, load_u256(q.tw_hi, h));
     }
     auto prefetch = [&](uint32_t src) -> u256 {        // memory operands only; everything else is resolved later
@@ -639,7 +641,10 @@ int quotient_set_lds_attr() {
     return 0;
 }
 
-int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a) {
+// coset < 0: the whole extended domain (columns of 2^extended_k rows).  coset = j >= 0: only coset j of it — the rows j, j + 2^(ek-k), ... —
+// with columns given as that coset's n = 2^k values (zk_coeff_to_coset_batch_dev); rotations then step by one row.  The 2^(ek-k) cosets are
+// independent, which is what lets a proof's quotient be split over GPUs: out receives the n numerator values of the coset.
+int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int coset) {
     auto it = ctx->programs.find(prog);
     if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_dev: unknown program %llu", (unsigned long long)prog);
     QuotProgram& P = *it->second;
@@ -677,9 +682,11 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a) {
         u256 cur = Fr::mul(beta, zeta);
         for (uint32_t j = 0; j < P.n_perm_cols; j++) { consts[P.c_delta + j] = cur; cur = Fr::mul(cur, delta); }
     }
-    const uint32_t size_log = P.ek;
+    if (coset >= (int)(1u << (P.ek - P.k))) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_dev: coset %d out of range", coset);
+    const bool cm = coset >= 0;
+    const uint32_t size_log = cm ? P.k : P.ek;
     const uint64_t size = 1ull << size_log;
-    const int64_t rot_scale = 1ll << (P.ek - P.k);
+    const int64_t rot_scale = cm ? 1 : 1ll << (P.ek - P.k);
     std::vector<uint32_t> rot_off(P.rotations.size() + 1, 0);
     for (size_t i = 0; i < P.rotations.size(); i++) {
         int64_t v = ((int64_t)P.rotations[i] * rot_scale) % (int64_t)size;
@@ -695,6 +702,8 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a) {
     q.code = (const uint4*)P.d_code; q.n_instr = (uint32_t)P.code.size(); q.consts = P.d_consts;
     q.cols = (const void* const*)P.d_cols; q.rot_off = (const uint32_t*)P.d_rot; q.size_log = size_log; q.out = a->out;
     q.uses_xpow = P.uses_xpow ? 1 : 0;
+    q.xpow_mul = cm ? 1u << (P.ek - P.k) : 1u;
+    q.xpow_add = cm ? (uint32_t)coset : 0u;
     if (P.uses_xpow) {
         int rc = ntt_pow_tables(ctx, P.ek, domain_omega(P.ek), &q.tw_lo, &q.tw_hi, &q.lo_bits);
         if (rc) return rc;
@@ -857,7 +866,7 @@ int evaluate_h_host(zk_ctx* ctx, uint64_t pkh, const void* const* advice, const 
     qa.lookup_product = dyn + P.n_advice + P.n_instance + P.n_sets;
     qa.lookup_input = qa.lookup_product + P.n_lookups; qa.lookup_table = qa.lookup_input + P.n_lookups;
     qa.challenges = challenges; qa.beta = beta; qa.gamma = gamma; qa.theta = theta; qa.y = y; qa.out = pk->h_ext;
-    int rc = quotient_run(ctx, pk->prog, &qa);
+    int rc = quotient_run(ctx, pk->prog, &qa, -1);
     if (rc) return rc;
     size_t out_bytes = (size_t)32 << P.ek;
     if (finish) {

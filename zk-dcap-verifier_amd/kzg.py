@@ -87,12 +87,34 @@ class ParamsKZG:
 
     # -- multi-GPU: base tables sharded by index range, partial points combined after an all-gather --------------------------------
     world, rank, lo, n_loc, all_gather = 1, 0, 0, None, None
+    coset_exchange = None
+    quotient_by_cosets = False       # world == 1 only: take the coset-by-coset quotient path anyway (tests; the result is the same proof)
+
+    def by_cosets(self) -> bool:
+        return self.world > 1 or self.quotient_by_cosets
+
+    def my_cosets(self, n_cosets: int) -> list:
+        """The extended domain is 2^(extended_k - k) interleaved cosets of the 2^k domain; evaluate_h never mixes them (rotations stay inside
+        a coset), so they are the units the quotient shards by: rank r evaluates cosets [r * slots, (r + 1) * slots), slots = ceil(cosets / world)."""
+        slots = -(-n_cosets // self.world)
+        return [j for j in range(self.rank * slots, (self.rank + 1) * slots) if j < n_cosets]
+
+    def gather_cosets(self, mine: np.ndarray, n_cosets: int) -> np.ndarray:
+        """mine: (slots, n, 4) numerator values of this rank's cosets (unused slots zero) -> (n_cosets, n, 4), every rank's, in coset order."""
+        if self.world == 1:
+            return mine[:n_cosets]
+        return self.all_gather(mine).reshape(-1, mine.shape[1], 4)[:n_cosets]
 
     @classmethod
-    def sharded(cls, k: int, g: np.ndarray, g_lagrange: np.ndarray, rank: int, world: int, all_gather, backend: Backend | None = None) -> "ParamsKZG":
+    def sharded(cls, k: int, g: np.ndarray, g_lagrange: np.ndarray, rank: int, world: int, all_gather, backend: Backend | None = None,
+                coset_exchange=None) -> "ParamsKZG":
         """Rank `rank` of `world` holds bases [rank * n / world, (rank + 1) * n / world) of both tables (window-expanded in ITS HBM only).
         `all_gather(partials: (count, 16) uint64) -> (world, count, 16)` exchanges the 128-byte XYZZ partial sums — one RCCL all_gather per
-        commitment phase; EC addition is not an RCCL reduction, so every rank adds the world partial points itself."""
+        commitment phase; EC addition is not an RCCL reduction, so every rank adds the world partial points itself.
+        `coset_exchange(nbytes) -> (send_ptr, recv_ptr, run)`, optional: device memory for the quotient's bulk all-gather (the caller owns it, e.g.
+        two torch tensors); `run()` gathers every rank's nbytes at send_ptr into recv_ptr[rank * nbytes ...] and returns when the data is there
+        (it must order itself against this library's stream: Backend.sync() before, a device synchronise after).  Without it the numerators
+        travel through `all_gather` as host arrays."""
         be = backend or default_backend()
         n = 1 << k
         assert n % world == 0 and 0 <= rank < world
@@ -102,6 +124,7 @@ class ParamsKZG:
         self.backend, self.k, self.n = be, k, n
         self.world, self.rank, self.n_loc, self.all_gather = world, rank, n // world, all_gather
         self.lo = rank * self.n_loc
+        self.coset_exchange = coset_exchange
         self.g_host, self.g_lagrange_host = g, g_lagrange
         self.g = BasesHandle(be, np.ascontiguousarray(g[self.lo:self.lo + self.n_loc]))
         self.g_lagrange = BasesHandle(be, np.ascontiguousarray(g_lagrange[self.lo:self.lo + self.n_loc]))

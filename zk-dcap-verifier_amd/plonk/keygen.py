@@ -55,6 +55,7 @@ class ProvingKey:
     evaluator: ev.Evaluator
     program: ev.Program
     lookup_compressors: list = field(default_factory=list)   # per lookup: (input Evaluator, table Evaluator) over the 2^k rows
+    coset_parts: Optional[dict] = None   # params.by_cosets(): coset j -> {"fixed", "sigma", "l"}: the 2^k values of that coset only (this rank's cosets)
 
     def release(self):
         self.evaluator.release()
@@ -62,7 +63,8 @@ class ProvingKey:
             a.release()
             b.release()
         for grp in (self.fixed_values, self.fixed_polys, self.fixed_cosets, self.sigma_values, self.sigma_polys, self.sigma_cosets,
-                    [self.l0, self.l_last, self.l_active_row]):
+                    [d for d in (self.l0, self.l_last, self.l_active_row) if d is not None],
+                    *[v for part in (self.coset_parts or {}).values() for v in part.values()]):
             for d in grp:
                 d.free()
 
@@ -148,8 +150,12 @@ def keygen(params: ParamsKZG, cs: ConstraintSystem, fixed_columns, assembly: Opt
                    cs.permutation_columns, cs.degree(), fixed_commitments, permutation_commitments)).encode())
     vk = VerifyingKey(k, cs, fixed_commitments, permutation_commitments, int.from_bytes(h.digest(), "little") % R_MOD)
 
-    # keygen_pk: polys and extended cosets
-    def to_poly_and_coset(values):
+    # keygen_pk: polys and extended cosets (when the quotient is sharded: only this rank's cosets, 2^k values each)
+    by_cosets = params.by_cosets()
+    my_cosets = params.my_cosets(1 << (ek - k)) if by_cosets else []
+    coset_parts = {j: {} for j in my_cosets} if by_cosets else None
+
+    def to_poly_and_coset(values, name=None):
         polys = []
         for v in values:
             p = be.alloc(n * 32)
@@ -157,12 +163,19 @@ def keygen(params: ParamsKZG, cs: ConstraintSystem, fixed_columns, assembly: Opt
             polys.append(p)
         if polys:
             be.lagrange_to_coeff_batch_dev(polys, k)
+        if by_cosets:
+            for j in my_cosets:
+                outs = [be.alloc(n * 32) for _ in polys]
+                if polys:
+                    be.coeff_to_coset_batch_dev(polys, outs, k, ek, j)
+                coset_parts[j][name] = outs
+            return polys, []
         cosets = [be.alloc((1 << ek) * 32) for _ in polys]
         if polys:
             be.coeff_to_extended_batch_dev(polys, cosets, k, ek)
         return polys, cosets
-    fixed_polys, fixed_cosets = to_poly_and_coset(fixed_values)
-    sigma_polys, sigma_cosets = to_poly_and_coset(sigma_values)
+    fixed_polys, fixed_cosets = to_poly_and_coset(fixed_values, "fixed")
+    sigma_polys, sigma_cosets = to_poly_and_coset(sigma_values, "sigma")
     one = fr_mont(1)
     l0 = np.zeros((n, 4), dtype=np.uint64)
     l0[0] = one
@@ -171,12 +184,14 @@ def keygen(params: ParamsKZG, cs: ConstraintSystem, fixed_columns, assembly: Opt
     l_act = np.zeros((n, 4), dtype=np.uint64)
     l_act[: n - bf - 1] = one                                            # 1 - (l_last + l_blind)
     lvals = [be.to_device(a) for a in (l0, l_last, l_act)]
-    lpolys, lcosets = to_poly_and_coset(lvals)
+    lpolys, lcosets = to_poly_and_coset(lvals, "l")
     for d in lvals + lpolys:
         d.free()
+    if by_cosets:
+        lcosets = [None, None, None]
 
     program = compile_program(cs, k, ek)
     evaluator = ev.Evaluator(program, backend=be)
     comps = [(_compressor(cs, k, lk.input_expressions, be), _compressor(cs, k, lk.table_expressions, be)) for lk in cs.lookups]
     return ProvingKey(vk, dom, be, fixed_values, fixed_polys, fixed_cosets, sigma_values, sigma_polys, sigma_cosets,
-                      lcosets[0], lcosets[1], lcosets[2], evaluator, program, comps)
+                      lcosets[0], lcosets[1], lcosets[2], evaluator, program, comps, coset_parts)

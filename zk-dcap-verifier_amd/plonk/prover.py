@@ -166,16 +166,43 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     lag = adv_values + inst_values + zs + lzs + flat                 # the witness-dependent columns, Lagrange basis
     be.lagrange_to_coeff_batch_dev(lag, k)                           # in place: from here on these buffers hold coefficients
     adv_polys, inst_polys = adv_values, inst_values
-    ext = [dev(en * 32) for _ in lag]
-    be.coeff_to_extended_batch_dev(lag, ext, k, ek)
     nA, nI, nZ = len(adv_polys), len(inst_polys), len(zs)
-    e_adv, e_inst = ext[:nA], ext[nA:nA + nI]
-    e_zs, e_lz = ext[nA + nI:nA + nI + nZ], ext[nA + nI + nZ:nA + nI + nZ + L]
-    e_perm = ext[nA + nI + nZ + L:]
+
+    def split(ext):
+        return dict(advice=ext[:nA], instance=ext[nA:nA + nI], perm_products=ext[nA + nI:nA + nI + nZ], lookup_product=ext[nA + nI + nZ:nA + nI + nZ + L],
+                    lookup_input=ext[nA + nI + nZ + L:][0::2], lookup_table=ext[nA + nI + nZ + L:][1::2])
+    scal = dict(challenges=[], beta=bt_m, gamma=gm_m, theta=th, y=fr_mont(y))
     h_ext = dev(en * 32)
-    pk.evaluator.evaluate_h(fixed=pk.fixed_cosets, advice=e_adv, instance=e_inst, l0=pk.l0, l_last=pk.l_last, l_active_row=pk.l_active_row,
-                            perm_cosets=pk.sigma_cosets, perm_products=e_zs, lookup_product=e_lz, lookup_input=e_perm[0::2],
-                            lookup_table=e_perm[1::2], challenges=[], beta=bt_m, gamma=gm_m, theta=th, y=fr_mont(y), out=h_ext)
+    if pk.coset_parts is None:
+        ext = [dev(en * 32) for _ in lag]
+        be.coeff_to_extended_batch_dev(lag, ext, k, ek)
+        pk.evaluator.evaluate_h(fixed=pk.fixed_cosets, l0=pk.l0, l_last=pk.l_last, l_active_row=pk.l_active_row, perm_cosets=pk.sigma_cosets,
+                                out=h_ext, **split(ext), **scal)
+    else:
+        # the quotient sharded by coset: this rank brings the columns to ITS cosets only (size-n NTTs), evaluates the numerator
+        # there, and the ranks exchange the numerator values — the one bulk collective of a proof (n * 32 bytes per coset)
+        n_cosets = 1 << (ek - k)
+        slots = -(-n_cosets // params.world)
+        xch = params.coset_exchange(slots * n * 32) if params.coset_exchange is not None else None
+        mine = np.zeros((slots, n, 4), dtype=np.uint64) if xch is None else None
+        ext = [dev(n * 32) for _ in range(max(len(lag) + 1, n_cosets))]
+        cols, num = ext[:len(lag)], ext[len(lag)]
+        for s_, j in enumerate(params.my_cosets(n_cosets)):
+            part = pk.coset_parts[j]
+            be.coeff_to_coset_batch_dev(lag, cols, k, ek, j)
+            pk.evaluator.evaluate_h(fixed=part["fixed"], l0=part["l"][0], l_last=part["l"][1], l_active_row=part["l"][2], perm_cosets=part["sigma"],
+                                    out=num if xch is None else xch[0] + s_ * n * 32, coset=j, **split(cols), **scal)
+            if xch is None:
+                mine[s_] = num.download((n, 4))
+        if xch is None:
+            every = params.gather_cosets(mine, n_cosets)
+            for j in range(n_cosets):
+                ext[j].upload(np.ascontiguousarray(every[j]))
+            srcs = ext[:n_cosets]
+        else:                                                       # device-resident exchange (RCCL all_gather on the caller's buffers)
+            xch[2]()
+            srcs = [xch[1] + j * n * 32 for j in range(n_cosets)]   # rank r's block starts at r * slots * n * 32: coset order
+        be.fr_interleave_dev(srcs, n, h_ext)
     for d in ext:                                                   # the cosets are dead once the numerator exists
         d.free()
         owned.remove(d)

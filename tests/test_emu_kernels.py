@@ -52,6 +52,21 @@ def test_msm_uniform(emu, orc, pyref, n, c):
         emu.tune(msm_c=0)
 
 
+@pytest.mark.parametrize("two_level", [0, 1])
+@pytest.mark.parametrize("n,c,kind", [(1, 0, "uniform"), (33, 0, "uniform"), (300, 7, "uniform"), (700, 0, "uniform"), (513, 9, "uniform"),
+                                      (257, 0, "ones"), (257, 0, "witness"), (257, 0, "minus_one"), (64, 0, "zeros")])
+def test_msm_both_sorts(emu, orc, pyref, n, c, kind, two_level):
+    """The pairs are grouped by bucket either by the one-level counting sort (small / batched inputs) or the two-level one (large inputs):
+    force each and compare with the oracle; a batch too."""
+    emu.tune(msm_c=c, msm_two_level_sort=two_level)
+    try:
+        pc.check_msm(emu, orc, pyref, n, seed=n + 1, kind=kind)
+        if n == 300:
+            pc.check_msm_batch(emu, orc, pyref, 120, 6)
+    finally:
+        emu.tune(msm_c=0, msm_two_level_sort=0)
+
+
 @pytest.mark.parametrize("kind", ["ones", "zeros", "witness", "minus_one"])
 def test_msm_degenerate_scalar_columns(emu, orc, pyref, kind):
     pc.check_msm(emu, orc, pyref, 257, seed=9, kind=kind)          # one heavy bucket -> several merge rounds

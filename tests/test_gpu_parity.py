@@ -57,6 +57,20 @@ def test_msm_uniform_vs_oracle(gpu, orc, pyref, n):
     pc.check_msm(gpu, orc, pyref, n, seed=n)
 
 
+@pytest.mark.parametrize("two_level", [0, 1])
+@pytest.mark.parametrize("n,c,kind", [(1, 0, "uniform"), (1000, 0, "uniform"), (3000, 8, "uniform"), (20000, 16, "uniform"), (40000, 0, "uniform"),
+                                      (5000, 0, "ones"), (5000, 0, "witness"), (5000, 16, "minus_one"), (5000, 0, "zeros")])
+def test_msm_both_sorts(gpu, orc, pyref, n, c, kind, two_level):
+    """one-level (small / batched) and two-level (large) bucket sort, each forced, against the oracle"""
+    gpu.tune(msm_c=c, msm_two_level_sort=two_level)
+    try:
+        pc.check_msm(gpu, orc, pyref, n, seed=n + 1, kind=kind)
+        if n == 3000:
+            pc.check_msm_batch(gpu, orc, pyref, 2000, 7, device=True)
+    finally:
+        gpu.tune(msm_c=0, msm_two_level_sort=0)
+
+
 @pytest.mark.parametrize("c", [3, 8, 11, 13, 16])
 def test_msm_window_sizes(gpu, orc, pyref, c):
     gpu.tune(msm_c=c)

@@ -16,13 +16,16 @@ TAU = 0x1C59A59B6CFF4308740943526ADE1D8C09F71B337A67269CC89586BCDD6DFCBA
 def main():
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 19
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    be = z.Backend(0)
+    be = z.Backend(0, os.environ.get("ZK_LIB"))        # ZK_LIB: A/B against another build of the library on the same box
     tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("ZK_TUNE", "").split(",") if kv}
     if tune:
         be.tune(**tune)
     out = {"k": k, "tune": tune, "host_witness": os.environ.get("ZK_HOST_WITNESS") == "1"}
     t = time.time(); cs, fixed, asm, advice = sc.build(z, be, k); out["build_witness_s"] = round(time.time() - t, 3)
     t = time.time(); params = z.kzg.ParamsKZG.setup(k, TAU, backend=be); out["srs_setup_s"] = round(time.time() - t, 3)
+    if os.environ.get("ZK_BY_COSETS") == "1":          # the multi-GPU quotient unit on one GPU: 2^(ek-k) coset NTTs of size n instead of one of size 2^ek
+        params.quotient_by_cosets = True
+        out["quotient_by_cosets"] = True
     t = time.time(); pk = z.plonk.keygen(params, cs, fixed, asm); out["keygen_s"] = round(time.time() - t, 3)
     out["program"] = be.quotient_program_info(pk.evaluator.handle)
     n = 1 << k

@@ -92,7 +92,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
         release_pks(ctx);
         release_programs(ctx);
         release_gtab(ctx);
-        zk::DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_sorted, &ctx->ws_small, &ctx->ws_sub0, &ctx->ws_sub1, &ctx->ws_cls0,
+        zk::DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_sorted, &ctx->ws_mid, &ctx->ws_small, &ctx->ws_sub0, &ctx->ws_sub1, &ctx->ws_cls0,
                               &ctx->ws_cls1, &ctx->ws_tmp, &ctx->ws_ntt, &ctx->ws_ntt_in, &ctx->ws_pts};
         for (auto* b : bufs) b->release();
         (void)hipStreamDestroy(ctx->stream);
@@ -105,7 +105,7 @@ const char* zk_last_error(zk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null c
 static int* tune_slot(zk_ctx* ctx, const char* key) {
     zk::Tune& t = ctx->tune;
     struct { const char* k; int* v; } tab[] = {
-        {"msm_c", &t.msm_c}, {"msm_sort_wgs", &t.msm_sort_wgs}, {"msm_sort_threads", &t.msm_sort_threads}, {"msm_sort_batch_wgs", &t.msm_sort_batch_wgs},
+        {"msm_c", &t.msm_c}, {"msm_sort_wgs", &t.msm_sort_wgs}, {"msm_sort_threads", &t.msm_sort_threads}, {"msm_sort_batch_wgs", &t.msm_sort_batch_wgs}, {"msm_bsort_threads", &t.msm_bsort_threads}, {"msm_two_level_sort", &t.msm_two_level_sort},
         {"msm_target_threads", &t.msm_target_threads}, {"msm_min_chunk", &t.msm_min_chunk}, {"msm_max_chunk", &t.msm_max_chunk},
         {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block},
         {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log},

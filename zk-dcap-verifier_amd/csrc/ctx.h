@@ -17,6 +17,8 @@ struct Tune {
     int msm_c = 0;               // 0 = pick from n
     int msm_sort_wgs = 256;      // workgroups of the counting-sort kernels (one per CU)
     int msm_sort_threads = 1024;
+    int msm_bsort_threads = 256;     // workgroup size of the per-bin bucket sort (small LDS footprint: several workgroups per CU hide its load latency)
+    int msm_two_level_sort = 0;      // 1: take the two-level bucket sort even where the one-level sort applies (tests, measurements)
     int msm_sort_batch_wgs = 2048;   // total sort workgroups aimed for by a batched call
     int msm_target_threads = 1 << 19;  // sub-bucket count the accumulate launch aims for
     int msm_min_chunk = 16;      // min pairs per accumulate thread
@@ -84,7 +86,7 @@ struct zk_ctx {
     std::vector<zk::TwiddleSet> twiddles;
     std::map<uint64_t, zk::QuotProgram*> programs;
     // workspaces (grow-only)
-    zk::DevBuf ws_scalars, ws_sorted, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts;
+    zk::DevBuf ws_scalars, ws_sorted, ws_mid, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts;
     // last-call kernel timing (ms), filled when timing is enabled
     bool timing = false;
     std::map<std::string, double> last_ms;

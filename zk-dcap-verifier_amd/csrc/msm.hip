@@ -49,6 +49,28 @@ ZK_HD void for_each_digit(u256 s, int c, int W, F&& f) {
     }
 }
 
+// the same walk with the window index as a compile-time constant (callers index register arrays with it); windows >= W are skipped
+template <int J> struct WinIdx { static constexpr int value = J; };
+template <int WMAX, int J = 0, class F>
+ZK_HD void for_each_digit_static(u256& s, int c, int W, F&& f, uint32_t carry = 0) {
+    if constexpr (J < WMAX) {
+        if (J < W) {
+            const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+            uint32_t d = (s.v[0] & mask) + carry;
+#pragma unroll
+            for (int i = 0; i < 7; i++) s.v[i] = (s.v[i] >> c) | (s.v[i + 1] << (32 - c));
+            s.v[7] >>= c;
+            uint32_t cy = 0;
+            if (d > half) {
+                cy = 1;
+                uint32_t m = (1u << c) - d;
+                if (m) f(WinIdx<J>{}, m, true);
+            } else if (d) f(WinIdx<J>{}, d, false);
+            for_each_digit_static<WMAX, J + 1>(s, c, W, f, cy);
+        }
+    }
+}
+
 // largest b in [0, B) with arr[b] <= j  (arr is a non-decreasing exclusive scan, arr[0] = 0)
 ZK_HD uint32_t find_segment(const uint32_t* arr, uint32_t B, uint32_t j) {
     uint32_t lo = 0, hi = B;
@@ -74,6 +96,9 @@ struct MsmPlan {
     uint32_t small_stride, o_off, o_cursor, o_suboff, o_info, o_tiles, o_fulloff, o_remorder, o_remhist, o_remstart, o_remcursor;
     uint32_t* sorted;                      // per column: pairs_max references
     uint64_t sorted_stride;
+    uint32_t low_bits, nbin, pch, o_bintot, o_bincur;   // two-level sort: bin = bucket >> low_bits; pch = scalars per partition workgroup
+    uint32_t* mid_ref;                     // per column (stride sorted_stride): references grouped by bin ...
+    uint8_t* mid_low;                      // ... and the low bits of their bucket
     void* sub[2];                          // level r lives in sub[r & 1]
     uint64_t sub_stride[2];                // entries per column
     void* cls[2];
@@ -88,8 +113,165 @@ ZK_HD uint32_t plan_eff_levels(const MsmPlan& p, uint32_t max_s) {  // merge rou
 }
 
 // ------------------------------------------------------------------------------------------------
-// counting sort of (scalar, window) pairs by bucket — histogram in LDS
+// grouping the (scalar, window) pairs by bucket: a two-level counting sort.
+// (Written to replace the one-level sort below, whose workgroups put ~1 pair into each of their 32768 buckets at n = 2^19 — millions of
+// global atomics and isolated 4-byte stores per column.  Measured, it does not: see the note at the one-level kernels.)
+//        bin_hist    bucket >> low_bits (<= 256 bins): per-column bin totals                                (LDS counters, 256 global atomics / workgroup)
+//        partition   a workgroup takes pch scalars, groups their pairs by bin in LDS and writes each bin's run with coalesced stores
+//                    (reference + low bucket bits) at a range reserved with ONE global atomic per bin
+//        bucket_sort one workgroup per bin: <= 128 bucket counters in LDS, the bin's slice of `sorted` is a window of a few hundred KB
+//                    (L2-resident); it also writes the bucket sizes the scans below start from.
+// reference = (negative << 31) | (window * n_table + scalar index)
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t MSM_MAX_BINS = 256, MSM_PART_PAIRS = 8192;
+
+// inclusive scan of v[0..N) in LDS (N <= MSM_MAX_BINS), any block size; tmp: N words
+__device__ __forceinline__ void block_incscan(uint32_t* v, uint32_t* tmp, uint32_t N) {
+    for (uint32_t d = 1; d < N; d <<= 1) {
+        for (uint32_t t = threadIdx.x; t < N; t += blockDim.x) tmp[t] = v[t] + (t >= d ? v[t - d] : 0u);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < N; t += blockDim.x) v[t] = tmp[t];
+        __syncthreads();
+    }
+}
+
+ZK_KERNEL void msm_bin_hist_kernel(MsmPlan p) {
+    __shared__ uint32_t lh[MSM_MAX_BINS];
+    const uint32_t col = blockIdx.y;
+    const void* scalars = p.scalars[col];
+    for (uint32_t b = threadIdx.x; b < p.nbin; b += blockDim.x) lh[b] = 0;
+    __syncthreads();
+    const uint32_t chunk = ceil_div(p.n, gridDim.x);
+    const uint32_t lo = blockIdx.x * chunk;
+    const uint32_t hi = lo + chunk < p.n ? lo + chunk : p.n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        u256 s = Fr::from_mont(load_u256(scalars, i));
+        for_each_digit(s, p.c, p.W, [&](int, uint32_t mag, bool) { atomicAdd(&lh[(mag - 1) >> p.low_bits], 1u); });
+    }
+    __syncthreads();
+    uint32_t* tot = plan_small(p, col) + p.o_bintot;
+    for (uint32_t b = threadIdx.x; b < p.nbin; b += blockDim.x) {
+        uint32_t v = lh[b];
+        if (v) atomicAdd(&tot[b], v);
+    }
+}
+
+// Every thread keeps its (<= PART_SPT) canonical scalars in registers between the counting and the placing sweep; the staging area is
+// small enough for three workgroups per CU (the sweeps are latency chains: load -> Montgomery reduction -> digits -> LDS atomics).
+constexpr uint32_t PART_SPT = 2;
+ZK_KERNEL void msm_partition_kernel(MsmPlan p) {
+    ZK_DYN_SHARED(uint32_t, st_ref);                       // [pch * W] references, then [pch * W] u16 bucket indices
+    __shared__ uint32_t cnt[MSM_MAX_BINS], start[MSM_MAX_BINS], dst[MSM_MAX_BINS], base[MSM_MAX_BINS], tmp[MSM_MAX_BINS];
+    const uint32_t col = blockIdx.y, nbin = p.nbin, cap = p.pch * (uint32_t)p.W;
+    uint16_t* st_key = reinterpret_cast<uint16_t*>(st_ref + cap);
+    const void* scalars = p.scalars[col];
+    uint32_t* sm = plan_small(p, col);
+    for (uint32_t b = threadIdx.x; b < nbin; b += blockDim.x) { cnt[b] = 0; base[b] = sm[p.o_bintot + b]; }
+    const uint32_t lo = blockIdx.x * p.pch;
+    const uint32_t hi = lo + p.pch < p.n ? lo + p.pch : p.n;
+    u256 sc[PART_SPT];
+#pragma unroll
+    for (uint32_t u = 0; u < PART_SPT; u++) {              // pch <= PART_SPT * blockDim (host)
+        const uint32_t i = lo + threadIdx.x + u * blockDim.x;
+        if (i < hi) sc[u] = load_u256(scalars, i);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < PART_SPT; u++) {
+        const uint32_t i = lo + threadIdx.x + u * blockDim.x;
+        if (i < hi) {
+            sc[u] = Fr::from_mont(sc[u]);
+            for_each_digit(sc[u], p.c, p.W, [&](int, uint32_t mag, bool) { atomicAdd(&cnt[(mag - 1) >> p.low_bits], 1u); });
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbin; b += blockDim.x) start[b] = cnt[b];
+    __syncthreads();
+    block_incscan(start, tmp, nbin);                       // start[b] = end of bin b inside this workgroup's staging area
+    block_incscan(base, tmp, nbin);                        // base[b]  = end of bin b in the column
+    for (uint32_t b = threadIdx.x; b < nbin; b += blockDim.x) {
+        const uint32_t c0 = cnt[b];
+        dst[b] = (base[b] - sm[p.o_bintot + b]) + (c0 ? atomicAdd(&sm[p.o_bincur + b], c0) : 0u);
+        tmp[b] = start[b] - c0;                            // cursor
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbin; b += blockDim.x) start[b] = tmp[b];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < PART_SPT; u++) {
+        const uint32_t i = lo + threadIdx.x + u * blockDim.x;
+        if (i < hi)
+            for_each_digit(sc[u], p.c, p.W, [&](int j, uint32_t mag, bool neg) {
+                const uint32_t pos = atomicAdd(&tmp[(mag - 1) >> p.low_bits], 1u);
+                st_ref[pos] = (neg ? 0x80000000u : 0u) | ((uint32_t)j * p.n_table + i);
+                st_key[pos] = (uint16_t)(mag - 1);
+            });
+    }
+    __syncthreads();
+    const uint32_t total = tmp[nbin - 1];                  // the last cursor ended at the number of staged pairs
+    uint32_t* mref = p.mid_ref + (size_t)col * p.sorted_stride;
+    uint8_t* mlow = p.mid_low + (size_t)col * p.sorted_stride;
+    const uint32_t lmask = (1u << p.low_bits) - 1u;
+    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {   // neighbouring lanes -> neighbouring addresses of the same bin's run
+        const uint32_t key = st_key[e], b = key >> p.low_bits;
+        const uint32_t d = dst[b] + (e - start[b]);
+        mref[d] = st_ref[e];
+        mlow[d] = (uint8_t)(key & lmask);
+    }
+}
+
+// One workgroup per (bin, column).  The bin's entries are read four at a time (one 4-byte load of low bits, one 16-byte load of references
+// per lane; the column arrays are 16-byte aligned and the range is widened to multiples of four entries, the overhang masked).
+ZK_KERNEL void msm_bucket_sort_kernel(MsmPlan p) {
+    __shared__ uint32_t cnt[128], cur[128], tmp[MSM_MAX_BINS], red[MSM_MAX_BINS];
+    const uint32_t col = blockIdx.y, bin = blockIdx.x, nlow = 1u << p.low_bits;
+    uint32_t* sm = plan_small(p, col);
+    for (uint32_t b = threadIdx.x; b < p.nbin; b += blockDim.x) red[b] = b < bin ? sm[p.o_bintot + b] : 0u;
+    for (uint32_t b = threadIdx.x; b < nlow; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    block_incscan(red, tmp, p.nbin);
+    const uint32_t base = red[p.nbin - 1], end = base + sm[p.o_bintot + bin];
+    const uint32_t* __restrict__ mref = p.mid_ref + (size_t)col * p.sorted_stride;
+    const uint8_t* __restrict__ mlow = p.mid_low + (size_t)col * p.sorted_stride;
+    const uint32_t a0 = base & ~3u, step = 4 * blockDim.x;
+    for (uint32_t e = a0 + 4 * threadIdx.x; e < end; e += 2 * step) {
+        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(mlow + e);
+        const uint32_t w1 = e + step < end ? *reinterpret_cast<const uint32_t*>(mlow + e + step) : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) if (e + u >= base && e + u < end) atomicAdd(&cnt[(w0 >> (8 * u)) & 0xffu], 1u);
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) if (e + step + u < end) atomicAdd(&cnt[(w1 >> (8 * u)) & 0xffu], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nlow; b += blockDim.x) { sm[bin * nlow + b] = cnt[b]; cur[b] = cnt[b]; }   // hist[bucket]
+    __syncthreads();
+    block_incscan(cur, tmp, nlow);
+    for (uint32_t b = threadIdx.x; b < nlow; b += blockDim.x) tmp[b] = base + cur[b] - cnt[b];
+    __syncthreads();
+    uint32_t* __restrict__ sorted = p.sorted + (size_t)col * p.sorted_stride;
+    for (uint32_t e = a0 + 4 * threadIdx.x; e < end; e += 2 * step) {
+        const bool two = e + step < end;
+        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(mlow + e);
+        const uint4 r0 = *reinterpret_cast<const uint4*>(mref + e);
+        const uint32_t w1 = two ? *reinterpret_cast<const uint32_t*>(mlow + e + step) : 0u;
+        const uint4 r1 = two ? *reinterpret_cast<const uint4*>(mref + e + step) : make_uint4(0, 0, 0, 0);
+        const uint32_t v0[4] = {r0.x, r0.y, r0.z, r0.w}, v1[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) if (e + u >= base && e + u < end) sorted[atomicAdd(&tmp[(w0 >> (8 * u)) & 0xffu], 1u)] = v0[u];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) if (e + step + u < end) sorted[atomicAdd(&tmp[(w1 >> (8 * u)) & 0xffu], 1u)] = v1[u];
+    }
+}
+
+// ---- one-level sort (the default) ---------------------------------------------------------------------------------------------------------
+// Every workgroup keeps all 2^(c-1) bucket counters in LDS (128 KiB at c = 16): hist counts, the scans run, scatter re-counts its chunk,
+// reserves a range per bucket with a global atomic and places the references.  scatter's counting atomicAdd already returns the pair's rank
+// inside (workgroup, bucket); it stays in a register (16 bits) until the bucket's base is known, so placing needs no second LDS atomic.
+// The rank registers bound a workgroup's chunk (<= SC_SPT scalars per thread, chunk * W <= 65536) and the window count (W <= SC_WMAX).
+// Measured against the two-level sort above on MI355X (profiles/r01/run41_sort_crossover.txt, run41 prover probes): single columns 2^19 .. 2^24
+// within 5 % of each other; batched columns (the prover's case) 4 % per proof in favour of this one — both end in 4-byte stores to 64
+// different cache lines per wave, and the two-level sort pays for its coalesced intermediate pass on top.  So the two-level sort runs only
+// where this one cannot (W > SC_WMAX: tiny inputs with narrow windows) or when forced (msm_two_level_sort = 1).
 ZK_KERNEL void msm_hist_kernel(MsmPlan p) {
     ZK_DYN_SHARED(uint32_t, lh);
     const uint32_t B = p.B, col = blockIdx.y;
@@ -108,6 +290,62 @@ ZK_KERNEL void msm_hist_kernel(MsmPlan p) {
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
         uint32_t v = lh[b];
         if (v) atomicAdd(&ghist[b], v);
+    }
+}
+
+
+constexpr uint32_t SC_SPT = 4, SC_WMAX = 32;
+ZK_KERNEL void msm_scatter_kernel(MsmPlan p) {
+    ZK_DYN_SHARED(uint32_t, lh);
+    const uint32_t B = p.B, col = blockIdx.y;
+    const void* scalars = p.scalars[col];
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lh[b] = 0;
+    const uint32_t chunk = ceil_div(p.n, gridDim.x);            // <= SC_SPT * blockDim and chunk * W <= 65536 (host): ranks fit 16 bits
+    const uint32_t lo = blockIdx.x * chunk;
+    const uint32_t hi = lo + chunk < p.n ? lo + chunk : p.n;
+    u256 sc[SC_SPT];
+    uint32_t rk[SC_SPT][SC_WMAX / 2] = {};                      // two 16-bit ranks per register
+#pragma unroll
+    for (uint32_t u = 0; u < SC_SPT; u++) {
+        const uint32_t i = lo + threadIdx.x + u * blockDim.x;
+        if (i < hi) sc[u] = load_u256(scalars, i);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < SC_SPT; u++) {
+        const uint32_t i = lo + threadIdx.x + u * blockDim.x;
+        if (i < hi) {
+            sc[u] = Fr::from_mont(sc[u]);
+            u256 t = sc[u];
+            for_each_digit_static<SC_WMAX>(t, p.c, p.W, [&](auto jc, uint32_t mag, bool) {
+                constexpr int j = decltype(jc)::value;
+                const uint32_t r = atomicAdd(&lh[mag - 1], 1u);
+                if (j & 1) rk[u][j / 2] |= r << 16; else rk[u][j / 2] = r;
+            });
+        }
+    }
+    __syncthreads();
+    uint32_t* cursor = plan_small(p, col) + p.o_cursor;
+    for (uint32_t b0 = threadIdx.x; b0 < B; b0 += 8 * blockDim.x) {   // 8 reservations in flight per thread
+        uint32_t v[8], r[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t b = b0 + u * blockDim.x; v[u] = b < B ? lh[b] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) r[u] = v[u] ? atomicAdd(&cursor[b0 + u * blockDim.x], v[u]) : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t b = b0 + u * blockDim.x; if (b < B) lh[b] = r[u]; }
+    }
+    __syncthreads();
+    uint32_t* sorted = p.sorted + (size_t)col * p.sorted_stride;
+#pragma unroll
+    for (uint32_t u = 0; u < SC_SPT; u++) {
+        const uint32_t i = lo + threadIdx.x + u * blockDim.x;
+        if (i < hi)
+            for_each_digit_static<SC_WMAX>(sc[u], p.c, p.W, [&](auto jc, uint32_t mag, bool neg) {
+                constexpr int j = decltype(jc)::value;
+                const uint32_t r = (j & 1) ? rk[u][j / 2] >> 16 : rk[u][j / 2] & 0xffffu;
+                sorted[lh[mag - 1] + r] = (neg ? 0x80000000u : 0u) | ((uint32_t)j * p.n_table + i);
+            });
     }
 }
 
@@ -247,44 +485,6 @@ ZK_KERNEL void msm_scan_apply_kernel(MsmPlan p) {
             }
             run += x[e].v[v];
         }
-    }
-}
-
-// second pass of the counting sort: every workgroup re-derives its chunk's LDS histogram, reserves
-// a contiguous range per bucket from the global cursors, then drops point references in place.
-// reference = (negative << 31) | (window * n_table + scalar index)
-ZK_KERNEL void msm_scatter_kernel(MsmPlan p) {
-    ZK_DYN_SHARED(uint32_t, lh);
-    const uint32_t B = p.B, col = blockIdx.y;
-    const void* scalars = p.scalars[col];
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lh[b] = 0;
-    __syncthreads();
-    const uint32_t chunk = ceil_div(p.n, gridDim.x);
-    const uint32_t lo = blockIdx.x * chunk;
-    const uint32_t hi = lo + chunk < p.n ? lo + chunk : p.n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        u256 s = Fr::from_mont(load_u256(scalars, i));
-        for_each_digit(s, p.c, p.W, [&](int, uint32_t mag, bool) { atomicAdd(&lh[mag - 1], 1u); });
-    }
-    __syncthreads();
-    uint32_t* cursor = plan_small(p, col) + p.o_cursor;
-    for (uint32_t b0 = threadIdx.x; b0 < B; b0 += 8 * blockDim.x) {   // 8 reservations in flight per thread
-        uint32_t v[8], r[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t b = b0 + u * blockDim.x; v[u] = b < B ? lh[b] : 0u; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) r[u] = v[u] ? atomicAdd(&cursor[b0 + u * blockDim.x], v[u]) : 0u;
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t b = b0 + u * blockDim.x; if (b < B) lh[b] = r[u]; }
-    }
-    __syncthreads();
-    uint32_t* sorted = p.sorted + (size_t)col * p.sorted_stride;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        u256 s = Fr::from_mont(load_u256(scalars, i));
-        for_each_digit(s, p.c, p.W, [&](int j, uint32_t mag, bool neg) {
-            uint32_t pos = atomicAdd(&lh[mag - 1], 1u);
-            sorted[pos] = (neg ? 0x80000000u : 0u) | ((uint32_t)j * p.n_table + i);
-        });
     }
 }
 
@@ -629,15 +829,25 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     p.o_remhist = p.o_remorder + B;
     p.o_remstart = p.o_remhist + REM_CLASSES;
     p.o_remcursor = p.o_remstart + REM_CLASSES;
-    p.small_stride = p.o_remcursor + REM_CLASSES;
+    p.o_bintot = p.o_remcursor + REM_CLASSES;
+    p.o_bincur = p.o_bintot + MSM_MAX_BINS;
+    p.small_stride = p.o_bincur + MSM_MAX_BINS;
+    p.low_bits = (uint32_t)std::min(7, c - 1);
+    p.nbin = B >> p.low_bits;
+    const int part_threads = std::min(256, tn.msm_sort_threads);
+    p.pch = std::min<uint32_t>(std::max<uint32_t>(1, MSM_PART_PAIRS / (uint32_t)W), PART_SPT * (uint32_t)part_threads);
+    if (p.nbin > MSM_MAX_BINS) return ctx->fail(ZK_ERR_LIMIT, "zk_msm: window width c = %d exceeds 16", c);
     ZK_HIP(ctx->ws_small.ensure((size_t)nb * p.small_stride * 4 + (size_t)nb * sizeof(void*) + 64));
     p.small = (uint32_t*)ctx->ws_small.p;
     const void** d_ptrs = (const void**)((char*)ctx->ws_small.p + (((size_t)nb * p.small_stride * 4 + 15) & ~(size_t)15));
     p.scalars = d_ptrs;
     p.table = bt.d_table;
-    p.sorted_stride = pairs_max + 4;
+    p.sorted_stride = (pairs_max + 4 + 15) & ~(uint64_t)15;      // columns of the 1-, 4-byte arrays start 16-byte aligned
     ZK_HIP(ctx->ws_sorted.ensure((size_t)nb * p.sorted_stride * 4));
     p.sorted = (uint32_t*)ctx->ws_sorted.p;
+    ZK_HIP(ctx->ws_mid.ensure((size_t)nb * p.sorted_stride * 5 + 64));          // (vector loads may touch the 3 entries after a column's last)
+    p.mid_ref = (uint32_t*)ctx->ws_mid.p;
+    p.mid_low = (uint8_t*)ctx->ws_mid.p + (size_t)nb * p.sorted_stride * 4;
     p.sub_stride[0] = cap[0];
     p.sub_stride[1] = R >= 1 ? cap[1] : 1;
     ZK_HIP(ctx->ws_sub0.ensure((size_t)nb * p.sub_stride[0] * 128));
@@ -653,24 +863,38 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     ZK_HIP(hipMemsetAsync(p.small, 0, (size_t)nb * p.small_stride * 4, st));
     ZK_HIP(hipMemcpyAsync((void*)d_ptrs, h_scal_ptrs, (size_t)nb * sizeof(void*), hipMemcpyHostToDevice, st));
     int wgs = tn.msm_sort_wgs;
-    {   // do not spread small inputs over many workgroups (each one flushes the full histogram)
+    {   // do not spread small inputs over many workgroups (each one flushes its counters)
         uint64_t per = (uint64_t)tn.msm_sort_threads * 4;
         uint64_t want = (n + per - 1) / per;
         if (want < (uint64_t)wgs) wgs = (int)std::max<uint64_t>(want, 1);
         if (nb > 1) wgs = std::max(1, std::min(wgs, (int)((tn.msm_sort_batch_wgs) / nb) + 1));
     }
-    const size_t lds = (size_t)B * 4;
+    // one-level sort: the rank registers of msm_scatter_kernel hold SC_SPT scalars per thread and 16-bit ranks
+    const uint64_t chunk_max = std::min<uint64_t>((uint64_t)SC_SPT * tn.msm_sort_threads, 65536 / (uint64_t)W);
+    const uint64_t need = (n + chunk_max - 1) / chunk_max;
+    const bool two_level = W > (int)SC_WMAX || tn.msm_two_level_sort != 0;   // (tiny inputs pick narrow windows: more of them than the rank registers cover)
     EvTimer t_sort(ctx, "msm_sort");
-    ZK_LAUNCH(msm_hist_kernel, dim3(wgs, nb), tn.msm_sort_threads, lds, st, p);
-    ZK_CHECK_LAUNCH();
+    if (two_level) {
+        ZK_LAUNCH(msm_bin_hist_kernel, dim3(wgs, nb), tn.msm_sort_threads, 0, st, p);
+        ZK_CHECK_LAUNCH();
+        ZK_LAUNCH(msm_partition_kernel, dim3(ceil_div(p.n, p.pch), nb), part_threads, (size_t)p.pch * W * 6, st, p);
+        ZK_CHECK_LAUNCH();
+        ZK_LAUNCH(msm_bucket_sort_kernel, dim3(p.nbin, nb), std::min(tn.msm_bsort_threads, tn.msm_sort_threads), 0, st, p);
+        ZK_CHECK_LAUNCH();
+    } else {
+        ZK_LAUNCH(msm_hist_kernel, dim3(wgs, nb), tn.msm_sort_threads, (size_t)B * 4, st, p);
+        ZK_CHECK_LAUNCH();
+    }
     ZK_LAUNCH(msm_scan_tiles_kernel, dim3(scan_tiles, nb), SC_T, 0, st, p);
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(msm_scan_tilesums_kernel, nb, 64, 0, st, p, scan_tiles);
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(msm_scan_apply_kernel, dim3(scan_tiles, nb), SC_T, 0, st, p);
     ZK_CHECK_LAUNCH();
-    ZK_LAUNCH(msm_scatter_kernel, dim3(wgs, nb), tn.msm_sort_threads, lds, st, p);
-    ZK_CHECK_LAUNCH();
+    if (!two_level) {
+        ZK_LAUNCH(msm_scatter_kernel, dim3((uint32_t)std::max<uint64_t>(need, (uint64_t)wgs), nb), tn.msm_sort_threads, (size_t)B * 4, st, p);
+        ZK_CHECK_LAUNCH();
+    }
     t_sort.stop();
 
     const int blk = tn.msm_block;
@@ -815,6 +1039,7 @@ int g1_fixed_base_mul(zk_ctx* ctx, const void* d_scalars, size_t n, void* d_out_
 
 int msm_set_lds_attr() {
 #ifndef ZK_EMU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msm_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msm_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msm_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif

@@ -421,7 +421,7 @@ def main(argv=None):
             traffic = json.load(open(tj)).get("msm_accumulate_bytes_per_launch")
         except Exception:
             traffic = None
-    XYZZ_MADD_PEAK = 12.73e9   # mixed additions/s of the same code in a register-only loop (profiles/r01/run27_microbench_fused_y3.txt)
+    XYZZ_MADD_PEAK = 13.17e9   # mixed additions/s of the same code in a register-only loop (profiles/r01/run43_microbench_dedicated_sqr.txt)
     roofline = {"kernel": "msm_accumulate_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_ms": round(acc_ms / max(acc_n, 1), 4), "launches": acc_n,

@@ -60,6 +60,13 @@ __global__ void k_fqmul(uint32_t* out, uint32_t seed) {
     for (int i = 0; i < ITER / 4; i++) { x = Fq::mul(x, y); y = Fq::mul(y, x); }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x.v[0] ^ y.v[3];
 }
+__global__ void k_fqsqr(uint32_t* out, uint32_t seed) {
+    u256 x = Fq::one(), y = Fq::R2();
+    x.v[0] ^= threadIdx.x + seed; y.v[1] ^= blockIdx.x;
+    x = Fq::reduce_once(x);
+    for (int i = 0; i < ITER / 4; i++) { x = Fq::sqr(x); y = Fq::sqr(y); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x.v[0] ^ y.v[3];
+}
 __global__ void k_fqmul_cios(uint32_t* out, uint32_t seed) {
     u256 x = Fq::one(), y = Fq::R2();
     x.v[0] ^= threadIdx.x + seed; y.v[1] ^= blockIdx.x;
@@ -113,6 +120,7 @@ int main() {
     }
     for (int bpc : {2, 4, 8}) {
         run("fq_mul", k_fqmul, 2.0 * (ITER / 4), 256, bpc);
+        run("fq_sqr", k_fqsqr, 2.0 * (ITER / 4), 256, bpc);
         run("fq_mul_cios", k_fqmul_cios, 2.0 * (ITER / 4), 256, bpc);
         run("fq_addsub", k_fqadd, 2.0 * ITER, 256, bpc);
     }

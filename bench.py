@@ -330,6 +330,8 @@ def main(argv=None):
     else:
         backend = "none"
     tdev = "cuda" if backend == "nccl" else "cpu"
+    if os.environ.get("ZK_SWITCH_INTERVAL"):                 # experiment knob: CPython's GIL hand-over interval for the per-proof host threads
+        sys.setswitchinterval(float(os.environ["ZK_SWITCH_INTERVAL"]))
     import zk_dcap_verifier_amd as z
     be = z.Backend(local)                      # raises if the HIP library / GPU is missing: no CPU path
     assert "gfx950" in be.version() or os.environ.get("ZK_BENCH_PLUMBING_TEST") == "1"

@@ -25,6 +25,19 @@ def test_sharded_msm_two_ranks_gloo(built):
             assert np.load(os.path.join(d, f"rank{r}.npy"))[0] == 1
 
 
+import pytest
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_create_proof_more_ranks_than_two(built, world):
+    """4 ranks: one coset of the quotient each (the toy circuit's extended domain has 4); 8 ranks: more ranks than cosets, the extra ranks idle in
+    the quotient and still emit the golden proof."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(multi_rank_worker.run_sharded_proof, args=(world, _free_port(), d), nprocs=world, join=True)
+        for r in range(world):
+            assert np.load(os.path.join(d, f"proof_rank{r}.npy"))[0] == 1
+
+
 def test_sharded_create_proof_two_ranks_gloo(built):
     """SURVEY §8e / BASELINE configs[4]: the prover with BOTH SRS tables sharded by index range over two ranks — every commitment of the proof is
     two partial MSMs + one all_gather — emits byte for byte the golden proof of the single-device prover, on every rank."""

@@ -444,6 +444,16 @@ def main(argv=None):
             lat.append((time.time() - t1, tm))
         best = min(lat, key=lambda x: x[0])
         extra["single_proof"] = {"ms": round(best[0] * 1e3, 2), "phase_ms": {k_: round(v, 2) for k_, v in best[1].items()}}
+        # the same proof once more with HIP-event timing on: alone on the GPU the event pairs bracket only this proof's kernels, so these
+        # (unlike kernel_ms_per_proof above) are kernel times
+        be.timing(True)
+        wl.step()
+        alone = {lab: be.timing_get(lab) for lab in ("msm_sort", "msm_accumulate", "msm_reduce", "quotient")}
+        pairs_alone = be.stat_get("msm_pairs")
+        be.timing(False)
+        extra["single_proof"]["kernel_ms"] = {lab: round(v[0], 3) for lab, v in alone.items() if v[0] is not None}
+        if alone["msm_accumulate"][0]:
+            extra["single_proof"]["int_alu_frac_alone"] = round(pairs_alone / (alone["msm_accumulate"][0] * 1e-3) / XYZZ_MADD_PEAK, 4)
     cfg = {"k": args.k, "ek": wl.ek, "A": wl.A, "F": wl.F, "L": wl.L, "n_perm": wl.n_perm, "d": wl.d,
            "n_msm": wl.n_msm, "n_intt": wl.n_intt, "n_ext": wl.n_ext}
     cpu = None

@@ -32,3 +32,13 @@ def test_emulated_cosets(emu, orc, pyref, k, e):
 @pytest.mark.parametrize("k,e", [(10, 2), (16, 2), (19, 2), (14, 3)])
 def test_gpu_cosets(gpu, orc, pyref, k, e):
     _check(gpu, orc, pyref, k, e, seed=k)
+
+
+def test_coset_arguments_are_checked(emu, orc, pyref):
+    import zk_dcap_verifier_amd as z
+    d = emu.to_device(pc.rand_fr(orc, pyref, 16, 1))
+    o = emu.alloc(16 * 32)
+    with pytest.raises(z.ZkError):
+        emu.coeff_to_coset_batch_dev([d], [o], 4, 6, 4)              # only cosets 0..3 exist
+    with pytest.raises(z.ZkError):
+        emu.coeff_to_coset_batch_dev([d], [o], 4, 3, 0)              # extended_k < k

@@ -309,7 +309,11 @@ int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* ni, uint32_t* ns, uint32_t* nc) { ENTER; return quotient_program_info(ctx, prog, ni, ns, nc); }
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog) { ENTER; return quotient_program_release(ctx, prog); }
 int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args, -1); }
-int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset) { ENTER; return quotient_run(ctx, prog, args, (int)coset); }
+int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset) {
+    ENTER;
+    if (coset >= (1u << 16)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_dev: coset %u out of range", coset);
+    return quotient_run(ctx, prog, args, (int)coset);
+}
 
 int zk_pk_load(zk_ctx* ctx, uint64_t prog, const void* const* fixed, const void* const* sigma, const void* l0, const void* l_last, const void* l_active,
                int form, uint64_t* pk) { ENTER; return pk_load(ctx, prog, fixed, sigma, l0, l_last, l_active, form, pk); }

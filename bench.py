@@ -15,8 +15,10 @@ acceptance check, sgx_dcap_verifier.rs:826-844); a proof that does not verify fa
 uniform, half witness-like sparse; no grand products / lookup permutation / evaluations / SHPLONK) — kept for continuity with
 profiles/r01 run1-run27.
 
-N > 1: one process per GPU, every rank proves its own stream of proofs (weak scaling, no data-path collective); the MSM-sharded
-path (base table split over ranks, 128-byte partial points all-gathered over RCCL) is timed separately and reported under "extra".
+N > 1: one process per GPU, every rank proves its own stream of proofs (weak scaling, no data-path collective) — that is `value`.
+Reported under "extra": ONE proof spread over the ranks (`sharded_proof`: SRS tables sharded by index range, 128-byte partial
+commitments all-gathered; the quotient sharded by extended-domain coset, numerators all-gathered between HBM buffers over RCCL;
+its bytes must equal the single-GPU proof) and the sharded MSM alone (`msm_sharded_2^{21,24}`).
 """
 import argparse
 import json

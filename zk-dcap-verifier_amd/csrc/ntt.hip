@@ -37,6 +37,7 @@ struct NttPassArgs {
     // fused operations
     uint32_t n_valid;       // first pass only (0 = all)
     int quarter_input;      // first pass only: n_valid <= N / 4, so rows >= R/4 of every tile are zero
+    int debug_mode;         // measurements only (results are wrong): 1 = no butterfly stages (memory time of a pass), 2 = no global loads / stores (its arithmetic time)
     // first pass only: input i *= w^((cs_stride * i) mod 2^cs_log) with w's two-level power tables (coset NTT: w = extended_omega, stride = coset)
     const void* cs_lo; const void* cs_hi; uint32_t cs_lo_bits; uint32_t cs_stride; uint32_t cs_log;
     int pre_zeta;
@@ -59,7 +60,9 @@ ZK_HD u256 zeta_pow(uint32_t k) {  // ZETA^k, k in {1, 2}
 }
 ZK_HD u256 ntt_load_input(const NttPassArgs& a, size_t idx) {
     if (a.n_valid && idx >= a.n_valid) return Fr::zero();
-    u256 v = load_u256(a.src, idx);
+    u256 v;
+    if (a.debug_mode == 2) { for (int i = 0; i < 8; i++) v.v[i] = (uint32_t)idx * 0x9e3779b9u + i; v.v[7] &= 0x0fffffffu; }
+    else v = load_u256(a.src, idx);
     if (a.pre_zeta) {
         uint32_t m = (uint32_t)idx % 3u;
         if (m) v = Fr::mul(v, zeta_pow(m));
@@ -176,7 +179,7 @@ ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
         lds_put(lo, hi, bitrev(row, a.r) * C + col, ntt_load_input(a, idx));
     }
     __syncthreads();
-    ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw, a.quarter_input != 0);
+    if (a.debug_mode != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw, a.quarter_input != 0);
     const uint32_t sh = a.log_n - a.blk_log;
     const uint32_t lomask = (1u << a.lo_bits) - 1;
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
@@ -193,7 +196,7 @@ ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
                 v = Fr::mul(v, tw);
             }
         }
-        store_u256(a.dst, base + ((size_t)row << cols_log) + col, v);
+        if (a.debug_mode != 2 || v.v[3] == 0x12345u) store_u256(a.dst, base + ((size_t)row << cols_log) + col, v);
     }
 }
 
@@ -214,11 +217,12 @@ ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
         lds_put(lo, hi, bitrev(row, a.r) * C + col, ntt_load_input(a, (o << a.r) + row));
     }
     __syncthreads();
-    ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw, a.quarter_input != 0);
+    if (a.debug_mode != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw, a.quarter_input != 0);
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
         const uint32_t col = e & (C - 1), row = e >> a.c_log;
         const size_t out_idx = (size_t)(j10 + col) + (((size_t)jm + ((size_t)row << a.p_log)) << a.q_log);
-        store_u256(a.dst, out_idx, ntt_post(a, lds_get(lo, hi, e), out_idx));
+        const u256 v = ntt_post(a, lds_get(lo, hi, e), out_idx);
+        if (a.debug_mode != 2 || v.v[3] == 0x12345u) store_u256(a.dst, out_idx, v);
     }
 }
 
@@ -419,6 +423,7 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
         a.log_n = log_n; a.blk_log = blk_log; a.r = ts->radix_log[p];
         a.stage_tw = ts->d_stage[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits; a.tw_full = last ? nullptr : ts->d_full[p];
         if (first && nf.cs_stride) { a.cs_lo = nf.cs_lo; a.cs_hi = nf.cs_hi; a.cs_lo_bits = nf.cs_lo_bits; a.cs_stride = nf.cs_stride; a.cs_log = nf.cs_log; }
+        a.debug_mode = tn.ntt_debug_mode;
         if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; a.quarter_input = tn.ntt_quarter_input && nf.n_valid && (size_t)nf.n_valid * 4 <= N && a.r >= 2; }
         if (last) { a.post_scale = nf.post_scale; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
         const uint32_t room = tl > a.r ? tl - a.r : 0;

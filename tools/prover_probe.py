@@ -28,6 +28,7 @@ def main():
         out["quotient_by_cosets"] = True
     t = time.time(); pk = z.plonk.keygen(params, cs, fixed, asm); out["keygen_s"] = round(time.time() - t, 3)
     out["program"] = be.quotient_program_info(pk.evaluator.handle)
+    out["program"]["opmix"] = be.quotient_program_opmix(pk.evaluator.handle)
     n = 1 << k
     master = [be.to_device(a) for a in advice]
     work = [be.alloc(n * 32) for _ in advice]

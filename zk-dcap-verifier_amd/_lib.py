@@ -414,6 +414,11 @@ class Backend:
         self._ck(self.lib.zk_quotient_program_info(self.ctx, C.c_uint64(prog), C.byref(a), C.byref(b), C.byref(c)))
         return {"instructions": a.value, "slots": b.value, "columns": c.value}
 
+    def quotient_program_opmix(self, prog: int) -> dict:
+        c = (C.c_uint32 * 9)()
+        self._ck(self.lib.zk_quotient_program_opmix(self.ctx, C.c_uint64(prog), c))
+        return dict(zip(("add", "sub", "mul", "sqr", "dbl", "neg", "mov", "muladd", "memory_operands"), [int(x) for x in c]))
+
     def quotient_program_release(self, prog: int):
         self._ck(self.lib.zk_quotient_program_release(self.ctx, C.c_uint64(prog)))
 

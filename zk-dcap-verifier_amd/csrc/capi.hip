@@ -43,6 +43,7 @@ int g1_ntt(zk_ctx* ctx, const void* d_affine_in, uint32_t log_n, const void* ome
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
+int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]);
 int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, int coset);
 int domain_coeff_to_coset_batch(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek, uint32_t coset);
 int fr_interleave(zk_ctx* ctx, const void* const* h_cosets, size_t count, size_t n, void* d_out);
@@ -307,6 +308,7 @@ int zk_fr_lincomb_dev(zk_ctx* ctx, const void* const* polys_dev, const void* sca
 // ---- quotient -----------------------------------------------------------------------------------
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog) { ENTER; return quotient_program_load(ctx, blob, len, prog); }
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* ni, uint32_t* ns, uint32_t* nc) { ENTER; return quotient_program_info(ctx, prog, ni, ns, nc); }
+int zk_quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]) { ENTER; return quotient_program_opmix(ctx, prog, counts); }
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog) { ENTER; return quotient_program_release(ctx, prog); }
 int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args, -1); }
 int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset) {

@@ -622,6 +622,18 @@ int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_
     if (n_columns) *n_columns = it->second->n_cols;
     return ZK_OK;
 }
+// counts[op] = instructions with opcode op (add, sub, mul, sqr, dbl, neg, mov, muladd), counts[8] = memory (column / constant) operands
+int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]) {
+    auto it = ctx->programs.find(prog);
+    if (it == ctx->programs.end() || !counts) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_opmix: unknown program / null pointer");
+    for (int i = 0; i < 9; i++) counts[i] = 0;
+    for (const uint4& ins : it->second->code) {
+        const uint32_t op = ins.x & 0xffu;
+        if (op < 8) counts[op]++;
+        for (uint32_t src : {ins.y, ins.z, ins.w}) { const uint32_t kind = src >> 28; if (kind == K_COL || kind == K_CONST) counts[8]++; }
+    }
+    return ZK_OK;
+}
 int quotient_program_release(zk_ctx* ctx, uint64_t prog) {
     auto it = ctx->programs.find(prog);
     if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_release: unknown program %llu", (unsigned long long)prog);

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""NTT launches (> 0.2 ms) of the LAST proof in a `rocprofv3 --kernel-trace --output-format csv` trace of tools/prover_probe.py:
+(kernel, grid x, ms).  usage: ntt_trace_summary.py <kernel_trace.csv>   (profiles/r01/run48_ntt_pass_memory_vs_arithmetic.txt)"""
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))

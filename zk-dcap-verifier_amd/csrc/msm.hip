@@ -558,6 +558,7 @@ ZK_KERNEL void msm_merge_kernel(MsmPlan p, uint32_t r, uint32_t Mpow_prev) {
 // One wave per group: every lane adds its members serially, then an LDS tree over the 64 lanes.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t RC_T = 64;
+template <uint32_t SEG>                     // sum over segments of SEG consecutive lanes; valid in each segment's first lane
 __device__ __forceinline__ XYZZ rc_wave_sum(XYZZ acc) {
     __shared__ uint4 pl[8 * RC_T];
     const uint32_t tid = threadIdx.x;
@@ -581,34 +582,40 @@ __device__ __forceinline__ XYZZ rc_wave_sum(XYZZ acc) {
     };
     put(acc);
     __syncthreads();
-    for (uint32_t d = RC_T >> 1; d > 0; d >>= 1) {
-        if (tid < d) { xyzz_add(acc, get(tid + d)); }
+    for (uint32_t d = SEG >> 1; d > 0; d >>= 1) {
+        const bool on = (tid & (SEG - 1)) < d;
+        if (on) { xyzz_add(acc, get(tid + d)); }
         __syncthreads();
-        if (tid < d) put(acc);
+        if (on) put(acc);
         __syncthreads();
     }
-    return acc;   // valid in lane 0
+    return acc;
 }
-// grid (n_hi + n_lo, nb): group g < n_hi is row hi = g, else column lo = g - n_hi.  out[col * (n_hi + n_lo) + g]
+// grid (ceil((n_hi + n_lo) / (RC_T / RC_G)), nb): group g < n_hi is row hi = g, else column lo = g - n_hi.  out[col * (n_hi + n_lo) + g]
+// RC_G lanes per group, each adding its members serially, then a log2(RC_G)-level tree inside the group.  RC_G = 64 (one wave per group) is the
+// shortest dependency chain — single columns, where the launch is latency-bound (0.125 vs 0.186 ms at 2^19); RC_G = 16 spends fewer addition-times
+// per group (a 64-lane group spends 6 of its 10 in the tree, most lanes idle) — batches, where the launch is throughput-bound (0.61 -> 0.40 ms for 25 columns).
+template <uint32_t RC_G>
 ZK_KERNEL void msm_rowcol_kernel(MsmPlan p) {
-    const uint32_t col = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, B = p.B;
+    const uint32_t col = blockIdx.y, tid = threadIdx.x, B = p.B, lane = tid & (RC_G - 1);
     const uint32_t lo_bits = p.lo_bits, n_lo = 1u << lo_bits, n_hi = (B >> lo_bits) + 1;
+    const uint32_t g = blockIdx.x * (RC_T / RC_G) + tid / RC_G;
     const uint32_t r = plan_eff_levels(p, plan_small(p, col)[p.o_info]);
     const uint32_t* so = plan_suboff(p, col, r);
     const void* buf = p.sub[r & 1];
     const size_t cbase = (size_t)col * p.sub_stride[r & 1];
     XYZZ acc = xyzz_identity();
-    const bool row = g < n_hi;
-    const uint32_t fixed = row ? g : g - n_hi, count = row ? n_lo : n_hi;
-    for (uint32_t m = tid; m < count; m += RC_T) {
+    const bool live = g < n_hi + n_lo, row = g < n_hi;
+    const uint32_t fixed = row ? g : g - n_hi, count = live ? (row ? n_lo : n_hi) : 0u;
+    for (uint32_t m = lane; m < count; m += RC_G) {
         const uint32_t w = row ? ((fixed << lo_bits) | m) : ((m << lo_bits) | fixed);
         if (w >= 1 && w <= B) {
             const uint32_t b = w - 1;
             if (so[b + 1] > so[b]) xyzz_add(acc, load_xyzz(buf, cbase + so[b]));
         }
     }
-    acc = rc_wave_sum(acc);
-    if (tid == 0) store_xyzz(p.cls[0], (size_t)col * (n_hi + n_lo) + g, acc);
+    acc = rc_wave_sum<RC_G>(acc);
+    if (live && lane == 0) store_xyzz(p.cls[0], (size_t)col * (n_hi + n_lo) + g, acc);
 }
 // grid (c, nb): class t < hi_bits sums the rows whose index has bit t, class hi_bits + t' the columns whose index has bit t'
 ZK_KERNEL void msm_rc_class_kernel(MsmPlan p) {
@@ -620,7 +627,7 @@ ZK_KERNEL void msm_rc_class_kernel(MsmPlan p) {
     XYZZ acc = xyzz_identity();
     for (uint32_t m = tid; m < count; m += RC_T)
         if ((m >> bit) & 1u) xyzz_add(acc, load_xyzz(p.cls[0], base + m));
-    acc = rc_wave_sum(acc);
+    acc = rc_wave_sum<RC_T>(acc);
     if (tid == 0) store_xyzz(p.cls[1], (size_t)col * p.c + t, acc);
 }
 
@@ -912,7 +919,8 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
             pw *= M;
         }
     }
-    ZK_LAUNCH(msm_rowcol_kernel, dim3(n_groups, nb), RC_T, 0, st, p);
+    if (nb >= 4) { ZK_LAUNCH(msm_rowcol_kernel<16>, dim3((n_groups + 3) / 4, nb), RC_T, 0, st, p); }
+    else { ZK_LAUNCH(msm_rowcol_kernel<64>, dim3(n_groups, nb), RC_T, 0, st, p); }
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(msm_rc_class_kernel, dim3((uint32_t)c, nb), RC_T, 0, st, p);
     ZK_CHECK_LAUNCH();

@@ -67,30 +67,11 @@ ZK_KERNEL void gp_lookup_fraction_batch_kernel(const void* const* cols, uint32_t
     store_u256(num, (size_t)l * n + i, Fr::mul(Fr::add(load_u256(c[0], i), beta), Fr::add(load_u256(c[1], i), gamma)));
     store_u256(den, (size_t)l * n + i, Fr::mul(Fr::add(load_u256(c[2], i), beta), Fr::add(load_u256(c[3], i), gamma)));
 }
-// frac[i] = num[i] / den[i] in place on num; one inversion per `chunk` rows (0 denominators invert to 0, as batch_invert does)
-ZK_KERNEL void gp_batch_divide_kernel(void* num, const void* den, uint32_t n, uint32_t chunk, void* scratch) {
-    const uint64_t lo64 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * chunk;
-    if (lo64 >= n) return;
-    const uint32_t lo = (uint32_t)lo64, hi = lo + chunk < n ? lo + chunk : n;
-    u256 acc = Fr::one();
-    for (uint32_t k = lo; k < hi; k++) {
-        store_u256(scratch, k, acc);
-        const u256 d = load_u256(den, k);
-        if (!Fr::is_zero(d)) acc = Fr::mul(acc, d);
-    }
-    u256 inv = Fr::inv(acc);
-    for (uint32_t k = hi; k-- > lo;) {
-        const u256 d = load_u256(den, k);
-        u256 di = Fr::zero();
-        if (!Fr::is_zero(d)) { di = Fr::mul(inv, load_u256(scratch, k)); inv = Fr::mul(inv, d); }
-        store_u256(num, k, Fr::mul(load_u256(num, k), di));
-    }
-}
-
 // ---- prefix product ------------------------------------------------------------------------------
+template <bool REVERSE = false>            // REVERSE: exclusive SUFFIX products (the scan runs over the threads in descending order)
 __device__ __forceinline__ u256 gp_block_exclusive_scan(u256 mine, u256* total_out) {
     __shared__ uint4 slo[GP_T], shi[GP_T];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = REVERSE ? blockDim.x - 1 - threadIdx.x : threadIdx.x;
     u256 incl = mine;
     slo[tid] = make_uint4(incl.v[0], incl.v[1], incl.v[2], incl.v[3]);
     shi[tid] = make_uint4(incl.v[4], incl.v[5], incl.v[6], incl.v[7]);
@@ -122,6 +103,42 @@ __device__ __forceinline__ u256 gp_block_exclusive_scan(u256 mine, u256* total_o
     __syncthreads();
     return excl;
 }
+// frac[i] = num[i] / den[i] in place on num (0 denominators invert to 0, as batch_invert does): Montgomery's trick on two levels — every thread
+// chains its `chunk` rows (prefix products to scratch), the workgroup chains its threads' totals (prefix and suffix scans in LDS), ONE field
+// inversion per workgroup (a thread-level inversion per 32 rows was 9 of the 12 products a row cost); 1 / total_t = 1/T * prefix_t * suffix_t.
+// The rows of a thread are strided by the thread count (row j * threads + g), so the lanes of a wave touch neighbouring 32-byte elements at every step.
+ZK_KERNEL void gp_batch_divide_kernel(void* num, const void* den, uint32_t n, uint32_t chunk, void* scratch) {
+    __shared__ uint4 binv[2];
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = ((uint64_t)n + chunk - 1) / chunk;
+    uint32_t cnt = 0;
+    u256 acc = Fr::one();
+    if (g < nth)
+        for (uint64_t k = g; k < n && cnt < chunk; k += nth, cnt++) {
+            store_u256(scratch, k, acc);
+            const u256 d = load_u256(den, k);
+            if (!Fr::is_zero(d)) acc = Fr::mul(acc, d);
+        }
+    u256 total;
+    const u256 pre = gp_block_exclusive_scan<false>(acc, &total);
+    const u256 suf = gp_block_exclusive_scan<true>(acc, nullptr);
+    if (threadIdx.x == 0) {
+        const u256 t = Fr::inv(total);
+        binv[0] = make_uint4(t.v[0], t.v[1], t.v[2], t.v[3]);
+        binv[1] = make_uint4(t.v[4], t.v[5], t.v[6], t.v[7]);
+    }
+    __syncthreads();
+    u256 inv;
+    { const uint4 l = binv[0], h = binv[1]; inv.v[0] = l.x; inv.v[1] = l.y; inv.v[2] = l.z; inv.v[3] = l.w; inv.v[4] = h.x; inv.v[5] = h.y; inv.v[6] = h.z; inv.v[7] = h.w; }
+    inv = Fr::mul(inv, Fr::mul(pre, suf));
+    for (uint32_t j = cnt; j-- > 0;) {
+        const uint64_t k = g + (uint64_t)j * nth;
+        const u256 d = load_u256(den, k);
+        u256 di = Fr::zero();
+        if (!Fr::is_zero(d)) { di = Fr::mul(inv, load_u256(scratch, k)); inv = Fr::mul(inv, d); }
+        store_u256(num, k, Fr::mul(load_u256(num, k), di));
+    }
+}
+
 // phase A: x[i] <- inclusive prefix product inside the workgroup's span; totals[b] <- product of the span
 ZK_KERNEL void gp_scan_local_kernel(void* x, uint32_t n, void* totals) {
     const uint32_t span = blockDim.x * GP_E;
@@ -194,7 +211,8 @@ static int gp_finish(zk_ctx* ctx, void* d_frac, void* d_den_scratch, void* d_aux
     hipStream_t st = ctx->stream;
     const int blk = ctx->tune.vec_block;
     const uint32_t chunk = 32;
-    ZK_LAUNCH(gp_batch_divide_kernel, (uint32_t)(((n + chunk - 1) / chunk + blk - 1) / blk), blk, 0, st, d_frac, (const void*)d_den_scratch, n, chunk, d_aux);
+    const int dblk = std::min<int>(ctx->tune.vec_block, (int)GP_T);   // the division kernel scans over its workgroup in LDS arrays of GP_T entries
+    ZK_LAUNCH(gp_batch_divide_kernel, (uint32_t)(((n + chunk - 1) / chunk + dblk - 1) / dblk), dblk, 0, st, d_frac, (const void*)d_den_scratch, n, chunk, d_aux);
     ZK_CHECK_LAUNCH();
     const uint32_t span = GP_T * GP_E, nblocks = (n + span - 1) / span;
     void* d_tot = (char*)d_aux;                       // scratch is free again after the division
@@ -303,7 +321,8 @@ int lookup_product_batch(zk_ctx* ctx, const void* const* cols4, size_t count, ui
               (void*)(base + o_num), (void*)(base + o_den));
     ZK_CHECK_LAUNCH();
     const uint32_t chunk = 32;
-    ZK_LAUNCH(gp_batch_divide_kernel, (uint32_t)(((N + chunk - 1) / chunk + blk - 1) / blk), blk, 0, st, (void*)(base + o_num), (const void*)(base + o_den), (uint32_t)N, chunk,
+    const int dblk = std::min<int>(ctx->tune.vec_block, (int)GP_T);   // the division kernel scans over its workgroup in LDS arrays of GP_T entries
+    ZK_LAUNCH(gp_batch_divide_kernel, (uint32_t)(((N + chunk - 1) / chunk + dblk - 1) / dblk), dblk, 0, st, (void*)(base + o_num), (const void*)(base + o_den), (uint32_t)N, chunk,
               (void*)(base + o_scr));
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(gp_scan_local_kernel, (uint32_t)(count * nblocks), GP_T, 0, st, (void*)(base + o_num), (uint32_t)N, (void*)(base + o_tot));
@@ -383,7 +402,8 @@ int permutation_product_all(zk_ctx* ctx, const void* const* values, const void* 
     ZK_HIP(hipMemcpyAsync(base + o_zp, d_zs, n_sets * sizeof(void*), hipMemcpyHostToDevice, st));
     if (bf) ZK_HIP(hipMemcpyAsync(base + o_bl, blinding, n_sets * (size_t)bf * 32, hipMemcpyHostToDevice, st));
     const uint32_t chunk = 32;
-    ZK_LAUNCH(gp_batch_divide_kernel, (uint32_t)(((N + chunk - 1) / chunk + blk - 1) / blk), blk, 0, st, (void*)(base + o_num), (const void*)(base + o_den), (uint32_t)N, chunk,
+    const int dblk = std::min<int>(ctx->tune.vec_block, (int)GP_T);   // the division kernel scans over its workgroup in LDS arrays of GP_T entries
+    ZK_LAUNCH(gp_batch_divide_kernel, (uint32_t)(((N + chunk - 1) / chunk + dblk - 1) / dblk), dblk, 0, st, (void*)(base + o_num), (const void*)(base + o_den), (uint32_t)N, chunk,
               (void*)(base + o_scr));
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(gp_scan_local_kernel, (uint32_t)(n_sets * nblocks), GP_T, 0, st, (void*)(base + o_num), (uint32_t)N, (void*)(base + o_tot));

@@ -226,3 +226,24 @@ def test_emulated_bench_program(emu, orc, pyref):
 @pytest.mark.gpu
 def test_gpu_bench_program(gpu, orc, pyref):
     _bench_program_case(gpu, orc, pyref, 9)
+
+
+
+@pytest.mark.parametrize("seed,shape", SHAPES[:2])
+def test_emulated_quotient_two_rows_per_thread(emu, orc, pyref, seed, shape):
+    """quot_rows = 2: one micro-op decode serves two rows of the extended domain; same values."""
+    emu.tune(quot_rows=2, quot_threads=4)
+    try:
+        qc.run_case(emu, orc, pyref, pc, qc.build_program(orc, pyref, seed=seed, **shape), seed=seed)
+    finally:
+        emu.tune(quot_rows=1, quot_threads=32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,shape", [SHAPES[0], (5, dict(k=10, cs_degree=5, n_fixed=4, n_advice=6, n_instance=1, n_challenges=1, n_perm=7, n_lookups=3))])
+def test_gpu_quotient_two_rows_per_thread(gpu, orc, pyref, seed, shape):
+    gpu.tune(quot_rows=2)
+    try:
+        qc.run_case(gpu, orc, pyref, pc, qc.build_program(orc, pyref, seed=seed, gate_ops=60 if shape["k"] >= 10 else 24, **shape), seed=seed)
+    finally:
+        gpu.tune(quot_rows=1)

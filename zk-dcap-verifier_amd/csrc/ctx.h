@@ -34,6 +34,7 @@ struct Tune {
     int ntt_debug_mode = 0;      // measurements only (WRONG results): 1 = passes without their butterfly stages, 2 = without global loads / stores
     int vec_block = 256;
     int quot_threads = 128;
+    int quot_rows = 1;           // rows per thread of the quotient interpreter (2: one micro-op decode serves two rows)
     int quot_remat_ops = 4;      // quotient compiler: a shared sub-expression of at most this many operations ...
     int quot_remat_distance = 24;   // ... is recomputed when its previous copy lies further back than this many micro-ops
     int lookup_force_generic_sort = 0;   // tests: take the every-digit sort of permute_expression_pair even when the 64-bit window sort is exact

@@ -79,87 +79,111 @@ struct QuotArgs {
 // constant operands of instruction pc + 1 are already in flight (the kernel is otherwise bound by the latency of ~850
 // dependent 32-byte loads per row, not by arithmetic: profiles/r01).  Slot, accumulator and X-power operands are read at
 // execute time because the previous instruction may just have written them.
-ZK_KERNEL void quotient_kernel(QuotArgs q) {
+// NR rows per thread (rows idx, idx + T, ...): one decode of a micro-op serves NR rows — the decode is ≈50 issue slots against ≈300 for a product.
+template <int NR>
+ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) quotient_kernel(QuotArgs q) {
     ZK_DYN_SHARED(uint4, smem);
     const uint32_t T = blockDim.x, tid = threadIdx.x;
-    const uint32_t idx = blockIdx.x * T + tid;
+    const uint32_t idx0 = blockIdx.x * (T * NR) + tid;          // row r of this thread: idx0 + r * T
     const uint32_t mask = (1u << q.size_log) - 1u;
-    u256 acc = Fr::zero(), xpow = Fr::one();
-    u256 rg0 = Fr::zero(), rg1 = rg0, rg2 = rg0;   // slots 0..QUOT_NREG-1 live in VGPRs
-    if (q.uses_xpow) {  // extended_omega^(position of this row in the extended domain)
-        const uint32_t xi = idx * q.xpow_mul + q.xpow_add;
-        xpow = load_u256(q.tw_lo, xi & ((1u << q.lo_bits) - 1u));
-        const uint32_t h = xi >> q.lo_bits;
-        if (h) xpow = Fr::mul(xpow, load_u256(q.tw_hi, h));
-    }
-    auto prefetch = [&](uint32_t src) -> u256 {        // memory operands only; everything else is resolved later
-        const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
-        if (kind == K_COL) {
-            const uint32_t row = (idx + q.rot_off[pay & 0xffu]) & mask;
-            return load_u256(q.cols[pay >> 8], row);
+    u256 acc[NR], xpow[NR], rg0[NR], rg1[NR], rg2[NR];          // slots 0..QUOT_NREG-1 live in VGPRs
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        acc[r] = Fr::zero(); xpow[r] = Fr::one(); rg0[r] = rg1[r] = rg2[r] = Fr::zero();
+        if (q.uses_xpow) {  // extended_omega^(position of this row in the extended domain)
+            const uint32_t xi = (idx0 + r * T) * q.xpow_mul + q.xpow_add;
+            xpow[r] = load_u256(q.tw_lo, xi & ((1u << q.lo_bits) - 1u));
+            const uint32_t h = xi >> q.lo_bits;
+            if (h) xpow[r] = Fr::mul(xpow[r], load_u256(q.tw_hi, h));
         }
-        if (kind == K_CONST) return load_u256(q.consts, pay);
-        return Fr::zero();
+    }
+    struct Rows { u256 v[NR]; };
+    auto prefetch = [&](uint32_t src) -> Rows {        // memory operands only; everything else is resolved later
+        const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
+        Rows o;
+        if (kind == K_COL) {
+            const uint32_t off = q.rot_off[pay & 0xffu];
+            const void* col = q.cols[pay >> 8];
+#pragma unroll
+            for (int r = 0; r < NR; r++) o.v[r] = load_u256(col, (idx0 + r * T + off) & mask);
+            return o;
+        }
+        if (kind == K_CONST) {
+            const u256 c = load_u256(q.consts, pay);
+#pragma unroll
+            for (int r = 0; r < NR; r++) o.v[r] = c;
+            return o;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) o.v[r] = Fr::zero();
+        return o;
     };
-    auto resolve = [&](uint32_t src, const u256& pre) -> u256 {
+    auto resolve = [&](uint32_t src, const Rows& pre, int r) -> u256 {
         const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
         switch (kind) {
             case K_SLOT: {
                 switch (pay) {
-                    case 0: return rg0; case 1: return rg1; case 2: return rg2;
+                    case 0: return rg0[r]; case 1: return rg1[r]; case 2: return rg2[r];
                     default: break;
                 }
-                const uint32_t ls = pay - QUOT_NREG;
+                const uint32_t ls = (pay - QUOT_NREG) * NR + r;
                 uint4 l = smem[(2 * ls) * T + tid], h = smem[(2 * ls + 1) * T + tid];
                 u256 o;
                 o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w;
                 return o;
             }
-            case K_ACC: return acc;
-            case K_XPOW: return xpow;
-            default: return pre;       // K_COL / K_CONST (already loaded) or K_NONE
+            case K_ACC: return acc[r];
+            case K_XPOW: return xpow[r];
+            default: return pre.v[r];       // K_COL / K_CONST (already loaded) or K_NONE
         }
     };
     uint4 ins = q.n_instr ? q.code[0] : make_uint4(M_MOV | (1u << 8), K_NONE << 28, K_NONE << 28, K_NONE << 28);
-    u256 pa = prefetch(ZK_UNIFORM(ins.y)), pb = prefetch(ZK_UNIFORM(ins.z)), pc_ = prefetch(ZK_UNIFORM(ins.w));
+    Rows pa = prefetch(ZK_UNIFORM(ins.y)), pb = prefetch(ZK_UNIFORM(ins.z)), pc_ = prefetch(ZK_UNIFORM(ins.w));
     for (uint32_t pc = 0; pc < q.n_instr; pc++) {
         const uint32_t w0 = ZK_UNIFORM(ins.x), sa = ZK_UNIFORM(ins.y), sb = ZK_UNIFORM(ins.z), sc = ZK_UNIFORM(ins.w);
         // put the next instruction's loads in flight before this one's arithmetic
         uint4 nxt = ins;
-        u256 na = pa, nb = pb, nc = pc_;
+        Rows na = pa, nb = pb, nc = pc_;
         if (pc + 1 < q.n_instr) {
             nxt = q.code[pc + 1];
             na = prefetch(ZK_UNIFORM(nxt.y)); nb = prefetch(ZK_UNIFORM(nxt.z)); nc = prefetch(ZK_UNIFORM(nxt.w));
         }
         const uint32_t op = w0 & 0xffu;
-        const u256 a = resolve(sa, pa);
-        u256 r;
-        switch (op) {
-            case M_ADD: r = Fr::add(a, resolve(sb, pb)); break;
-            case M_SUB: r = Fr::sub(a, resolve(sb, pb)); break;
-            case M_MUL: r = Fr::mul(a, resolve(sb, pb)); break;
-            case M_SQR: r = Fr::sqr(a); break;
-            case M_DBL: r = Fr::dbl(a); break;
-            case M_NEG: r = Fr::neg(a); break;
-            case M_MULADD: r = Fr::add(Fr::mul(a, resolve(sb, pb)), resolve(sc, pc_)); break;
-            default: r = a; break;
+        u256 res[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const u256 a = resolve(sa, pa, r);
+            switch (op) {
+                case M_ADD: res[r] = Fr::add(a, resolve(sb, pb, r)); break;
+                case M_SUB: res[r] = Fr::sub(a, resolve(sb, pb, r)); break;
+                case M_MUL: res[r] = Fr::mul(a, resolve(sb, pb, r)); break;
+                case M_SQR: res[r] = Fr::sqr(a); break;
+                case M_DBL: res[r] = Fr::dbl(a); break;
+                case M_NEG: res[r] = Fr::neg(a); break;
+                case M_MULADD: res[r] = Fr::add(Fr::mul(a, resolve(sb, pb, r)), resolve(sc, pc_, r)); break;
+                default: res[r] = a; break;
+            }
         }
-        if ((w0 >> 8) & 0xffu) {
-            acc = r;
-        } else {
-            const uint32_t slot = w0 >> 16;
-            switch (slot) {
-                case 0: rg0 = r; break; case 1: rg1 = r; break; case 2: rg2 = r; break;
-                default: {
-                    const uint32_t ls = slot - QUOT_NREG;
-                    smem[(2 * ls) * T + tid] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-                    smem[(2 * ls + 1) * T + tid] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if ((w0 >> 8) & 0xffu) {
+                acc[r] = res[r];
+            } else {
+                const uint32_t slot = w0 >> 16;
+                switch (slot) {
+                    case 0: rg0[r] = res[r]; break; case 1: rg1[r] = res[r]; break; case 2: rg2[r] = res[r]; break;
+                    default: {
+                        const uint32_t ls = (slot - QUOT_NREG) * NR + r;
+                        smem[(2 * ls) * T + tid] = make_uint4(res[r].v[0], res[r].v[1], res[r].v[2], res[r].v[3]);
+                        smem[(2 * ls + 1) * T + tid] = make_uint4(res[r].v[4], res[r].v[5], res[r].v[6], res[r].v[7]);
+                    }
                 }
             }
         }
         ins = nxt; pa = na; pb = nb; pc_ = nc;
     }
-    store_u256(q.out, idx, acc);
+#pragma unroll
+    for (int r = 0; r < NR; r++) store_u256(q.out, idx0 + r * T, acc[r]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -648,7 +672,8 @@ void release_programs(zk_ctx* ctx) {
 
 int quotient_set_lds_attr() {
 #ifndef ZK_EMU
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
     return 0;
 }
@@ -720,15 +745,17 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
         int rc = ntt_pow_tables(ctx, P.ek, domain_omega(P.ek), &q.tw_lo, &q.tw_hi, &q.lo_bits);
         if (rc) return rc;
     }
-    uint32_t T = (uint32_t)ctx->tune.quot_threads;
+    uint32_t T = (uint32_t)std::min(ctx->tune.quot_threads, 256);     // the kernel is compiled for <= 256 threads per workgroup
     if (T > size) T = (uint32_t)size;
     const uint32_t lds_slots = P.n_slots > QUOT_NREG ? P.n_slots - QUOT_NREG : 0;
     while (T > 64 && (size_t)lds_slots * T * 32 > 32 * 1024) T >>= 1;
     if (T < 1) T = 1;
-    const size_t lds = (size_t)lds_slots * T * 32;
+    const uint32_t NR = (ctx->tune.quot_rows >= 2 && size % ((size_t)T * 2) == 0) ? 2u : 1u;      // rows per thread
+    const size_t lds = (size_t)lds_slots * T * 32 * NR;
     if (lds > 160 * 1024) return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %zu bytes of LDS", lds);
     EvTimer tq(ctx, "quotient");
-    ZK_LAUNCH(quotient_kernel, (uint32_t)(size / T), T, lds, st, q);
+    if (NR == 2) { ZK_LAUNCH(quotient_kernel<2>, (uint32_t)(size / T / 2), T, lds, st, q); }
+    else { ZK_LAUNCH(quotient_kernel<1>, (uint32_t)(size / T), T, lds, st, q); }
     ZK_CHECK_LAUNCH();
     tq.stop();
     ZK_HIP(hipStreamSynchronize(st));

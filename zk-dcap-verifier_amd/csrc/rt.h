@@ -17,4 +17,5 @@
     extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
     type* name = reinterpret_cast<type*>(name##_raw)
 #define ZK_KERNEL __global__
+#define ZK_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 #endif

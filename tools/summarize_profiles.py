@@ -11,7 +11,7 @@ import sys
 
 
 def short(n):
-    return re.sub(r"\(.*", "", n).replace("zk::", "")
+    return re.sub(r"<.*", "", re.sub(r"\(.*", "", n).replace("zk::", "").replace("void ", ""))      # templates: quotient_kernel<1> -> quotient_kernel
 
 
 def last_json_line(path):

@@ -12,7 +12,12 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     short = lambda r: r["Kernel_Name"].split("(")[0].replace("zk::", "")
-    first = [i for i, r in enumerate(rows) if short(r) in ("msm_bin_hist_kernel", "msm_hist_kernel")]
+    first, prev_msm = [], False                      # an MSM batch starts at the first msm_* kernel after a non-msm one
+    for i, r in enumerate(rows):
+        is_msm = short(r).replace("void ", "").startswith("msm_")
+        if is_msm and not prev_msm:
+            first.append(i)
+        prev_msm = is_msm
     start = first[-per_proof]
     agg = collections.OrderedDict()
     for r in rows[start:]:
@@ -25,9 +30,9 @@ def main():
     for i in first[-per_proof:]:
         out = []
         for r in rows[i:i + 40]:
-            if not short(r).startswith("msm"):
+            if not short(r).replace("void ", "").startswith("msm"):
                 break
-            out.append((short(r)[4:12], round(dur(r), 3)))
+            out.append((short(r).replace("void ", "")[4:12], round(dur(r), 3)))
         print("cols", rows[i].get("Grid_Size_Y"), out)
 
 

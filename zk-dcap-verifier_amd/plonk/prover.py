@@ -18,6 +18,8 @@ Single circuit instance per proof (the reference passes `&[circuit]`); no user c
 """
 from __future__ import annotations
 
+import threading
+
 import time
 from typing import List, Optional, Sequence
 
@@ -145,19 +147,28 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
         perm_values.append({ADVICE: adv_values, FIXED: pk.fixed_values, INSTANCE: inst_values}[t][i])
     chunk = cs.permutation_chunk_len()
     n_sets = (len(perm_values) + chunk - 1) // chunk if perm_values else 0
-    zs = permutation_commit(perm_values, pk.sigma_values, k, cs.degree(), bt_m, gm_m, [rand_fr_array(rng, bf) for _ in range(n_sets)], backend=be) \
-        if perm_values else []
-    owned += zs
-    lzs = lookup_commit_products([(c[0], c[1], p_[0], p_[1]) for c, p_ in zip(compressed, permuted)], k, bt_m, gm_m,
-                                 np.stack([rand_fr_array(rng, bf) for _ in compressed]) if compressed else np.zeros((0, bf, 4), np.uint64), backend=be)
-    owned += lzs
+    # every random draw of phases 4 and 5 up front, in the order the phases consume them: the two blinding sets, then — on a helper thread,
+    # while the GPU builds the grand products — the n coefficients of the vanishing argument's random polynomial (3-4 ms of host RNG that
+    # otherwise sits between two commitment phases with the GPU idle)
+    perm_blind = [rand_fr_array(rng, bf) for _ in range(n_sets)]
+    lookup_blind = np.stack([rand_fr_array(rng, bf) for _ in compressed]) if compressed else np.zeros((0, bf, 4), np.uint64)
+    drawn = {}
+    drawer = threading.Thread(target=lambda: drawn.__setitem__("random_poly", rand_fr_array(rng, n)))
+    drawer.start()
+    try:
+        zs = permutation_commit(perm_values, pk.sigma_values, k, cs.degree(), bt_m, gm_m, perm_blind, backend=be) if perm_values else []
+        owned += zs
+        lzs = lookup_commit_products([(c[0], c[1], p_[0], p_[1]) for c, p_ in zip(compressed, permuted)], k, bt_m, gm_m, lookup_blind, backend=be)
+        owned += lzs
+    finally:
+        drawer.join()                                               # (the generator is used by nobody else until here)
     for pt in commit_all("g_lagrange", zs + lzs):      # permutation products, then lookup products: one MSM batch, transcript order kept
         transcript.write_point(pt)
 
     lap("4_grand_products")
     # ---- 5. vanishing argument: random polynomial -----------------------------------------------------------------------------
     random_poly = dev(n * 32)
-    random_poly.upload(rand_fr_array(rng, n))
+    random_poly.upload(drawn["random_poly"])
     transcript.write_point(commit_all("g", [random_poly])[0])
 
     lap("5_random_poly")

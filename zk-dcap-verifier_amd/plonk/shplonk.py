@@ -66,6 +66,23 @@ def lagrange_interpolate(points: Sequence[int], evals: Sequence[int]) -> List[in
     return coeffs
 
 
+def lagrange_basis(points: Sequence[int]) -> List[List[int]]:
+    """coefficients of the Lagrange basis polynomials of a point set: lagrange_interpolate(points, evals) = sum_j evals[j] * basis[j].
+    A rotation set interpolates every one of its commitments over the SAME points, so the products and the modular inverses are done once per set."""
+    n = len(points)
+    out = []
+    for j in range(n):
+        unit = [0] * n
+        unit[j] = 1
+        out.append(lagrange_interpolate(points, unit))
+    return out
+
+
+def interpolate_with_basis(basis: Sequence[Sequence[int]], evals: Sequence[int]) -> List[int]:
+    n = len(basis)
+    return [sum(evals[j] * basis[j][i] for j in range(n)) % R_MOD for i in range(n)]
+
+
 def eval_poly_ints(coeffs: Sequence[int], x: int) -> int:
     acc = 0
     for c in reversed(coeffs):
@@ -99,8 +116,9 @@ class ProverSHPLONK:
         for pts, commitments in rotation_sets:
             ypow, scal, polys, rsum = 1, [], [], [0] * len(pts)
             rs = []
+            basis = lagrange_basis(pts)
             for q, evals in commitments:
-                r = lagrange_interpolate(pts, evals)
+                r = interpolate_with_basis(basis, evals)
                 rs.append(r)
                 for i, c in enumerate(r):
                     rsum[i] = (rsum[i] - ypow * c) % R_MOD

@@ -36,11 +36,9 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
 def rand_fr(n, seed):
-    """n values < 2^253 < r as (n, 4) uint64 — used directly as Montgomery-form field elements."""
-    rng = np.random.default_rng(seed)
-    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
-    a[:, 3] &= np.uint64((1 << 61) - 1)
-    return a
+    """n field elements uniform in [0, r) by rejection (BASELINE.md §3 / SURVEY 8d cfg 3) as (n, 4) uint64 raw limbs, read as Montgomery forms."""
+    from zk_dcap_verifier_amd.fields import rand_fr_array
+    return rand_fr_array(np.random.default_rng(seed), n)
 
 
 def witness_like(n, seed):

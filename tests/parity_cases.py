@@ -8,10 +8,8 @@ import zk_dcap_verifier_amd as z
 
 
 def rand_fr(orc, pyref, n, seed):
-    rng = np.random.default_rng(seed)
-    raw = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
-    raw[:, 3] &= np.uint64((1 << 61) - 1)          # < 2^253 < r : canonical values, then treat as Montgomery
-    return np.ascontiguousarray(raw)
+    """n field elements uniform in [0, r) (rejection sampling), raw limbs read as Montgomery forms"""
+    return np.ascontiguousarray(z.fields.rand_fr_array(np.random.default_rng(seed), n))
 
 
 def check_vec_ops(be, orc, pyref, n, seed=11):

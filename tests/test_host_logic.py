@@ -87,3 +87,50 @@ def test_xyzz_group_law_including_special_cases(hh, orc, pyref):
     o5 = np.zeros(16, dtype=np.uint64)
     hh.hh_xyzz_dbl(P(out), P(o5))
     assert xyzz_to_affine(orc, p, o5) == p.g1_add(want, want)
+
+
+def test_chained_copy_rows_equals_scalar_copy_and_is_a_bijection():
+    """Assembly.copy_rows must only take its vectorised path for cells that are their own (singleton) cycle: `sizes` is kept for cycle
+    representatives only, so after copy_rows(A, B) the B cells still read size 1 — a chained copy_rows(B, C) has to fall back to copy()."""
+    import numpy as np
+    from zk_dcap_verifier_amd import plonk
+    from zk_dcap_verifier_amd.plonk import ADVICE
+    cs = plonk.ConstraintSystem(num_advice_columns=4)
+    for c in range(4):
+        cs.enable_equality(ADVICE, c)
+    rows = [0, 1, 2, 3, 5]
+    fast, slow = plonk.Assembly(cs, 3), plonk.Assembly(cs, 3)
+    fast.copy_rows((ADVICE, 0), (ADVICE, 1), rows)
+    fast.copy_rows((ADVICE, 1), (ADVICE, 2), rows)
+    fast.copy_rows((ADVICE, 3), (ADVICE, 0), [5, 6])
+    for r in rows:
+        slow.copy((ADVICE, 0, r), (ADVICE, 1, r))
+    for r in rows:
+        slow.copy((ADVICE, 1, r), (ADVICE, 2, r))
+    for r in (5, 6):
+        slow.copy((ADVICE, 3, r), (ADVICE, 0, r))
+    assert (fast.map_c == slow.map_c).all() and (fast.map_r == slow.map_r).all()
+    succ = set(zip(fast.map_c.ravel().tolist(), fast.map_r.ravel().tolist()))
+    assert len(succ) == 4 * 8                                       # the successor map is a permutation of the cells
+    # the cycle through (0, 0) is A -> B -> C -> A in some rotation: three cells
+    seen, cell = [], (0, 0)
+    while cell not in seen:
+        seen.append(cell)
+        cell = (int(fast.map_c[cell]), int(fast.map_r[cell]))
+    assert sorted(seen) == [(0, 0), (1, 0), (2, 0)]
+
+
+def test_rand_fr_array_is_uniform_below_r_and_reproducible():
+    import numpy as np
+    from zk_dcap_verifier_amd import fields as F
+    a = F.rand_fr_array(np.random.default_rng(5), 4000)
+    b = F.rand_fr_array(np.random.default_rng(5), 4000)
+    assert (a == b).all()
+    vals = [F.unlimbs(x) for x in a]
+    assert all(v < F.R_MOD for v in vals)
+    top = sum(v >= (1 << 253) for v in vals) / len(vals)            # (r - 2^253) / r = 0.339 of the field lies above 2^253
+    assert 0.30 < top < 0.38
+    edge = np.array([F.limbs(F.R_MOD), F.limbs(F.R_MOD - 1), F.limbs(F.R_MOD + 1), F.limbs(0)], dtype=np.uint64)
+    assert F._below_r(edge).tolist() == [False, True, False, True]
+    c = F.rand_fr_array(F.OsRng(), 100)
+    assert c.shape == (100, 4) and all(F.unlimbs(x) < F.R_MOD for x in c)

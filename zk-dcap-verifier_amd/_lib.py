@@ -63,11 +63,12 @@ class DeviceBuffer:
 
     def __init__(self, backend: "Backend", nbytes: int):
         self.backend, self.nbytes = backend, int(nbytes)
-        cached = backend._pool.get(self.nbytes)
-        if cached:                                    # hipMalloc / hipFree of 16-64 MiB columns cost far more than the kernels between them
-            self.ptr = cached.pop()
-            backend._pool_bytes -= self.nbytes
-            return
+        with backend._pool_lock:                      # several host threads may share one Backend
+            cached = backend._pool.get(self.nbytes)
+            if cached:                                # hipMalloc / hipFree of 16-64 MiB columns cost far more than the kernels between them
+                self.ptr = cached.pop()
+                backend._pool_bytes -= self.nbytes
+                return
         p = C.c_void_p()
         backend._ck(backend.lib.zk_dev_alloc(backend.ctx, C.c_size_t(self.nbytes), C.byref(p)))
         self.ptr = p.value
@@ -97,12 +98,14 @@ class DeviceBuffer:
     def free(self):
         if self.ptr:
             b = self.backend
-            if b.ctx and b._pool_bytes + self.nbytes <= b.pool_limit_bytes:
-                b._pool.setdefault(self.nbytes, []).append(self.ptr)      # size-keyed free list, released by Backend.close()
-                b._pool_bytes += self.nbytes
-            elif b.ctx:
-                b.lib.zk_dev_free(b.ctx, C.c_void_p(self.ptr))
-            self.ptr = 0
+            ptr, self.ptr = self.ptr, 0
+            with b._pool_lock:
+                keep = bool(b.ctx) and b._pool_bytes + self.nbytes <= b.pool_limit_bytes
+                if keep:
+                    b._pool.setdefault(self.nbytes, []).append(ptr)       # size-keyed free list, released by Backend.close()
+                    b._pool_bytes += self.nbytes
+            if not keep and b.ctx:
+                b.lib.zk_dev_free(b.ctx, C.c_void_p(ptr))
 
     def __del__(self):
         try:
@@ -123,7 +126,7 @@ class Backend:
             raise ZkError(rc, f"zk_ctx_create(device={device}) failed — no usable gfx950 GPU? (no CPU fallback)")
         self.device = device
         self._bases_cache = {}
-        self._pool, self._pool_bytes = {}, 0
+        self._pool, self._pool_bytes, self._pool_lock = {}, 0, threading.Lock()
         self.pool_limit_bytes = int(os.environ.get("ZK_POOL_LIMIT_GIB", "24")) << 30   # freed device buffers kept for reuse (per context)
 
     # -- plumbing -------------------------------------------------------------------------------
@@ -135,10 +138,11 @@ class Backend:
         return self.lib.zk_version().decode()
 
     def trim_pool(self):
-        for ptrs in self._pool.values():
+        with self._pool_lock:
+            pool, self._pool, self._pool_bytes = self._pool, {}, 0
+        for ptrs in pool.values():
             for p in ptrs:
                 self.lib.zk_dev_free(self.ctx, C.c_void_p(p))
-        self._pool, self._pool_bytes = {}, 0
 
     def close(self):
         if self.ctx:

@@ -75,10 +75,43 @@ def g1_affine_ints(jac12) -> tuple | None:
     return fq_int(j[0:4]), fq_int(j[4:8])
 
 
-def rand_fr_array(rng: np.random.Generator, n: int) -> np.ndarray:
-    """n field elements as raw limb patterns below 2^253 (< r), used directly as Montgomery forms.  This is the
-    mirror's stand-in for `Fr::random(&mut rng)` draws (blinding rows / the vanishing argument's random polynomial):
-    deterministic under the caller's seeded generator, which is what makes proof bytes reproducible."""
-    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
-    a[:, 3] &= np.uint64((1 << 61) - 1)
-    return a
+_R_L = [np.uint64((R_MOD >> (64 * i)) & _MASK) for i in range(4)]
+
+
+def _below_r(a: np.ndarray) -> np.ndarray:
+    """row-wise (n, 4) little-endian limbs < r"""
+    top = a[:, 3]
+    lt = top < _R_L[3]
+    eq = np.nonzero(top == _R_L[3])[0]                 # 2^-62 of the draws: decided by the lower limbs
+    for j in eq:
+        lt[j] = unlimbs(a[j]) < R_MOD
+    return lt
+
+
+class OsRng:
+    """`OsRng` of the reference's call (sgx_dcap_verifier.rs:811): raw limbs from the operating system's CSPRNG.  What a production caller
+    passes as `rng`; tests and benches pass a seeded numpy Generator so that proof bytes are reproducible."""
+
+    def integers(self, low, high, size, dtype=np.uint64):
+        assert low == 0 and high == 1 << 64 and dtype == np.uint64
+        import os
+        m = int(np.prod(size))
+        return np.frombuffer(os.urandom(8 * m), dtype=np.uint64).reshape(size).copy()
+
+
+def rand_fr_array(rng, n: int) -> np.ndarray:
+    """n field elements UNIFORM in [0, r) by rejection (254-bit draws, accepted when below r: 75.6 % pass), as raw limbs.  A raw limb
+    pattern v < r is the Montgomery form of v/R, and v -> v/R is a bijection of [0, r), so the elements are uniform whichever way the limbs
+    are read.  This is the mirror's `Fr::random(&mut rng)` (blinding rows, the vanishing argument's random polynomial): `rng` is a numpy
+    Generator (seeded: deterministic proofs for tests) or `OsRng()` (production).  The number of raw draws depends on n only through the
+    accepted count, so a seeded stream stays reproducible."""
+    out = np.empty((n, 4), dtype=np.uint64)
+    filled = 0
+    while filled < n:
+        m = (n - filled) * 3 // 2 + 32
+        a = rng.integers(0, 1 << 64, size=(m, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 62) - 1)
+        a = a[_below_r(a)][: n - filled]
+        out[filled:filled + len(a)] = a
+        filled += len(a)
+    return out

@@ -42,29 +42,32 @@ class ConstraintSystem:
     minimum_degree: int = 1
 
     # -- construction (ConstraintSystem::{create_gate, lookup, enable_equality}) -------------------------------------
+    # halo2 records a column query the moment `meta.query_*` runs, i.e. in CALL order across create_gate / lookup / enable_equality
+    # (enable_equality queries the column at Rotation::cur() itself): the query log below is kept the same way, so the order of the advice /
+    # fixed evaluations in the proof follows the order of the configure() calls, as in the reference.
+    _query_log: Dict[Tuple[str, int, int], None] = field(default_factory=dict, repr=False, compare=False)
+
     def create_gate(self, *polys: ex.Expression) -> None:
         self.gates.extend(polys)
+        for g in polys:
+            ex.queries(g, self._query_log)
 
     def lookup(self, pairs: Sequence[Tuple[ex.Expression, ex.Expression]]) -> int:
         self.lookups.append(LookupArgument([p[0] for p in pairs], [p[1] for p in pairs]))
+        for inp, tab in pairs:
+            ex.queries(inp, self._query_log)
+            ex.queries(tab, self._query_log)
         return len(self.lookups) - 1
 
     def enable_equality(self, column_type: int, index: int) -> None:
+        # permutation::Argument::add_column + query_any_index(column, Rotation::cur())
+        self._query_log.setdefault(({ADVICE: "advice", FIXED: "fixed", INSTANCE: "instance"}[column_type], index, 0), None)
         if (column_type, index) not in self.permutation_columns:
             self.permutation_columns.append((column_type, index))
 
     # -- derived quantities -------------------------------------------------------------------------------------------
     def _queries(self) -> Dict[Tuple[str, int, int], None]:
-        q: Dict[Tuple[str, int, int], None] = {}
-        for g in self.gates:
-            ex.queries(g, q)
-        for lk in self.lookups:
-            for e in lk.input_expressions + lk.table_expressions:
-                ex.queries(e, q)
-        # permutation::Argument::add_column queries every equality-enabled column at Rotation::cur()
-        for t, i in self.permutation_columns:
-            q.setdefault(({ADVICE: "advice", FIXED: "fixed", INSTANCE: "instance"}[t], i, 0), None)
-        return q
+        return self._query_log
 
     def advice_queries(self) -> List[Tuple[int, int]]:
         return [(c, r) for (k, c, r) in self._queries() if k == "advice"]
@@ -76,7 +79,7 @@ class ConstraintSystem:
         return [(c, r) for (k, c, r) in self._queries() if k == "instance"]
 
     def degree(self) -> int:
-        d = 3 if self.permutation_columns else 1                       # permutation::Argument::required_degree
+        d = 3                                                           # permutation::Argument::required_degree(): 3 whether or not a column is equality-enabled
         for lk in self.lookups:
             d = max(d, lk.required_degree())
         for g in self.gates:
@@ -140,7 +143,9 @@ class Assembly:
         import numpy as np
         lc, rc = self.columns.index(left), self.columns.index(right)
         rows = np.asarray(rows, dtype=np.int64)
-        if lc == rc or (self.sizes[lc, rows] != 1).any() or (self.sizes[rc, rows] != 1).any() or np.unique(rows).size != rows.size:
+        def singleton(c):        # `sizes` is kept for cycle representatives only: a merged non-representative cell still reads 1 there
+            return (self.aux_c[c, rows] == c) & (self.aux_r[c, rows] == rows) & (self.sizes[c, rows] == 1)
+        if lc == rc or not singleton(lc).all() or not singleton(rc).all() or np.unique(rows).size != rows.size:
             for r in rows.tolist():
                 self.copy((left[0], left[1], r), (right[0], right[1], r))
             return

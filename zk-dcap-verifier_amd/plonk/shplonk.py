@@ -107,7 +107,8 @@ class ProverSHPLONK:
         rotation_sets, super_points = construct_intermediate_sets(queries)
         v = transcript.squeeze_challenge()
 
-        zero_tail = np.zeros((8, 4), dtype=np.uint64)
+        pad = max(len(pts) for pts, _ in rotation_sets)              # largest rotation set: coefficients of the low-degree corrections / truncated tail
+        zero_tail = np.zeros((pad, 4), dtype=np.uint64)
         rbuf = be.to_device(np.zeros((n, 4), dtype=np.uint64))        # carries the low-degree corrections (zero beyond a few coefficients)
         one = fr_mont(1)
         quotients, tmp = [], [be.alloc(n * 32), be.alloc(n * 32)]
@@ -126,7 +127,7 @@ class ProverSHPLONK:
                 scal.append(ypow)
                 ypow = ypow * y % R_MOD
             low_degree.append(rs)
-            rbuf.upload(fr_mont_array(rsum + [0] * (8 - len(rsum))))
+            rbuf.upload(fr_mont_array(rsum + [0] * (pad - len(rsum))))
             be.fr_lincomb_dev(polys + [rbuf], fr_mont_array(scal + [1]), n, tmp[0])
             cur, ln = 0, n
             for p in pts:                                             # div_by_vanishing: one synthetic division per point
@@ -163,7 +164,7 @@ class ProverSHPLONK:
         z0_inv = pow(z_diffs[0], -1, R_MOD)
         polys.append(h_x)
         scal.append((-zt) % R_MOD)
-        rbuf.upload(fr_mont_array([const * z0_inv % R_MOD] + [0] * 7))
+        rbuf.upload(fr_mont_array([const * z0_inv % R_MOD] + [0] * (pad - 1)))
         be.fr_lincomb_dev(polys + [rbuf], fr_mont_array([s * z0_inv % R_MOD for s in scal] + [1]), n, tmp[0])
         be.kate_division_dev(tmp[0], n, fr_mont(u), tmp[1])
         tmp[1].upload(zero_tail[:1], offset=(n - 1) * 32)

@@ -65,6 +65,13 @@ int zk_dev_upload(zk_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int zk_dev_download(zk_ctx* ctx, void* host, const void* dptr, size_t bytes);
 int zk_dev_copy(zk_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);   /* device -> device */
 int zk_dev_sync(zk_ctx* ctx);
+/* The witness crosses the boundary once per proof (create_proof receives host-owned circuits: sgx_dcap_verifier.rs:814-822, `&[circuit]`; halo2's prover
+ * holds the synthesised advice columns as host Vec<Fr>).  zk_host_alloc hands out page-locked host memory the shim can synthesise / batch-invert the
+ * columns into, so that the upload runs at link rate without a bounce buffer; zk_dev_upload_batch ships `count` columns of bytes_each in one call
+ * (hosts / dptrs: HOST arrays of pointers; ordinary pageable memory works too, slower). */
+int zk_host_alloc(zk_ctx* ctx, size_t bytes, void** hptr);
+int zk_host_free(zk_ctx* ctx, void* hptr);
+int zk_dev_upload_batch(zk_ctx* ctx, void* const* dptrs_dev, const void* const* hosts, size_t count, size_t bytes_each);
 
 /* ---- MSM: replaces arithmetic::best_multiexp / ParamsKZG::{commit, commit_lagrange} -------- *
  * halo2_proofs src/arithmetic.rs best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1 and

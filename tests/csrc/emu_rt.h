@@ -85,6 +85,8 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return 0; }
 static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return 0; }
 static inline hipError_t hipHostUnregister(void*) { return 0; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return posix_memalign(p, 4096, n ? n : 4096) ? 2 : 0; }
+static inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 
 // ---- launcher ------------------------------------------------------------------------------
 static void emu_fiber_main() {

@@ -61,6 +61,11 @@ def test_bench_prove_mode_emits_verified_proof(built, capsys, monkeypatch):
     assert line["config"]["mode"] == "prove" and line["unit"] == "proofs/hour"
     assert line["cpu_baseline"]["verify_proof"]["accepted"] is True
     assert line["roofline"]["kernel"] == "msm_accumulate_kernel"
+    # the PCIe-inclusive regions (witness starting in host memory) and the thin-shim replay (per-call host-buffer entry points + CPU port of a13-a16)
+    assert set(line["extra"]["host_witness"]) >= {"pinned", "pageable", "bytes_per_proof"}
+    ts = line["extra"]["thin_shim"]
+    assert ts["calls"] == {"zk_msm": line["extra"]["ops_per_proof"]["msm"], "zk_ntt": line["extra"]["ops_per_proof"]["intt_2^k"], "zk_evaluate_h": 1}
+    assert ts["proofs_per_hour"] > 0 and line["cpu_baseline"]["a13_a16_cpu_port"]["total_ms"] > 0
 
 
 def _bench_rank(rank, world, port, out_dir):

@@ -127,6 +127,7 @@ class Backend:
         self.device = device
         self._bases_cache = {}
         self._pool, self._pool_bytes, self._pool_lock = {}, 0, threading.Lock()
+        self._pinned = {}
         self.pool_limit_bytes = int(os.environ.get("ZK_POOL_LIMIT_GIB", "24")) << 30   # freed device buffers kept for reuse (per context)
 
     # -- plumbing -------------------------------------------------------------------------------
@@ -147,6 +148,9 @@ class Backend:
     def close(self):
         if self.ctx:
             self.trim_pool()
+            for p in list(self._pinned.values()):
+                self.lib.zk_host_free(self.ctx, C.c_void_p(p))
+            self._pinned = {}
             self.lib.zk_ctx_destroy(self.ctx)
             self.ctx = C.c_void_p()
 
@@ -181,6 +185,29 @@ class Backend:
 
     def sync(self):
         self._ck(self.lib.zk_dev_sync(self.ctx))
+
+    def host_alloc(self, shape, dtype=np.uint64) -> np.ndarray:
+        """page-locked host array (zk_host_alloc) — staging memory for columns that cross PCIe every proof; released by host_free / close()"""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._ck(self.lib.zk_host_alloc(self.ctx, C.c_size_t(nbytes), C.byref(p)))
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = self._pinned.pop(arr.ctypes.data, None)
+        if p is not None and self.ctx:
+            self._ck(self.lib.zk_host_free(self.ctx, C.c_void_p(p)))
+
+    def upload_columns(self, dev_cols, host_cols, nbytes_each: int):
+        """host_cols[i] (contiguous arrays of nbytes_each) -> dev_cols[i], one call"""
+        assert len(dev_cols) == len(host_cols)
+        hosts = [np.ascontiguousarray(h) for h in host_cols]
+        assert all(h.nbytes >= nbytes_each for h in hosts)
+        harr = (C.c_void_p * max(1, len(hosts)))(*[h.ctypes.data for h in hosts])
+        self._ck(self.lib.zk_dev_upload_batch(self.ctx, self._ptr_array(dev_cols), harr, C.c_size_t(len(hosts)), C.c_size_t(nbytes_each)))
 
     # -- MSM ------------------------------------------------------------------------------------
     def bases_register(self, bases) -> int:

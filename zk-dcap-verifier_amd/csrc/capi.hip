@@ -155,6 +155,20 @@ int zk_dev_copy(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
     ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream)); ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
 }
 int zk_dev_sync(zk_ctx* ctx) { ENTER; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
+// page-locked staging memory for the columns the caller hands over every proof (the witness): DMA reads it at link rate, no bounce buffer
+int zk_host_alloc(zk_ctx* ctx, size_t bytes, void** hptr) {
+    ENTER; if (!hptr) return ctx->fail(ZK_ERR_ARG, "zk_host_alloc: null");
+    ZK_HIP(hipHostMalloc(hptr, bytes ? bytes : 32, 0)); return ZK_OK;
+}
+int zk_host_free(zk_ctx* ctx, void* hptr) { ENTER; ZK_HIP(hipHostFree(hptr)); return ZK_OK; }
+int zk_dev_upload_batch(zk_ctx* ctx, void* const* dptrs, const void* const* hosts, size_t count, size_t bytes_each) {
+    ENTER; if ((!dptrs || !hosts) && count) return ctx->fail(ZK_ERR_ARG, "zk_dev_upload_batch: null");
+    for (size_t i = 0; i < count; i++) {
+        if (!dptrs[i] || !hosts[i]) return ctx->fail(ZK_ERR_ARG, "zk_dev_upload_batch: null column %zu", i);
+        ZK_HIP(hipMemcpyAsync(dptrs[i], hosts[i], bytes_each, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
+}
 
 // ---- MSM ----------------------------------------------------------------------------------------
 int zk_bases_register(zk_ctx* ctx, const void* p, size_t n, uint64_t* h) { ENTER; return msm_register(ctx, p, n, false, h); }

@@ -40,21 +40,22 @@ def rotate_omega(x: int, rot: int, k: int) -> int:
 
 
 def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances: Sequence[Sequence[int]], rng: np.random.Generator, transcript,
-                 timings: Optional[dict] = None) -> dict:
+                 timings: Optional[dict] = None, capture: Optional[dict] = None) -> dict:
     """advice: cs.num_advice_columns columns of n rows — (n, 4) uint64 Montgomery host arrays or device buffers; rows past
     `usable_rows` are overwritten with blinding and device buffers are consumed (they hold coefficients afterwards).  instances:
     canonical ints per instance column.  Writes the proof into `transcript` and returns bookkeeping for tests / benches
     ({"commitments", "evals", "h_eval"}); `timings`, when given, receives wall milliseconds per phase.  Device buffers allocated
-    along the way are released (back to the backend's pool) on success and on failure alike."""
+    along the way are released (back to the backend's pool) on success and on failure alike.  `capture` (measurement tooling only): receives host
+    copies of the proof's committed Lagrange columns and challenges, so that a driver of the per-call host-buffer entry points can replay them."""
     owned: List = []
     try:
-        return _create_proof(params, pk, advice, instances, rng, transcript, timings, owned)
+        return _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture)
     finally:
         for d in owned:
             d.free()
 
 
-def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned) -> dict:
+def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture=None) -> dict:
     be, cs, k, n = pk.backend, pk.vk.cs, params.k, params.n
     dom = pk.domain
     ek, en = dom.extended_k, dom.extended_n
@@ -94,16 +95,15 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
 
     lap("1_instances")
     # ---- 2. advice: blind the unusable rows, commit ----------------------------------------------------------------------
-    adv_values = []
-    for col in advice:
-        blind = rand_fr_array(rng, n - usable)
-        if isinstance(col, np.ndarray):
-            d = dev(n * 32)
-            d.upload(np.ascontiguousarray(col, dtype=np.uint64).reshape(n, 4))
-        else:
-            d = col
-        d.upload(blind, offset=usable * 32)
-        adv_values.append(d)
+    # host columns (what halo2's prover holds after synthesis: Vec<Fr> per column) cross PCIe here, all in one call; page-locked arrays
+    # (Backend.host_alloc) travel at link rate.  Device buffers are taken as they are.
+    adv_values = [dev(n * 32) if isinstance(col, np.ndarray) else col for col in advice]
+    from_host = [i for i, col in enumerate(advice) if isinstance(col, np.ndarray)]
+    if from_host:
+        be.upload_columns([adv_values[i] for i in from_host], [np.ascontiguousarray(advice[i], dtype=np.uint64).reshape(n, 4) for i in from_host], n * 32)
+    blinds = [rand_fr_array(rng, n - usable) for _ in advice]
+    if advice:
+        be.upload_columns([d.ptr + usable * 32 for d in adv_values], blinds, (n - usable) * 32)
     for pt in commit_all("g_lagrange", adv_values):
         transcript.write_point(pt)
 
@@ -175,6 +175,11 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     # ---- 6. y; everything to coefficient form; h(X) ------------------------------------------------------------------------------
     y = transcript.squeeze_challenge()
     lag = adv_values + inst_values + zs + lzs + flat                 # the witness-dependent columns, Lagrange basis
+    if capture is not None:
+        capture.update(advice=[d.download((n, 4)) for d in adv_values], perm_products=[d.download((n, 4)) for d in zs],
+                       lookup_products=[d.download((n, 4)) for d in lzs], permuted=[(a_.download((n, 4)), s_.download((n, 4))) for a_, s_ in permuted],
+                       compressed=[(c[0].download((n, 4)), c[1].download((n, 4))) for c in compressed], random_poly=drawn["random_poly"],
+                       theta=theta, beta=beta, gamma=gamma, y=y)
     be.lagrange_to_coeff_batch_dev(lag, k)                           # in place: from here on these buffers hold coefficients
     adv_polys, inst_polys = adv_values, inst_values
     nA, nI, nZ = len(adv_polys), len(inst_polys), len(zs)

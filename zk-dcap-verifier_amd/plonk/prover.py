@@ -39,6 +39,16 @@ def rotate_omega(x: int, rot: int, k: int) -> int:
     return x * pow(w, rot % (1 << k), R_MOD) % R_MOD
 
 
+class _Joiner:
+    """lets the helper thread sit in the `owned` list: create_proof's cleanup calls .free() on every entry"""
+
+    def __init__(self, thread):
+        self.thread = thread
+
+    def free(self):
+        self.thread.join()
+
+
 def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances: Sequence[Sequence[int]], rng: np.random.Generator, transcript,
                  timings: Optional[dict] = None, capture: Optional[dict] = None) -> dict:
     """advice: cs.num_advice_columns columns of n rows — (n, 4) uint64 Montgomery host arrays or device buffers; rows past
@@ -104,6 +114,36 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     blinds = [rand_fr_array(rng, n - usable) for _ in advice]
     if advice:
         be.upload_columns([d.ptr + usable * 32 for d in adv_values], blinds, (n - usable) * 32)
+    # Every later `Fr::random` draw of the proof (lookup / permutation blinding rows, the n coefficients of the vanishing argument's random
+    # polynomial) depends on no challenge: a helper thread draws them now, in the order the phases consume them (the stream — hence the proof —
+    # is the same), while the GPU commits the advice columns; a phase waits only for its own item.
+    chunk = cs.permutation_chunk_len()
+    n_sets = (len(cs.permutation_columns) + chunk - 1) // chunk if cs.permutation_columns else 0
+    drawn, ready = {}, {name: threading.Event() for name in ("bi", "bt", "perm_blind", "lookup_blind", "random_poly")}
+    draw_error = []
+
+    def draw_all():
+        try:
+            for name, fn in (("bi", lambda: np.stack([rand_fr_array(rng, bf + 1) for _ in range(L)]) if L else np.zeros((0, bf + 1, 4), np.uint64)),
+                             ("bt", lambda: np.stack([rand_fr_array(rng, bf + 1) for _ in range(L)]) if L else np.zeros((0, bf + 1, 4), np.uint64)),
+                             ("perm_blind", lambda: [rand_fr_array(rng, bf) for _ in range(n_sets)]),
+                             ("lookup_blind", lambda: np.stack([rand_fr_array(rng, bf) for _ in range(L)]) if L else np.zeros((0, bf, 4), np.uint64)),
+                             ("random_poly", lambda: rand_fr_array(rng, n))):
+                drawn[name] = fn()
+                ready[name].set()
+        except BaseException as e:                                   # never leave the main thread waiting
+            draw_error.append(e)
+            for ev_ in ready.values():
+                ev_.set()
+
+    def take_draw(name):
+        ready[name].wait()
+        if draw_error:
+            raise draw_error[0]
+        return drawn[name]
+    drawer = threading.Thread(target=draw_all)
+    drawer.start()
+    owned.append(_Joiner(drawer))                                    # joined on every exit path (the generator belongs to the caller again afterwards)
     for pt in commit_all("g_lagrange", adv_values):
         transcript.write_point(pt)
 
@@ -128,8 +168,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
             table_cache[key] = run_compressor(ctab_ev)
         compressed.append([run_compressor(cin_ev), table_cache[key]])
     # permute_expression_pair of every lookup in one device call (raises ZkError when an input is not in the table)
-    bi = np.stack([rand_fr_array(rng, bf + 1) for _ in compressed]) if compressed else np.zeros((0, bf + 1, 4), np.uint64)
-    bt = np.stack([rand_fr_array(rng, bf + 1) for _ in compressed]) if compressed else np.zeros((0, bf + 1, 4), np.uint64)
+    bi, bt = take_draw("bi"), take_draw("bt")
     permuted = permute_expression_pairs([c[0] for c in compressed], [c[1] for c in compressed], k, bf, bi, bt, backend=be)
     for a_, s_ in permuted:
         owned += [a_, s_]
@@ -145,30 +184,18 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     perm_values = []
     for t, i in cs.permutation_columns:
         perm_values.append({ADVICE: adv_values, FIXED: pk.fixed_values, INSTANCE: inst_values}[t][i])
-    chunk = cs.permutation_chunk_len()
-    n_sets = (len(perm_values) + chunk - 1) // chunk if perm_values else 0
-    # every random draw of phases 4 and 5 up front, in the order the phases consume them: the two blinding sets, then — on a helper thread,
-    # while the GPU builds the grand products — the n coefficients of the vanishing argument's random polynomial (3-4 ms of host RNG that
-    # otherwise sits between two commitment phases with the GPU idle)
-    perm_blind = [rand_fr_array(rng, bf) for _ in range(n_sets)]
-    lookup_blind = np.stack([rand_fr_array(rng, bf) for _ in compressed]) if compressed else np.zeros((0, bf, 4), np.uint64)
-    drawn = {}
-    drawer = threading.Thread(target=lambda: drawn.__setitem__("random_poly", rand_fr_array(rng, n)))
-    drawer.start()
-    try:
-        zs = permutation_commit(perm_values, pk.sigma_values, k, cs.degree(), bt_m, gm_m, perm_blind, backend=be) if perm_values else []
-        owned += zs
-        lzs = lookup_commit_products([(c[0], c[1], p_[0], p_[1]) for c, p_ in zip(compressed, permuted)], k, bt_m, gm_m, lookup_blind, backend=be)
-        owned += lzs
-    finally:
-        drawer.join()                                               # (the generator is used by nobody else until here)
+    perm_blind, lookup_blind = take_draw("perm_blind"), take_draw("lookup_blind")
+    zs = permutation_commit(perm_values, pk.sigma_values, k, cs.degree(), bt_m, gm_m, perm_blind, backend=be) if perm_values else []
+    owned += zs
+    lzs = lookup_commit_products([(c[0], c[1], p_[0], p_[1]) for c, p_ in zip(compressed, permuted)], k, bt_m, gm_m, lookup_blind, backend=be)
+    owned += lzs
     for pt in commit_all("g_lagrange", zs + lzs):      # permutation products, then lookup products: one MSM batch, transcript order kept
         transcript.write_point(pt)
 
     lap("4_grand_products")
     # ---- 5. vanishing argument: random polynomial -----------------------------------------------------------------------------
     random_poly = dev(n * 32)
-    random_poly.upload(drawn["random_poly"])
+    random_poly.upload(take_draw("random_poly"))
     transcript.write_point(commit_all("g", [random_poly])[0])
 
     lap("5_random_poly")

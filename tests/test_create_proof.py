@@ -16,13 +16,14 @@ from zk_dcap_verifier_amd.fields import R_MOD, fr_mont_array
 from zk_dcap_verifier_amd.transcript import Blake2bWrite
 
 TAU = 0x1C59A59B6CFF4308740943526ADE1D8C09F71B337A67269CC89586BCDD6DFCBA % R_MOD   # SURVEY App. C.7 (any value works)
-GOLDEN_PROOF = "toy_proof_k6_seed7.bin"      # tools/gen_golden_proof.py (emulator run of this very prover; see tests/golden/README.md)
+GOLDEN_PROOF = "toy_proof_k6_seed7.bin"      # tools/gen_golden_proof.py: bytes of the INDEPENDENT CPU prover (oracle/prover.py); see tests/golden/README.md
+GOLDEN_SGX = "sgx_shaped_k8_seed3.bin"       # the same for the sgx_dcap_verifier-shaped circuit at k = 8, rng seed 3
 
 
-def _golden():
+def _golden(name=GOLDEN_PROOF):
     import os
     from conftest import ROOT
-    return open(os.path.join(ROOT, "tests", "golden", GOLDEN_PROOF), "rb").read()
+    return open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
 
 
 
@@ -50,6 +51,7 @@ def toy_circuit(k, with_lookup=True, tamper=None):
     T = [i if i < 16 else 0 for i in range(n)]
     inst = [C[0], C[3]]
     asm = plonk.Assembly(cs, k)
+    asm.copies = []                                                   # logged for the independent CPU prover (oracle/prover.py)
     for i in range(0, u - 1, 2):
         asm.copy((ADVICE, 1, i), (ADVICE, 1, i + 1))
     asm.copy((ADVICE, 2, 0), (INSTANCE, 0, 0))
@@ -187,6 +189,8 @@ def _sgx_shaped(be, k, by_cosets=False):
         assert tr2.finalize() == proof
         pk2.release()
     assert info["commitments"] == 71 and len(proof) == 32 * (71 + info["evals"])
+    if k == 8:                          # same SRS / witness / RNG stream as the independent CPU prover's golden: the bytes must be identical
+        assert proof == _golden(GOLDEN_SGX)
     assert verifier.verify_proof(pk.vk, TAU, [], proof) is True
     bad = bytearray(proof)
     bad[32 * 69 + 5] ^= 4
@@ -211,6 +215,24 @@ def test_sgx_shaped_circuit_proof_verifies_gpu(gpu, orc, k):
     _sgx_shaped(gpu, k)
 
 
+def test_cpu_prover_reproduces_the_committed_goldens(orc):
+    """tests/golden/{toy_proof_k6_seed7, sgx_shaped_k8_seed3}.bin are what oracle/prover.py (independent CPU prover: Python integers, quotient from
+    its definition) emits — regenerate them here and compare, so the goldens cannot drift from their generator; verify_proof accepts both."""
+    import os, sys
+    import verifier
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_golden_proof as gg
+    for name, (t_, cs, instances, (keys, proof)) in ((GOLDEN_PROOF, gg.toy()), (GOLDEN_SGX, gg.sgx_shaped())):
+        assert proof == _golden(name), name
+        assert verifier.verify_proof(keys, TAU, instances, proof) is True
+
+
+def test_sgx_shaped_golden_is_reproduced_by_the_emulated_kernels(emu, orc):
+    """the sgx-shaped circuit at k = 8 through the product prover on the emulated kernels: byte-identical to the CPU prover's proof"""
+    _sgx_shaped(emu, 8)
+
+
 def test_golden_proof_is_accepted_and_reproduced_on_the_emulator(emu, orc):
     import verifier
     vk, instances, proof, _ = prove(emu, 6, seed=7)
@@ -220,8 +242,9 @@ def test_golden_proof_is_accepted_and_reproduced_on_the_emulator(emu, orc):
 
 @pytest.mark.gpu
 def test_gpu_emits_the_golden_proof_bytes(gpu, orc):
-    """Same SRS, same witness, same seeded RNG, same transcript => the GPU kernels must emit byte-for-byte the proof the CPU-emulated
-    kernels emitted (every MSM / NTT / quotient / sort result is a canonical value): the north star's bit-exactness claim, end to end."""
+    """Same SRS, same witness, same seeded RNG, same transcript => the GPU kernels must emit byte-for-byte the proof the independent CPU prover
+    (oracle/prover.py) emitted (every MSM / NTT / quotient / sort result is a canonical value): the north star's bit-exactness claim, end to end.
+    The sgx-shaped golden is compared in test_sgx_shaped_circuit_proof_verifies_gpu[8]."""
     assert prove(gpu, 6, seed=7)[2] == _golden()
 
 

@@ -1,30 +1,76 @@
 #!/usr/bin/env python3
-"""Regenerate tests/golden/toy_proof_k6_seed7.bin: the proof bytes of tests/test_create_proof.py's toy circuit at k = 6 under
-np.random.default_rng(7) and the SRS trapdoor TAU of that test, produced by plonk.create_proof on the kernel EMULATOR (the product's
-kernel sources run on CPU threads, tests/csrc/emu_rt.h).  It is a regression + CPU/GPU bit-exactness pin of OUR prover (the GPU must
-emit these exact bytes, and the pure-Python verifier must accept them) — not an output of the reference, which holds no proof for
-stack A and cannot be built here."""
+"""Regenerate the golden proofs under tests/golden/ with the INDEPENDENT CPU prover (oracle/prover.py: Python integers, quotient from its
+definition, MSMs on the C oracle — no product code, no kernel emulator):
+    toy_proof_k6_seed7.bin     the toy circuit of tests/test_create_proof.py, k = 6, np.random.default_rng(7)
+    sgx_shaped_k8_seed3.bin    the sgx_dcap_verifier-shaped circuit (tools/sgx_shaped_circuit.py: 25 advice, 11 lookups, 16 equality columns), k = 8, rng 3
+Both with the SRS trapdoor TAU of the tests.  The GPU prover (and the emulated kernels) must emit exactly these bytes, and the pure-Python
+verifier must accept them.  They are NOT outputs of the reference (no Rust toolchain here; the reference holds no stack-A proof): they replace the
+round-1 goldens, which the emulator build of the product's own kernels had produced."""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
-    sys.path.insert(0, p)
-import zk_dcap_verifier_amd as z  # noqa: E402
-import test_create_proof as t  # noqa: E402
-from conftest import EMU_SO  # noqa: E402
+for p_ in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
+    sys.path.insert(0, p_)
+import numpy as np  # noqa: E402
+
+
+def oracle_proof(k, tau, cs, fixed, copies, advice, instances, seed):
+    """circuit description + witness (Montgomery arrays or int lists) -> (keys, proof bytes) from the CPU prover"""
+    import oracle as orc
+    import prover as op
+    ints = lambda col: orc.fr_to_ints(col) if isinstance(col, np.ndarray) else [int(v) for v in col]
+    params = op.Params(k, tau)
+    keys = op.keygen(params, cs, [ints(c) for c in fixed], copies)
+    return keys, op.create_proof(params, keys, [ints(c) for c in advice], instances, np.random.default_rng(seed))
+
+
+def toy(k=6, seed=7):
+    import test_create_proof as t
+    cs, fixed, asm, advice, instances = t.toy_circuit(k)
+    return t, cs, instances, oracle_proof(k, t.TAU, cs, fixed, asm.copies, advice, instances, seed)
+
+
+def sgx_shaped(k=8, seed=3):
+    import test_create_proof as t
+    import sgx_shaped_circuit as sc
+    import zk_dcap_verifier_amd as z
+
+    class FieldCalc:                      # build() uses its backend argument as a field calculator for d = a + b*c only: do that on the oracle here
+        def __init__(self):
+            import oracle as orc
+            self.orc = orc
+
+        class _Buf:
+            def __init__(self, a):
+                self.a = np.array(a, dtype=np.uint64)
+
+            def download(self, shape):
+                return self.a.reshape(shape)
+
+            def free(self):
+                pass
+
+        def to_device(self, a):
+            return FieldCalc._Buf(a)
+
+        def fr_mul_dev(self, a, b, out, n):
+            out.a = self.orc.fr_mul(a.a[:n], b.a[:n])
+
+        def fr_add_dev(self, a, b, out, n):
+            out.a = self.orc.fr_add(a.a[:n], b.a[:n])
+    cs, fixed, asm, advice = sc.build(z, FieldCalc(), k)
+    return t, cs, [], oracle_proof(k, t.TAU, cs, fixed, asm.copies, advice, [], seed)
 
 
 def main():
-    be = z.Backend(0, lib_path=EMU_SO)
-    be.tune(msm_sort_threads=64, msm_sort_wgs=3, msm_block=32, ntt_threads=32, ntt_tile_log=6, ntt_max_radix_log=4,
-            msm_target_threads=64, msm_min_chunk=2, vec_block=32, quot_threads=32)
-    vk, instances, proof, info = t.prove(be, 6, seed=7)
     import verifier
-    assert verifier.verify_proof(vk, t.TAU, instances, proof) is True
-    out = os.path.join(ROOT, "tests", "golden", "toy_proof_k6_seed7.bin")
-    open(out, "wb").write(proof)
-    print("wrote", out, len(proof), "bytes;", info["commitments"], "commitments,", info["evals"], "evaluations")
+    for name, (t, cs, instances, (keys, proof)) in (("toy_proof_k6_seed7.bin", toy()), ("sgx_shaped_k8_seed3.bin", sgx_shaped())):
+        keys.cs, keys.k = cs, keys.k
+        assert verifier.verify_proof(keys, t.TAU, instances, proof) is True, name
+        out = os.path.join(ROOT, "tests", "golden", name)
+        open(out, "wb").write(proof)
+        print("wrote", out, len(proof), "bytes (CPU prover, accepted by verify_proof)")
 
 
 if __name__ == "__main__":

@@ -90,6 +90,8 @@ def build(z, be, k: int, seed: int = 20241008, table_bits: int = TABLE_BITS):
 
     # ---- copy constraints ------------------------------------------------------------------------------------------------------
     asm = plonk.Assembly(cs, k)
+    if k <= 10:
+        asm.copies = []                                               # small sizes: keep the copy list (the independent CPU prover of oracle/ replays it)
     brow = np.arange(nblk, dtype=np.int64) * 4 + 1
     for c in range(0, N_GATE_COLS, 2):
         asm.copy_rows((plonk.ADVICE, c), (plonk.ADVICE, c + 1), brow)

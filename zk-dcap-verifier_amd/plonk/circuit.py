@@ -113,9 +113,12 @@ class Assembly:
         self.map_r = np.repeat(rows[None, :], m, axis=0)
         self.aux_c, self.aux_r = self.map_c.copy(), self.map_r.copy()
         self.sizes = np.ones((m, self.n), dtype=np.int32)
+        self.copies = None          # set to [] to have every copy constraint logged as ((type, index, row), (type, index, row)) — small circuits only
 
     def copy(self, left: Tuple[int, int, int], right: Tuple[int, int, int]) -> None:
         """left/right = (column_type, index, row).  Mirrors Assembly::copy (cycle merge by swapping successors)."""
+        if self.copies is not None:
+            self.copies.append((tuple(int(v) for v in left), tuple(int(v) for v in right)))
         lc = self.columns.index((left[0], left[1]))
         rc = self.columns.index((right[0], right[1]))
         lr, rr = left[2], right[2]
@@ -145,7 +148,7 @@ class Assembly:
         rows = np.asarray(rows, dtype=np.int64)
         def singleton(c):        # `sizes` is kept for cycle representatives only: a merged non-representative cell still reads 1 there
             return (self.aux_c[c, rows] == c) & (self.aux_r[c, rows] == rows) & (self.sizes[c, rows] == 1)
-        if lc == rc or not singleton(lc).all() or not singleton(rc).all() or np.unique(rows).size != rows.size:
+        if self.copies is not None or lc == rc or not singleton(lc).all() or not singleton(rc).all() or np.unique(rows).size != rows.size:
             for r in rows.tolist():
                 self.copy((left[0], left[1], r), (right[0], right[1], r))
             return

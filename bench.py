@@ -189,8 +189,8 @@ class ProverWorkload:
     def __init__(self, z, be, k, circuit, srs=None):
         self.z, self.be, self.k, self.n = z, be, k, 1 << k
         cs, fixed, asm, advice = circuit
-        # one SRS for the process: the first context runs ParamsKZG::setup (fixed-base powers + EC-NTT), the others register the same points
-        self.params = z.kzg.ParamsKZG.setup(k, TAU, backend=be) if srs is None else z.kzg.ParamsKZG(k, srs.g_host, srs.g_lagrange_host, backend=be)
+        # one SRS for the process: the first context runs ParamsKZG::setup (fixed-base powers + EC-NTT); the others share its expanded tables in HBM
+        self.params = z.kzg.ParamsKZG.setup(k, TAU, backend=be) if srs is None else z.kzg.ParamsKZG.shared_with(srs, be)
         self.pk = z.plonk.keygen(self.params, cs, fixed, asm)
         self.master = [be.to_device(a) for a in advice]
         self.work = [be.alloc(self.n * 32) for _ in advice]
@@ -530,6 +530,8 @@ def main(argv=None):
     ap.add_argument("--perm-columns", type=int, default=16)
     ap.add_argument("--degree", type=int, default=5)
     ap.add_argument("--mode", choices=("prove", "opmix"), default="prove", help="prove: real create_proof over the sgx-shaped circuit (default); opmix: the hot-path call list over synthetic columns")
+    ap.add_argument("--census", choices=("chip_estimate", "reference_exact"), default="chip_estimate",
+                    help="which synthetic circuit `value` is measured on (tools/sgx_shaped_circuit.py); the other one is measured as extra.census_* unless --no-extras")
     ap.add_argument("--inflight", type=int, default=3, help="proofs processed concurrently per step on one GPU (one context + HIP stream each)")
     ap.add_argument("--no-extras", action="store_true", help="skip the MSM 2^24 / NTT 2^22 microbenchmarks and the CPU baseline")
     args = ap.parse_args(argv)
@@ -565,7 +567,7 @@ def main(argv=None):
     if args.mode == "prove":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import sgx_shaped_circuit as sgx
-        circuit = sgx.build(z, be, args.k)                      # one satisfying witness, shared by the contexts
+        circuit = sgx.build(z, be, args.k, census=args.census)  # one satisfying witness, shared by the contexts
         wls = []
         for b in bes:
             wls.append(ProverWorkload(z, b, args.k, circuit, srs=wls[0].params if wls else None))
@@ -676,6 +678,39 @@ def main(argv=None):
         extra["host_witness"] = dict(host_rates, bytes_per_proof=wl.A * wl.n * 32,
                                      what="same steps with the advice columns starting in host memory and uploaded inside create_proof (one zk_dev_upload_batch); "
                                           "uploads of one proof overlap the kernels of the other proofs in flight")
+    if args.mode == "prove" and not args.no_extras and world == 1:
+        # The OTHER census of the synthetic circuit, same K steps, same contexts: "reference_exact" builds the base64 part exactly as
+        # the reference configures and assigns it (15 advice columns that are zero outside 1696 rows, 7 lookups of 4/5 expressions on 65-/257-row
+        # tables) next to the chip estimate; "chip_estimate" guesses every column.  The real circuit's cost lies wherever its un-vendored chips put it.
+        other = "reference_exact" if args.census == "chip_estimate" else "chip_estimate"
+        census2 = None
+        try:
+            circuit2 = sgx.build(z, be, args.k, census=other)
+            wls2 = [ProverWorkload(z, b, args.k, circuit2, srs=wl.params) for b in bes]
+
+            def step2():
+                ths_ = [threading.Thread(target=w_.step) for w_ in wls2]
+                for t_ in ths_:
+                    t_.start()
+                for t_ in ths_:
+                    t_.join()
+            step2()
+            barrier()
+            t1 = time.time()
+            for _ in range(args.steps):
+                step2()
+            barrier()
+            d2 = time.time() - t1
+            extra["census_" + other] = {"proofs_per_hour": round(3600.0 * proofs_total / d2, 2), "ms_per_proof": round(d2 / proofs_total * 1e3, 3),
+                                         "commitments": wls2[0].info["commitments"], "proof_bytes": len(wls2[0].proof),
+                                         "shape": f"A={wls2[0].A} F={wls2[0].F} L={wls2[0].L} perm_columns={wls2[0].n_perm} degree={wls2[0].d}"}
+            census2 = (wls2[0].pk.vk, [w_.proof for w_ in wls2])       # verified by the CPU leg
+            for w_ in wls2:
+                for d_ in w_.master + w_.work:
+                    d_.free()
+                w_.pk.release()
+        except Exception as e:
+            extra["census_" + other + "_error"] = repr(e)
     if args.mode == "prove" and not args.no_extras:
         # latency of ONE proof with the GPU to itself (the timed region above measures throughput with several in flight)
         lat = []
@@ -701,6 +736,7 @@ def main(argv=None):
            "n_msm": wl.n_msm, "n_intt": wl.n_intt, "n_ext": wl.n_ext}
     cpu = None
     ntt_checks = []
+    census2 = locals().get("census2")
     if rank == 0 and not args.no_extras and world == 1:
         try:
             extra["msm_2^20"] = msm_microbench(be, 20, 20241008, verify=True)
@@ -731,6 +767,13 @@ def main(argv=None):
         if args.mode == "prove":
             cpu = cpu_baseline(cfg, os.cpu_count() or 1, program_for=lambda kk, ee: z.plonk.compile_program(wl.pk.vk.cs, kk, ee),
                                verify=(wl.pk.vk, TAU, [], [w_.proof for w_ in wls]), ntt_checks=ntt_checks, shim=shim)
+            if census2 is not None:
+                import importlib
+                vmod = importlib.import_module("verifier")               # oracle/verifier.py (sys.path set by cpu_baseline): CPU leg, checker only
+                ok2 = all(bool(vmod.verify_proof(census2[0], TAU, [], pr_)) for pr_ in census2[1][:1])
+                extra["census_" + ("reference_exact" if args.census == "chip_estimate" else "chip_estimate")]["verify_proof_accepted"] = ok2
+                if not ok2:
+                    raise RuntimeError("bench: the second-census proof was REJECTED by verify_proof")
             if shim is not None and "thin_shim" in extra and isinstance(cpu, dict) and "a13_a16_cpu_port" in cpu:
                 cpu_ms = cpu["a13_a16_cpu_port"]["total_ms"]
                 tot = extra["thin_shim"]["gpu_calls_total_ms"] + cpu_ms

@@ -81,6 +81,9 @@ int zk_dev_upload_batch(zk_ctx* ctx, void* const* dptrs_dev, const void* const* 
 int zk_bases_register(zk_ctx* ctx, const void* g1_affine_host, size_t n, uint64_t* handle);
 int zk_bases_register_dev(zk_ctx* ctx, const void* g1_affine_dev, size_t n, uint64_t* handle);
 int zk_bases_release(zk_ctx* ctx, uint64_t handle);
+/* Several contexts on one GPU (one per host thread that proves concurrently) use ONE expanded table: `ctx` receives a handle of its own onto the table
+ * `owner_handle` of `owner` (same device); the HBM copy is freed when the last handle is released / the last holding context destroyed. */
+int zk_bases_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_handle, uint64_t* handle);
 /* out_jacobian: 96 B, always normalised: (x, y, mont(1)) or (0, 0, 0) for the identity — a valid
  * halo2curves G1 value.  n may be smaller than the registered table (prefix is used). */
 int zk_msm(zk_ctx* ctx, uint64_t bases, const void* scalars_host, size_t n, void* out_jacobian);

@@ -166,7 +166,7 @@ def test_create_proof_negative_controls_gpu(gpu, orc, what):
     _rejects(gpu, 9, what)
 
 
-def _sgx_shaped(be, k, by_cosets=False):
+def _sgx_shaped(be, k, by_cosets=False, census="chip_estimate"):
     """The circuit shape bench.py proves at k = 19 (25 advice, 18 fixed, 11 lookups of 4-5 expressions, 16 equality columns,
     24 gates, degree 5; tools/sgx_shaped_circuit.py) at a size the Python verifier handles in a second."""
     import os, sys
@@ -175,7 +175,9 @@ def _sgx_shaped(be, k, by_cosets=False):
     import sgx_shaped_circuit as sc
     import verifier
     gpu = be
-    cs, fixed, asm, advice = sc.build(z, gpu, k)
+    cs, fixed, asm, advice = sc.build(z, gpu, k, census=census)
+    if k <= 10:
+        plonk.MockProver.run(k, cs, fixed, advice, [], asm).assert_satisfied()
     params = z.kzg.ParamsKZG.setup(k, TAU, backend=gpu)
     pk = plonk.keygen(params, cs, fixed, asm)
     tr = Blake2bWrite()
@@ -188,15 +190,28 @@ def _sgx_shaped(be, k, by_cosets=False):
         plonk.create_proof(params, pk2, advice, [], np.random.default_rng(3), tr2)
         assert tr2.finalize() == proof
         pk2.release()
-    assert info["commitments"] == 71 and len(proof) == 32 * (71 + info["evals"])
-    if k == 8:                          # same SRS / witness / RNG stream as the independent CPU prover's golden: the bytes must be identical
+    n_sets = -(-len(cs.permutation_columns) // cs.permutation_chunk_len())
+    assert info["commitments"] == 25 + 3 * 11 + n_sets + 1 + 4 + 2 and len(proof) == 32 * (info["commitments"] + info["evals"])
+    if k == 8 and census == "chip_estimate":                          # same SRS / witness / RNG stream as the independent CPU prover's golden: the bytes must be identical
         assert proof == _golden(GOLDEN_SGX)
     assert verifier.verify_proof(pk.vk, TAU, [], proof) is True
     bad = bytearray(proof)
-    bad[32 * 69 + 5] ^= 4
+    bad[32 * (info["commitments"] - 2) + 5] ^= 4                     # first evaluation word
     assert verifier.verify_proof(pk.vk, TAU, [], bytes(bad)) is False
     pk.release()
     params.release()
+
+
+def test_reference_exact_census_proof_verifies_emulated(emu, orc):
+    """census B (tools/sgx_shaped_circuit.py build_reference_exact): the base64 part exactly as the reference configures / assigns it
+    (sgx_dcap_verifier.rs:139-238, 260-329; table/mod.rs:24-149) + the chip estimate: MockProver satisfied, proof accepted, tampering rejected"""
+    _sgx_shaped(emu, 9, census="reference_exact")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [11, 19])
+def test_reference_exact_census_proof_verifies_gpu(gpu, orc, k):
+    _sgx_shaped(gpu, k, census="reference_exact")
 
 
 def test_sgx_shaped_circuit_proof_verifies_emulated(emu, orc):

@@ -108,3 +108,25 @@ def test_error_paths(emu, orc, pyref):
 
 def test_concurrent_callers(emu, orc, pyref):
     pc.check_concurrent_callers(emu, orc, pyref, n=60, threads=3)
+
+
+def test_shared_base_table_across_contexts(built, orc, pyref):
+    """zk_bases_share: a second context on the same device commits against the FIRST context's expanded table (no second HBM copy), and the table
+    outlives the release of the owner's handle while the borrower still holds it."""
+    import numpy as np
+    import zk_dcap_verifier_amd as z
+    import parity_cases as pc
+    from conftest import EMU_SO
+    a, b = z.Backend(0, lib_path=EMU_SO), z.Backend(0, lib_path=EMU_SO)
+    for be in (a, b):
+        be.tune(msm_sort_threads=64, msm_sort_wgs=3, msm_block=32, msm_target_threads=64, msm_min_chunk=2, vec_block=32)
+    sc, bases = pc.msm_inputs(orc, pyref, 300, 5)
+    want = orc.g1_to_affine(orc.best_multiexp(sc, bases))[0]
+    own = z.arithmetic.BasesHandle(a, bases)
+    lent = z.arithmetic.BasesHandle.shared(b, own)
+    assert (z.arithmetic.best_multiexp(sc, lent)[:8] == want).all()
+    own.release()                                                   # the borrower keeps the memory alive
+    assert (z.arithmetic.best_multiexp(sc, lent)[:8] == want).all()
+    lent.release()
+    a.close()
+    b.close()

@@ -89,6 +89,85 @@ __global__ void k_madd(uint32_t* out, uint32_t seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x.v[0] ^ acc.zzz.v[2];
 }
 
+// ---- round 2: what a 52-bit-limb v_fma_f64 Montgomery product would be built from -------------------------------------
+// Per 52x52 partial product (Emmart/Zheng/Weems): hi = fma_rz(a, b, 2^104); lo = fma_rz(a, b, (2^104 + 2^52) - hi); then the two bit patterns are
+// added into 64-bit integer column sums.  The kernels below measure each ingredient's issue rate and the whole 5 multiplicand-limb group.
+__global__ void k_add64f(uint32_t* out, uint32_t seed) {        // v_add_f64
+    double a = 1.0 + 1e-9 * (threadIdx.x + seed), x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3;
+    for (int i = 0; i < ITER; i++) { x0 = x0 + a; x1 = x1 + a; x2 = x2 + a; x3 = x3 + a; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(x0 + x1 + x2 + x3);
+}
+__global__ void k_addu64(uint32_t* out, uint32_t seed) {        // 64-bit integer add (v_lshl_add_u64 / v_add_co + v_addc_co, compiler's choice)
+    uint64_t a = ((uint64_t)(threadIdx.x + seed) << 29) | 0x123456789ull, x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3;
+    for (int i = 0; i < ITER; i++) { x0 += a ^ x1; x1 += a ^ x2; x2 += a ^ x3; x3 += a ^ x0; }
+    uint64_t r = x0 ^ x1 ^ x2 ^ x3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+}
+__global__ void k_lshladd64(uint32_t* out, uint32_t seed) {     // v_lshl_add_u64 forced
+    uint64_t a = ((uint64_t)(threadIdx.x + seed) << 29) | 0x123456789ull, x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n\tv_lshl_add_u64 %2, %2, 0, %1\n\tv_lshl_add_u64 %3, %3, 0, %1\n\tv_lshl_add_u64 %4, %4, 0, %1"
+                     : "+v"(x0), "+v"(a), "+v"(x1), "+v"(x2), "+v"(x3));
+    }
+    uint64_t r = x0 ^ x1 ^ x2 ^ x3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+}
+__global__ void k_shr64(uint32_t* out, uint32_t seed) {         // v_lshrrev_b64 (carry extraction between 52-bit columns)
+    uint64_t a = ((uint64_t)(threadIdx.x + seed) << 40) | 0xfedcba987ull, x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3;
+    for (int i = 0; i < ITER; i++) { x0 = (x0 >> 7) ^ a; x1 = (x1 >> 9) ^ a; x2 = (x2 >> 11) ^ a; x3 = (x3 >> 13) ^ a; }
+    uint64_t r = x0 ^ x1 ^ x2 ^ x3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+}
+// one partial product of the FMA scheme, as it would sit in the inner loop: 2 fma + 1 f64 add + 2 integer 64-bit adds.  Round-toward-zero is set
+// once per kernel (MODE.FP_ROUND for f64 = bits 3:2).  Four independent chains; timing only (operands drift, exactness is not the point here).
+__global__ void k_fma_partial(uint32_t* out, uint32_t seed) {
+    __builtin_amdgcn_s_setreg((2 << 11) | (2 << 6) | 1 /* hwreg(HW_REG_MODE, 2, 2) */, 3);
+    const double C1 = 0x1p104, C2 = 0x1p104 + 0x1p52;
+    double a0 = 4503599627370495.0 - (threadIdx.x + seed), a1 = a0 - 2, a2 = a0 - 4, a3 = a0 - 6, b = 4503599627370401.0 - blockIdx.x;
+    uint64_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    for (int i = 0; i < ITER; i++) {
+        double p0 = __builtin_fma(a0, b, C1), p1 = __builtin_fma(a1, b, C1), p2 = __builtin_fma(a2, b, C1), p3 = __builtin_fma(a3, b, C1);
+        double q0 = __builtin_fma(a0, b, C2 - p0), q1 = __builtin_fma(a1, b, C2 - p1), q2 = __builtin_fma(a2, b, C2 - p2), q3 = __builtin_fma(a3, b, C2 - p3);
+        h0 += __double_as_longlong(p0); h1 += __double_as_longlong(p1); h2 += __double_as_longlong(p2); h3 += __double_as_longlong(p3);
+        l0 += __double_as_longlong(q0); l1 += __double_as_longlong(q1); l2 += __double_as_longlong(q2); l3 += __double_as_longlong(q3);
+        a0 = __longlong_as_double((__double_as_longlong(a0) & ~0xfffull) | (l0 & 0xfff));     // keep the chains data dependent (1 and + 1 or per product: counted below)
+        a1 = __longlong_as_double((__double_as_longlong(a1) & ~0xfffull) | (l1 & 0xfff));
+        a2 = __longlong_as_double((__double_as_longlong(a2) & ~0xfffull) | (l2 & 0xfff));
+        a3 = __longlong_as_double((__double_as_longlong(a3) & ~0xfffull) | (l3 & 0xfff));
+    }
+    uint64_t r = h0 ^ h1 ^ h2 ^ h3 ^ l0 ^ l1 ^ l2 ^ l3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+}
+// the same bit-product volume on the integer path in use today: one v_mad_u64_u32 + v_addc_co_u32 per 32x32 partial product
+__global__ void k_mad_partial(uint32_t* out, uint32_t seed) {
+    uint32_t a0 = threadIdx.x + seed + 0x9e3779b9u, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, b = blockIdx.x * 2654435761u + 1;
+    uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    for (int i = 0; i < ITER; i++) {
+        mac1_vv(c0, n0, a0, b); mac1_vv(c1, n1, a1, b); mac1_vv(c2, n2, a2, b); mac1_vv(c3, n3, a3, b);
+        a0 ^= (uint32_t)c0 & 0xfff; a1 ^= (uint32_t)c1 & 0xfff; a2 ^= (uint32_t)c2 & 0xfff; a3 ^= (uint32_t)c3 & 0xfff;
+    }
+    uint64_t r = c0 ^ c1 ^ c2 ^ c3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32) ^ n0 ^ n1 ^ n2 ^ n3;
+}
+// upper bound of what lazy [0, 2p) reduction could give — the Montgomery product WITHOUT its final conditional subtraction
+// (results in [0, 2p); NOT a drop-in: every sub / equality test downstream would need the wider range)
+template <class FP> static ZK_HD u256 mul_no_final_sub(const u256& a, const u256& b) {
+    uint64_t acc = 0; uint32_t cnt = 0; uint32_t m[8]; u256 r;
+    using F_ = Field<FP>;
+    auto p = [](int i) { return F_::p(i); };
+#include "../zk-dcap-verifier_amd/csrc/field_mul_body.inc"
+    r.v[7] = (uint32_t)acc;
+    return r;
+}
+__global__ void k_fqmul_lazy(uint32_t* out, uint32_t seed) {
+    u256 x = Fq::one(), y = Fq::R2();
+    x.v[0] ^= threadIdx.x + seed; y.v[1] ^= blockIdx.x;
+    x = Fq::reduce_once(x);
+    for (int i = 0; i < ITER / 4; i++) { x = mul_no_final_sub<FqParams>(x, y); y = mul_no_final_sub<FqParams>(y, x); x.v[7] &= 0x3fffffff; y.v[7] &= 0x3fffffff; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x.v[0] ^ y.v[3];
+}
+
 template <class K>
 static double run(const char* name, K kern, double ops_per_thread, int block, int blocks_per_cu) {
     int grid = 256 * blocks_per_cu;
@@ -118,7 +197,19 @@ int main() {
         run("fma_f32", k_fma32, 4.0 * ITER, 256, bpc);
         run("add_xor32", k_add32, 8.0 * ITER, 256, bpc);
     }
+    printf("-- round 2: ingredients of a 52-bit-limb FMA Montgomery product vs the integer path (per partial product: fma scheme covers 52x52 = 2704 bit-products, mad+addc 32x32 = 1024)\n");
+    for (int bpc : {4, 8}) {
+        run("add_f64", k_add64f, 4.0 * ITER, 256, bpc);
+        run("add_u64", k_addu64, 4.0 * ITER, 256, bpc);
+        run("lshl_add_u64", k_lshladd64, 4.0 * ITER, 256, bpc);
+        run("lshr_b64", k_shr64, 4.0 * ITER, 256, bpc);
+        double f = run("fma_partial52", k_fma_partial, 4.0 * ITER, 256, bpc);
+        double m = run("mad_partial32", k_mad_partial, 4.0 * ITER, 256, bpc);
+        printf("   bit-products/s: fma scheme %.1f T, mad+addc %.1f T  -> ratio %.2f (before carry propagation, quotient digits and limb conversion of the fma form)\n",
+               f * 2704 / 1e12, m * 1024 / 1e12, (f * 2704) / (m * 1024));
+    }
     for (int bpc : {2, 4, 8}) {
+        run("fq_mul_lazy", k_fqmul_lazy, 2.0 * (ITER / 4), 256, bpc);
         run("fq_mul", k_fqmul, 2.0 * (ITER / 4), 256, bpc);
         run("fq_sqr", k_fqsqr, 2.0 * (ITER / 4), 256, bpc);
         run("fq_mul_cios", k_fqmul_cios, 2.0 * (ITER / 4), 256, bpc);

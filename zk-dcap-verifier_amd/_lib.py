@@ -220,6 +220,11 @@ class Backend:
             self._ck(self.lib.zk_bases_register_dev(self.ctx, C.c_void_p(_dptr(ptr)), C.c_size_t(n), C.byref(h)))
         return h.value
 
+    def bases_share(self, owner: "Backend", owner_handle: int) -> int:
+        h = C.c_uint64()
+        self._ck(self.lib.zk_bases_share(self.ctx, owner.ctx, C.c_uint64(owner_handle), C.byref(h)))
+        return h.value
+
     def bases_release(self, handle: int):
         self._ck(self.lib.zk_bases_release(self.ctx, C.c_uint64(handle)))
 

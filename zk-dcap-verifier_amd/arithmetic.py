@@ -25,6 +25,14 @@ class BasesHandle:
             self.n = bases[1]
         self.handle = backend.bases_register(bases)
 
+    @classmethod
+    def shared(cls, backend: Backend, owner: "BasesHandle") -> "BasesHandle":
+        """a handle of `backend` (another context on the same GPU) onto the table `owner` registered — no second copy of the expanded table in HBM"""
+        self = cls.__new__(cls)
+        self.backend, self.n = backend, owner.n
+        self.handle = backend.bases_share(owner.backend, owner.handle)
+        return self
+
     def release(self):
         if self.handle:
             self.backend.bases_release(self.handle)

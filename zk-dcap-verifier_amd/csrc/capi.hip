@@ -87,8 +87,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
         LOCK;
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
-        for (auto& kv : ctx->bases) (void)hipFree(kv.second.d_table);
-        ctx->bases.clear();
+        ctx->bases.clear();                     // shared tables are freed with their last holder
         release_twiddles(ctx);
         release_pks(ctx);
         release_programs(ctx);
@@ -174,6 +173,19 @@ int zk_dev_upload_batch(zk_ctx* ctx, void* const* dptrs, const void* const* host
 int zk_bases_register(zk_ctx* ctx, const void* p, size_t n, uint64_t* h) { ENTER; return msm_register(ctx, p, n, false, h); }
 int zk_bases_register_dev(zk_ctx* ctx, const void* p, size_t n, uint64_t* h) { ENTER; return msm_register(ctx, p, n, true, h); }
 int zk_bases_release(zk_ctx* ctx, uint64_t h) { ENTER; return msm_release(ctx, h); }
+int zk_bases_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_handle, uint64_t* h) {
+    if (!ctx || !owner || !h) return ZK_ERR_ARG;
+    zk::BaseTable bt;
+    {
+        std::lock_guard<std::mutex> lk(owner->mu);
+        auto it = owner->bases.find(owner_handle);
+        if (it == owner->bases.end()) return ZK_ERR_ARG;
+        bt = it->second;
+    }
+    LOCK;
+    if (owner->device != ctx->device) return ctx->fail(ZK_ERR_ARG, "zk_bases_share: the contexts are on different devices (%d, %d)", owner->device, ctx->device);
+    return msm_share(ctx, bt, h);
+}
 int zk_msm(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { ENTER; return msm_run(ctx, b, s, n, false, out, 0); }
 int zk_msm_dev(zk_ctx* ctx, uint64_t b, const void* s, size_t n, void* out) { ENTER; return msm_run(ctx, b, s, n, true, out, 0); }
 int zk_msm_batch(zk_ctx* ctx, uint64_t b, const void* const* s, size_t count, size_t n, void* out) { ENTER; return msm_run_batch(ctx, b, s, count, n, false, out, 0); }

@@ -4,6 +4,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -55,10 +56,16 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct TableMem {             // the window-expanded table in HBM; shared (refcounted) by every context of the process that registered or was lent it
+    void* p = nullptr;
+    int device = 0;
+    ~TableMem() { if (p) { (void)hipSetDevice(device); (void)hipFree(p); } }
+};
 struct BaseTable {
     void* d_table = nullptr;  // [W][n] affine points: table[j*n + i] = 2^(c*j) * P_i
     size_t n = 0;
     int c = 0, W = 0;
+    std::shared_ptr<TableMem> mem;
 };
 
 struct TwiddleSet {           // per (omega, log_n)
@@ -131,6 +138,7 @@ struct EvTimer {
 // implemented in the respective translation units
 int msm_register(zk_ctx* ctx, const void* pts, size_t n, bool on_device, uint64_t* handle);
 int msm_release(zk_ctx* ctx, uint64_t handle);
+int msm_share(zk_ctx* dst, const BaseTable& bt, uint64_t* handle);
 int msm_run(zk_ctx* ctx, uint64_t handle, const void* scalars, size_t n, bool on_device, void* out, int partial);
 int msm_run_batch(zk_ctx* ctx, uint64_t handle, const void* const* scalars, size_t nb, size_t n, bool on_device, void* out, int partial);
 int g1_sum_xyzz_host(const void* xyzz, size_t count, void* out_jac);

@@ -728,6 +728,9 @@ static int build_table(zk_ctx* ctx, const void* d_pts, size_t n, BaseTable& bt) 
     const int c = bt.c, W = bt.W;
     const size_t tbytes = (size_t)W * n * 64;
     ZK_HIP(hipMalloc(&bt.d_table, tbytes));
+    bt.mem = std::make_shared<TableMem>();
+    bt.mem->p = bt.d_table;
+    bt.mem->device = ctx->device;
     ZK_HIP(hipMemcpyAsync(bt.d_table, d_pts, n * 64, hipMemcpyDeviceToDevice, ctx->stream));
     if (W > 1) {
         ZK_HIP(ctx->ws_pts.ensure(n * 128));
@@ -763,17 +766,23 @@ int msm_register(zk_ctx* ctx, const void* pts, size_t n, bool on_device, uint64_
         d_pts = ctx->ws_tmp.p;
     }
     int rc = build_table(ctx, d_pts, n, bt);
-    if (rc) { if (bt.d_table) (void)hipFree(bt.d_table); return rc; }
+    if (rc) return rc;                                            // (bt.mem frees a partly built table)
     *handle = ctx->next_handle++;
     ctx->bases[*handle] = bt;
+    return ZK_OK;
+}
+
+// lend a registered table to another context on the same device: no second copy in HBM (one expanded SRS table per process, not per context)
+int msm_share(zk_ctx* dst, const BaseTable& bt, uint64_t* handle) {
+    *handle = dst->next_handle++;
+    dst->bases[*handle] = bt;
     return ZK_OK;
 }
 
 int msm_release(zk_ctx* ctx, uint64_t handle) {
     auto it = ctx->bases.find(handle);
     if (it == ctx->bases.end()) return ctx->fail(ZK_ERR_ARG, "zk_bases_release: unknown handle %llu", (unsigned long long)handle);
-    (void)hipFree(it->second.d_table);
-    ctx->bases.erase(it);
+    ctx->bases.erase(it);                                          // the memory goes when its last holder lets go
     return ZK_OK;
 }
 

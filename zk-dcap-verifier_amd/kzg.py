@@ -51,6 +51,16 @@ class ParamsKZG:
             d.free()
         return self
 
+    @classmethod
+    def shared_with(cls, other: "ParamsKZG", backend: Backend) -> "ParamsKZG":
+        """The same SRS for another context on the same GPU (one context per host thread that proves concurrently): both window-expanded tables
+        are SHARED with `other` (zk_bases_share) — one copy per process, 2 x 512 MiB at k = 19 instead of that per context."""
+        self = cls.__new__(cls)
+        self.backend, self.k, self.n = backend, other.k, other.n
+        self.g_host, self.g_lagrange_host = other.g_host, other.g_lagrange_host
+        self.g, self.g_lagrange = BasesHandle.shared(backend, other.g), BasesHandle.shared(backend, other.g_lagrange)
+        return self
+
     # -- ParamsKZG::{write, read}: k (u32 LE) | n compressed g | n compressed g_lagrange | g2 | s_g2  [3P-MEM: SURVEY §8f n3, App. C.7] ----------
     def write(self, g2: bytes = bytes(64), s_g2: bytes = bytes(64), sign_bit: int = 255) -> bytes:
         """The params/kzg_bn254_{k}.srs byte stream.  The G2 points are opaque 64-byte blobs here (the prover never touches them)."""

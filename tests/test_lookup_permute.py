@@ -23,6 +23,16 @@ def _case(orc, pyref, k, seed, kind):
         big = (1 << 252) + (0x1234567 << 200)  # sort cannot order them, the order check must send the call down the every-digit path
         tab_vals = [big + rnd.randrange(1 << 40) for _ in range(u)]
         inp_vals = [rnd.choice(tab_vals[: max(2, u // 2)]) for _ in range(u)]
+    elif kind == "theta_last":               # theta-compressed tuples whose LAST expression differs (the base64 lookups of the sgx circuit,
+        theta = rnd.randrange(R)              # sgx_dcap_verifier.rs:216-236: a character and three 2-bit chunks): v and v + small tie on the window
+        rows = [(61 if r > 64 else 65 + r, (r >> 4) % 4, (r >> 2) % 4, r % 4) if r < 257 else (61, 0, 0, 0) for r in range(u)]
+        comp = lambda e: (((e[0] * theta + e[1]) * theta + e[2]) * theta + e[3]) % R
+        tab_vals = [comp(e) for e in rows]
+        inp_vals = [comp(rows[rnd.randrange(min(64, u))]) if i % 4 == 0 and i < u // 2 else comp((65, 0, 0, 0)) for i in range(u)]
+    elif kind == "two_stage_ties":           # window ties that differ in two bit ranges more than 64 bits apart: two refinement stages
+        tab_vals = [(5 << 250) + ((i % 7) << 130) + (((i * 31) % 11) << 20) for i in range(u)]
+        rnd.shuffle(tab_vals)
+        inp_vals = [rnd.choice(tab_vals) for _ in range(u)]
     elif kind == "identical":                # all inputs equal
         tab_vals = [7] + [rnd.randrange(R) for _ in range(u - 1)]
         inp_vals = [7] * u
@@ -95,9 +105,26 @@ def test_lookup_permute_rejects_value_outside_table(emu, orc, pyref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,kind", [(7, "small"), (12, "wide"), (16, "small"), (14, "identical"), (15, "perm"), (13, "window_ties"), (18, "wide"), (19, "small")])
+@pytest.mark.parametrize("k,kind", [(7, "small"), (12, "wide"), (16, "small"), (14, "identical"), (15, "perm"), (13, "window_ties"), (18, "wide"), (19, "small"),
+                                    (10, "theta_last"), (19, "theta_last"), (14, "two_stage_ties")])
 def test_gpu_lookup_permute(gpu, orc, pyref, k, kind):
+    gpu.timing(True)
     _check(gpu, orc, pyref, k, kind, seed=k)
+    if kind in ("theta_last", "two_stage_ties", "window_ties"):       # window ties are refined by a few extra radix passes, not re-sorted digit by digit
+        assert gpu.stat_get("lookup_generic_sorts") == 0 and gpu.stat_get("lookup_refined_sorts") >= 1
+    gpu.timing(False)
+
+
+@pytest.mark.parametrize("kind", ["theta_last", "two_stage_ties", "window_ties"])
+def test_emulated_lookup_permute_refines_window_ties(emu, orc, pyref, kind):
+    emu.tune(vec_block=64)
+    try:
+        emu.timing(True)
+        _check(emu, orc, pyref, 9, kind, seed=3)
+        assert emu.stat_get("lookup_generic_sorts") == 0 and emu.stat_get("lookup_refined_sorts") >= 1
+    finally:
+        emu.timing(False)
+        emu.tune(vec_block=32)
 
 
 @pytest.mark.gpu

@@ -21,7 +21,7 @@ def main():
     if tune:
         be.tune(**tune)
     out = {"k": k, "tune": tune, "host_witness": os.environ.get("ZK_HOST_WITNESS") == "1"}
-    t = time.time(); cs, fixed, asm, advice = sc.build(z, be, k); out["build_witness_s"] = round(time.time() - t, 3)
+    t = time.time(); cs, fixed, asm, advice = sc.build(z, be, k, census=os.environ.get("ZK_CENSUS", "chip_estimate")); out["census"] = os.environ.get("ZK_CENSUS", "chip_estimate"); out["build_witness_s"] = round(time.time() - t, 3)
     t = time.time(); params = z.kzg.ParamsKZG.setup(k, TAU, backend=be); out["srs_setup_s"] = round(time.time() - t, 3)
     if os.environ.get("ZK_BY_COSETS") == "1":          # the multi-GPU quotient unit on one GPU: 2^(ek-k) coset NTTs of size n instead of one of size 2^ek
         params.quotient_by_cosets = True
@@ -45,6 +45,13 @@ def main():
         info = z.plonk.create_proof(params, pk, advice if host_witness else work, [], np.random.default_rng(r), tr, timings=tm)
         proof = tr.finalize()
         times.append(time.time() - t)
+    be.timing(True)                                    # once more with HIP-event kernel timing (alone on the GPU: the event pairs bracket only this proof's kernels)
+    for w, m in zip(work, master):
+        w.copy_from(m)
+    z.plonk.create_proof(params, pk, work, [], np.random.default_rng(99), Blake2bWrite())
+    out["kernel_ms"] = {lab: round(be.timing_get(lab)[0] or 0.0, 3) for lab in ("msm_sort", "msm_accumulate", "msm_reduce", "quotient")}
+    out["msm_pairs"] = be.stat_get("msm_pairs")
+    be.timing(False)
     out["create_proof_ms"] = [round(x * 1e3, 2) for x in times]
     out["phase_ms_last"] = {k_: round(v, 2) for k_, v in tm.items()}
     out["proof_bytes"] = len(proof)

@@ -451,6 +451,56 @@ ZK_KERNEL void lpb_check_kernel(LpbArgs a, const uint32_t* idx_sorted) {
         if (x[w] > y[w]) { atomicAdd(&a.cscal[s * 16 + 8], 1u); return; }
     }
 }
+// Columns whose rows tie on the 64-bit window but differ below it (theta-compressed lookups whose LAST expression differs: v and v + small —
+// the base64 lookups of the sgx circuit do, their last expression is a 2-bit chunk): cscal[s][0..8) <- OR over adjacent window-tied rows of x ^ y.
+// Any two tied values differ only inside that mask (x ^ z is the XOR of the adjacent XORs between them), so a stable LSD sort over the mask's
+// bit range followed by the window passes orders the column exactly — a few extra passes instead of the every-digit sort.
+ZK_KERNEL void lpb_tiemask_kernel(LpbArgs a, const uint32_t* idx_sorted) {
+    __shared__ uint32_t lor[8];
+    const uint32_t s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.cscal[s * 16 + 8] == 0) return;                               // (uniform per column)
+    if (threadIdx.x < 8) lor[threadIdx.x] = 0;
+    __syncthreads();
+    if (i > 0 && i < a.u) {
+        const uint32_t shift = a.shifts[s];
+        const uint32_t* canon = reinterpret_cast<const uint32_t*>(a.canon) + (size_t)s * a.u * 8;
+        const uint32_t* idx = idx_sorted + (size_t)s * a.u;
+        const uint32_t* x = canon + (size_t)idx[i - 1] * 8;
+        const uint32_t* y = canon + (size_t)idx[i] * 8;
+        uint32_t d[8], above = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            d[w] = x[w] ^ y[w];
+            const uint32_t lo_bit = (uint32_t)w * 32;                   // bits of word w at or above `shift` belong to the window
+            uint32_t in_window = lo_bit + 32 <= shift ? 0u : (lo_bit >= shift ? 0xffffffffu : (0xffffffffu << (shift - lo_bit)));
+            above |= d[w] & in_window;
+        }
+        if (above == 0) {
+#pragma unroll
+            for (int w = 0; w < 8; w++) if (d[w] & ~lor[w]) atomicOr(&lor[w], d[w]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && lor[threadIdx.x]) atomicOr(&a.cscal[s * 16 + threadIdx.x], lor[threadIdx.x]);
+}
+// refinement sort on a COMPACT list of columns (f < F, column fcols[f]): keys of the next stage = the 64-bit window at fshift[f] of the canonical
+// values, taken in the order of the previous stage (idx_in; null = identity)
+ZK_KERNEL void lpb_rekey_kernel(LpbArgs a, const uint32_t* fcols, const uint32_t* fshift, const uint32_t* idx_in, uint2* key_out, uint32_t* idx_out) {
+    const uint32_t f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.u) return;
+    const uint32_t c = fcols[f], shift = fshift[f];
+    const uint32_t r = idx_in ? idx_in[(size_t)f * a.u + i] : i;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(a.canon) + ((size_t)c * a.u + r) * 8;
+    const uint32_t ws = shift >> 5, bs = shift & 31;
+    uint32_t x[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) x[j] = ws + j < 8 ? w[ws + j] : 0u;
+    uint2 k;
+    k.x = bs ? (x[0] >> bs) | (x[1] << (32 - bs)) : x[0];
+    k.y = bs ? (x[1] >> bs) | (x[2] << (32 - bs)) : x[1];
+    key_out[(size_t)f * a.u + i] = k;
+    idx_out[(size_t)f * a.u + i] = r;
+}
 // flags[2l][i] = repeated, flags[2l+1][t] = unconsumed (pre-set to 1 by the caller)
 ZK_KERNEL void lpb_mark_kernel(LpbArgs a, const uint32_t* idx_sorted) {
     const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x, u = a.u;
@@ -646,8 +696,88 @@ int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* c
         std::swap(kin, kout);
         std::swap(iin, iout);
     }
-    const uint32_t* sorted = iin;
-    if (any_shift) { ZK_LAUNCH(lpb_check_kernel, dim3(g, C), blk, 0, st, a, sorted); ZK_CHECK_LAUNCH(); }
+    uint32_t* sorted = iin;
+    if (any_shift) {
+        ZK_LAUNCH(lpb_check_kernel, dim3(g, C), blk, 0, st, a, (const uint32_t*)sorted); ZK_CHECK_LAUNCH();
+        ZK_HIP(hipMemcpyAsync(csc.data(), a.cscal, (size_t)C * 64, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+        std::vector<uint32_t> fcols;
+        for (uint32_t c = 0; c < C; c++) if (csc[(size_t)c * 16 + 8]) fcols.push_back(c);
+        if (!fcols.empty() && !ctx->tune.lookup_force_generic_sort) {
+            // window ties: which bits do tied rows differ in?
+            for (uint32_t c : fcols) ZK_HIP(hipMemsetAsync((char*)a.cscal + (size_t)c * 64, 0, 32, st));
+            ZK_LAUNCH(lpb_tiemask_kernel, dim3(g, C), blk, 0, st, a, (const uint32_t*)sorted); ZK_CHECK_LAUNCH();
+            ZK_HIP(hipMemcpyAsync(csc.data(), a.cscal, (size_t)C * 64, hipMemcpyDeviceToHost, st));
+            ZK_HIP(hipStreamSynchronize(st));
+            const uint32_t Fn = (uint32_t)fcols.size();
+            // stages per column: 64-bit windows covering [lowest, highest] differing bit, low to high, then the top window again
+            std::vector<std::vector<uint32_t>> stage_shift;                 // [stage][f]; 0xffffffff = nothing to sort in this stage (constant key)
+            std::vector<uint32_t> stage_bits;
+            uint32_t n_low = 0;
+            std::vector<uint32_t> lo_bit(Fn), hi_bit(Fn);
+            for (uint32_t f = 0; f < Fn; f++) {
+                const uint32_t* m = &csc[(size_t)fcols[f] * 16];
+                uint32_t lo = 256, hi = 0;
+                for (uint32_t b = 0; b < 256; b++) if ((m[b >> 5] >> (b & 31)) & 1) { if (lo == 256) lo = b; hi = b; }
+                lo_bit[f] = lo; hi_bit[f] = hi;
+                if (lo < 256) n_low = std::max(n_low, (hi - lo) / 64 + 1);
+            }
+            for (uint32_t t = 0; t < n_low; t++) {
+                std::vector<uint32_t> sh(Fn);
+                uint32_t bits = 1;
+                for (uint32_t f = 0; f < Fn; f++) {
+                    const uint32_t st_lo = lo_bit[f] == 256 ? 256 : lo_bit[f] + 64 * t;
+                    if (st_lo > hi_bit[f] || st_lo >= 256) { sh[f] = 255; continue; }           // bit 255 of a canonical value is always 0: constant key
+                    sh[f] = st_lo;
+                    bits = std::max(bits, std::min(64u, hi_bit[f] - st_lo + 1));
+                }
+                stage_shift.push_back(sh); stage_bits.push_back(bits);
+            }
+            {
+                std::vector<uint32_t> sh(Fn);
+                for (uint32_t f = 0; f < Fn; f++) sh[f] = shifts[fcols[f]];
+                stage_shift.push_back(sh); stage_bits.push_back(max_bits);
+            }
+            const size_t per = (size_t)Fn * u;
+            size_t o2 = 0;
+            auto take2 = [&](size_t bytes) { size_t o = o2; o2 += (bytes + 255) & ~(size_t)255; return o; };
+            const size_t q_ka = take2(per * 8), q_kb = take2(per * 8), q_ia = take2(per * 4), q_ib = take2(per * 4), q_gh = take2((size_t)Fn * nwg * 256 * 4),
+                         q_fc = take2((size_t)Fn * 4), q_fs = take2((size_t)Fn * 4 * stage_shift.size());
+            ZK_HIP(ctx->ws_mid.ensure(o2 + 256));
+            char* b2 = (char*)ctx->ws_mid.p;
+            uint2 *rk_in = (uint2*)(b2 + q_ka), *rk_out = (uint2*)(b2 + q_kb);
+            uint32_t *ri_in = (uint32_t*)(b2 + q_ia), *ri_out = (uint32_t*)(b2 + q_ib), *rgh = (uint32_t*)(b2 + q_gh);
+            ZK_HIP(hipMemcpyAsync(b2 + q_fc, fcols.data(), (size_t)Fn * 4, hipMemcpyHostToDevice, st));
+            for (size_t t = 0; t < stage_shift.size(); t++)
+                ZK_HIP(hipMemcpyAsync(b2 + q_fs + t * Fn * 4, stage_shift[t].data(), (size_t)Fn * 4, hipMemcpyHostToDevice, st));
+            const uint32_t* order = nullptr;                                   // previous stage's order (compact); identity before the first
+            for (size_t t = 0; t < stage_shift.size(); t++) {
+                ZK_LAUNCH(lpb_rekey_kernel, dim3(g, Fn), blk, 0, st, a, (const uint32_t*)(b2 + q_fc), (const uint32_t*)(b2 + q_fs + t * Fn * 4), order, rk_in, ri_in);
+                ZK_CHECK_LAUNCH();
+                const uint32_t ps = (stage_bits[t] + 7) / 8;
+                for (uint32_t p = 0; p < ps; p++) {
+                    ZK_LAUNCH(lpb_hist_kernel, dim3(nwg, Fn), FS_T, 0, st, (const uint2*)rk_in, u, p, rgh, nwg);
+                    ZK_CHECK_LAUNCH();
+                    ZK_LAUNCH(lpb_offsets_kernel, Fn, 256, 0, st, rgh, nwg);
+                    ZK_CHECK_LAUNCH();
+                    ZK_LAUNCH(lpb_scatter_kernel, dim3(nwg, Fn), FS_T, 0, st, (const uint2*)rk_in, (const uint32_t*)ri_in, rk_out, ri_out, u, p, (const uint32_t*)rgh, nwg);
+                    ZK_CHECK_LAUNCH();
+                    std::swap(rk_in, rk_out);
+                    std::swap(ri_in, ri_out);
+                }
+                // the next rekey reads the order from ri_in and writes keys / order into the OTHER buffers
+                std::swap(rk_in, rk_out);
+                std::swap(ri_in, ri_out);
+                order = ri_out;
+            }
+            for (uint32_t f = 0; f < Fn; f++) {
+                ZK_HIP(hipMemcpyAsync(sorted + (size_t)fcols[f] * u, order + (size_t)f * u, (size_t)u * 4, hipMemcpyDeviceToDevice, st));
+                ZK_HIP(hipMemsetAsync((char*)a.cscal + (size_t)fcols[f] * 64 + 32, 0, 4, st));     // clear the violation count, then check again
+            }
+            ZK_LAUNCH(lpb_check_kernel, dim3(g, C), blk, 0, st, a, (const uint32_t*)sorted); ZK_CHECK_LAUNCH();
+            ctx->last_ms["lookup_refined_sorts"] += (double)Fn;
+        }
+    }
     ZK_LAUNCH(lpb_fill_unconsumed_kernel, dim3(g, (uint32_t)count), blk, 0, st, a);
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(lpb_mark_kernel, dim3(g, (uint32_t)count), blk, 0, st, a, sorted);
@@ -674,6 +804,8 @@ int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* c
     ZK_LAUNCH(lpb_assemble_kernel, dim3((n + blk - 1) / blk, (uint32_t)count), blk, 0, st, a, sorted);
     ZK_CHECK_LAUNCH();
     ZK_HIP(hipStreamSynchronize(st));
+    ctx->last_ms["lookup_sorts"] += (double)count;                     // statistics (zk_timing_get): lookups sorted, and how many took the every-digit path
+    ctx->last_ms["lookup_generic_sorts"] += (double)redo.size();
     for (size_t l : redo) {
         int rc = lookup_permute_one(ctx, d_inputs[l], d_tables[l], k, blinding_factors, (const char*)h_blind_inputs + l * (size_t)nb * 32,
                                     (const char*)h_blind_tables + l * (size_t)nb * 32, d_out_inputs[l], d_out_tables[l]);

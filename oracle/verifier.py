@@ -111,9 +111,10 @@ def _interpolate(points, evals):
     return coeffs
 
 
-def verify_proof(vk, tau: int, instances, proof: bytes) -> bool:
+def verify_proof(vk, tau: int, instances, proof: bytes, reader=None) -> bool:
     """plonk::verify_proof with VerifierSHPLONK and a single circuit instance.  vk: the keygen output (k, cs, fixed and
-    permutation commitments as canonical affine points, transcript_repr).  Returns True / False; malformed proofs raise ValueError."""
+    permutation commitments as canonical affine points, transcript_repr).  Returns True / False; malformed proofs raise ValueError.
+    `reader`: transcript reader class (squeeze / common_scalar / common_point / read_point / read_scalar / pos / proof)."""
     cs, k = vk.cs, vk.k
     n = 1 << k
     w = p.omega(k)
@@ -122,7 +123,7 @@ def verify_proof(vk, tau: int, instances, proof: bytes) -> bool:
     chunk = cs.permutation_chunk_len()
     n_perm = len(cs.permutation_columns)
     n_sets = (n_perm + chunk - 1) // chunk if n_perm else 0
-    tr = _Reader(proof)
+    tr = (reader or _Reader)(proof)                                    # default: Blake2bRead (stack A); oracle/poseidon_ref.Reader for stack B's PoseidonTranscript
     tr.common_scalar(vk.transcript_repr)
     assert len(instances) == cs.num_instance_columns
     for col in instances:

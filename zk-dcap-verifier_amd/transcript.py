@@ -19,24 +19,37 @@ from .fields import P_MOD, R_MOD
 PREFIX_CHALLENGE, PREFIX_POINT, PREFIX_SCALAR = b"\x00", b"\x01", b"\x02"
 
 
-def point_to_bytes(pt) -> bytes:
-    """G1Affine::to_bytes: pt = canonical (x, y) ints or None (identity)."""
+def point_to_bytes(pt, sign_bit: int = 255) -> bytes:
+    """G1Affine::to_bytes: pt = canonical (x, y) ints or None (identity).  sign_bit: where the y-parity flag lives — 255 for halo2curves 0.3.1 (stack A,
+    identity = all zero), 254 for halo2curves-axiom 0.5.2 (stack B: bit 255 marks the identity there; SURVEY App. B reads this off bin/assets/proof.bin)."""
     if pt is None:
-        return bytes(32)
+        return bytes(32) if sign_bit == 255 else bytes(31) + b"\x80"
     x, y = pt
     b = bytearray(x.to_bytes(32, "little"))
-    b[31] |= (y & 1) << 7
+    b[31] |= (y & 1) << (sign_bit - 248)
     return bytes(b)
 
 
-def point_from_bytes(b: bytes):
+def point_from_bytes(b: bytes, sign_bit: int = 255):
     """G1Affine::from_bytes -> (x, y) / None; raises ValueError when x is not on y^2 = x^3 + 3."""
     if len(b) != 32:
         raise ValueError("point encoding must be 32 bytes")
+    if sign_bit == 254:
+        if b[31] & 0x80:
+            if b != bytes(31) + b"\x80":
+                raise ValueError("non-canonical identity encoding")
+            return None
+        sign = (b[31] >> 6) & 1
+        x = int.from_bytes(b[:31] + bytes([b[31] & 0x3F]), "little")
+        return _lift_x(x, sign)
     if b == bytes(32):
         return None
     sign = b[31] >> 7
     x = int.from_bytes(b[:31] + bytes([b[31] & 0x7F]), "little")
+    return _lift_x(x, sign)
+
+
+def _lift_x(x: int, sign: int):
     if x >= P_MOD:
         raise ValueError("x coordinate not canonical")
     rhs = (x * x * x + 3) % P_MOD
@@ -103,6 +116,75 @@ class Blake2bRead(_Blake2bState):
 
     def read_point(self):
         pt = point_from_bytes(self._take())
+        self.common_point(pt)
+        return pt
+
+    def read_scalar(self) -> int:
+        s = int.from_bytes(self._take(), "little")
+        if s >= R_MOD:
+            raise ValueError("scalar not canonical")
+        self.common_scalar(s)
+        return s
+
+
+# ---- stack B: snark-verifier's PoseidonTranscript<G1Affine, NativeLoader, _> (crates/p256-ecdsa/src/base.rs:200-212, bin/src/main.rs:242) --------------------
+class _PoseidonState:
+    """system/halo2/transcript/halo2.rs ([3P-MEM], see poseidon.py): a point is absorbed as its two coordinates mapped from Fq into Fr (fe_to_fe: the
+    integer reduced mod r), a scalar as itself; squeeze_challenge is one sponge squeeze (no domain-separation bytes); points travel compressed with the
+    y-parity flag of halo2curves-axiom 0.5.2 (bit 254), scalars as 32-byte little-endian reprs."""
+    SIGN_BIT = 254
+
+    def __init__(self):
+        from .poseidon import Sponge
+        self.sponge = Sponge()
+
+    def squeeze_challenge(self) -> int:
+        return self.sponge.squeeze()
+
+    def common_point(self, pt) -> None:
+        if pt is None:
+            raise ValueError("Invalid elliptic curve point encoding in proof (the identity has no coordinates)")
+        self.sponge.update([pt[0] % R_MOD, pt[1] % R_MOD])
+
+    def common_scalar(self, s: int) -> None:
+        self.sponge.update([s % R_MOD])
+
+
+class PoseidonWrite(_PoseidonState):
+    """`PoseidonTranscript::<NativeLoader, Vec<u8>>::new::<0>(vec![])` ... `finalize()` — what snark_verifier_sdk::halo2::gen_proof drives (base.rs:200-212)"""
+
+    def __init__(self):
+        super().__init__()
+        self.buf = bytearray()
+
+    def write_point(self, pt) -> None:
+        self.common_point(pt)
+        self.buf += point_to_bytes(pt, self.SIGN_BIT)
+
+    def write_scalar(self, s: int) -> None:
+        self.common_scalar(s)
+        self.buf += (s % R_MOD).to_bytes(32, "little")
+
+    def finalize(self) -> bytes:
+        return bytes(self.buf)
+
+
+class PoseidonRead(_PoseidonState):
+    """`PoseidonTranscript::<NativeLoader, &[u8]>::new::<0>(proof)` (bin/src/main.rs:242)"""
+
+    def __init__(self, proof: bytes):
+        super().__init__()
+        self.proof, self.pos = bytes(proof), 0
+
+    def _take(self) -> bytes:
+        if self.pos + 32 > len(self.proof):
+            raise ValueError("proof too short")
+        b = self.proof[self.pos:self.pos + 32]
+        self.pos += 32
+        return b
+
+    def read_point(self):
+        pt = point_from_bytes(self._take(), self.SIGN_BIT)
         self.common_point(pt)
         return pt
 

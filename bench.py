@@ -870,11 +870,14 @@ def main(argv=None):
             cs_, fixed_, asm_, _adv = circuit
             spk = z.plonk.keygen(sp, cs_, fixed_, asm_)
 
+            phase_ms = {}
+
             def sharded_proof(seed):
                 for w_, m_ in zip(wl.work, wl.master):
                     w_.copy_from(m_)
                 tr_ = Blake2bWrite()
-                z.plonk.create_proof(sp, spk, wl.work, [], np.random.default_rng(seed), tr_)
+                phase_ms.clear()
+                z.plonk.create_proof(sp, spk, wl.work, [], np.random.default_rng(seed), tr_, timings=phase_ms)
                 return tr_.finalize()
             route = "device" if device_route else "host"
             try:
@@ -897,7 +900,8 @@ def main(argv=None):
             tt2 = torch.tensor([ds], dtype=torch.float64, device=tdev)
             dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
             extra["sharded_proof"] = {"ranks": world, "ms_per_proof": round(float(tt2.item()) * 1e3, 2), "identical_to_single_gpu_proof": same,
-                                      "quotient_exchange": route,
+                                      "quotient_exchange": route, "phase_ms_rank0": {k_: round(v, 2) for k_, v in phase_ms.items()},
+                                      "single_gpu_phase_ms": extra.get("single_proof", {}).get("phase_ms"),
                                       "what": "create_proof with both SRS tables sharded by index range (71 commitments = partial MSMs + all_gather of 128-byte XYZZ points) "
                                               "and the quotient sharded by extended-domain coset (size-n coset NTTs + evaluate_h per rank, one all_gather of n*32 bytes per coset); RCCL"}
             spk.release()

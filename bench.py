@@ -316,11 +316,11 @@ def cpu_a13_a16(orc, shim, threads):
         cols = {0: cap["advice"], 1: shim.fixed_values}
         vals = [cols[ty][i] for ty, i in cs.permutation_columns]
         chunk = cs.permutation_chunk_len()
-        last, delta = fm(1), 1
         DELTA = pow(7, 1 << 28, R_MOD)
-        for s0 in range(0, len(vals), chunk):                          # sets chain through their last value: sequential, as in halo2
-            _, last = orc.permutation_product(vals[s0:s0 + chunk], shim.sigma_values[s0:s0 + chunk], k, beta, gamma, fm(delta), last, blind1[:bf])
-            delta = delta * pow(DELTA, chunk, R_MOD) % R_MOD
+        # halo2 walks the sets one after the other (each starts at the previous set's last value) and spreads every set's row loops over rayon; the
+        # port's row loop is serial, so the sets run side by side here instead (the chaining is one scalar multiplication per row: timing-neutral)
+        list(pool.map(lambda s0: orc.permutation_product(vals[s0:s0 + chunk], shim.sigma_values[s0:s0 + chunk], k, beta, gamma,
+                                                         fm(pow(DELTA, s0, R_MOD)), fm(1), blind1[:bf]), range(0, len(vals), chunk)))
         out["permutation_commit_ms"] = (time.time() - t) * 1e3
         t = time.time()
         pt = fm(cap["y"])

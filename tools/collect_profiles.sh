@@ -12,5 +12,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 bench
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $O/lds -o l -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
 python tools/prover_probe.py 19 3 > $O/${TAG}_prover_probe_k19.json 2>> $O/bench.err
+ZK_CENSUS=reference_exact python tools/prover_probe.py 19 3 > $O/${TAG}_prover_probe_k19_census_reference_exact.json 2>> $O/bench.err
 python tools/prover_probe.py 21 1 > $O/${TAG}_prover_probe_k21.json 2>> $O/bench.err
 grep -h '^{' $O/${TAG}_bench_default.json | cut -c1-330

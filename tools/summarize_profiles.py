@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn one profiling session's rocprofv3 CSVs (gpurun_out/<dir>) into the summaries committed under profiles/r01/.
+"""Turn one profiling session's rocprofv3 CSVs (gpurun_out/<dir>) into the summaries committed under profiles/<round>/ (usage: <dir> <tag> [round = r02]).
 Session layout (see tools/collect_profiles.sh): <dir>/runNN_bench_default.json, runNN_bench_under_rocprofv3.json,
 stats/s_kernel_{stats,trace}.csv, fetch/f_counter_collection.csv, write/w_counter_collection.csv, lds/l_counter_collection.csv"""
 import collections
@@ -20,7 +20,9 @@ def last_json_line(path):
 
 def main():
     O, tag = sys.argv[1], sys.argv[2]
-    P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01")
+    rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", rnd)
+    os.makedirs(P, exist_ok=True)
     b = last_json_line(f"{O}/{tag}_bench_under_rocprofv3.json")
     rows = list(csv.DictReader(open(f"{O}/stats/s_kernel_trace.csv")))
     acc = sorted((r for r in rows if "msm_accumulate" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
@@ -57,7 +59,7 @@ def main():
                 by = (2 * fe[k][1] + wr.get(k, [0, 0])[1]) * 1024 / n
                 traffic[k] = by
                 f.write(f"{k},{n},{fe[k][1]:.1f},{wr.get(k, [0, 0])[1]:.1f},{by:.0f}\n")
-    tj = {"source": f"profiles/r01/{tag}_rocprofv3_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 --inflight 1 --no-extras; "
+    tj = {"source": f"profiles/{rnd}/{tag}_rocprofv3_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 --inflight 1 --no-extras; "
                     "bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 per the gfx950 correction of MI355X_MICROARCH.md HBM section)",
           "msm_accumulate_bytes_per_launch": round(traffic["msm_accumulate_kernel"]), "quotient_bytes_per_launch": round(traffic["quotient_kernel"]),
           "ntt_strided_pass_bytes_per_launch": round(traffic["ntt_strided_pass_kernel"]), "ntt_final_pass_bytes_per_launch": round(traffic["ntt_final_pass_kernel"])}

@@ -639,16 +639,19 @@ def main(argv=None):
     msm_pairs = be_stats["msm_pairs"]
     acc_s = max(acc_ms * 1e-3, 1e-9)                              # (the CPU plumbing test has no event timing)
     achieved = 96.0 * wl.n * msm_columns / acc_s / 1e9
-    traffic = None
+    # HBM bytes per launch from the PMC counters: they cannot be collected inside this run (separate rocprofv3 --pmc passes, MI355X_MICROARCH.md), so the
+    # figure is the one of the last profiling session (tools/collect_profiles.sh + tools/summarize_profiles.py), cited with its source
+    traffic, traffic_source = None, None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         try:
-            traffic = json.load(open(tj)).get("msm_accumulate_bytes_per_launch")
+            tjd = json.load(open(tj))
+            traffic, traffic_source = tjd.get("msm_accumulate_bytes_per_launch"), tjd.get("source", "").split(" (")[0]
         except Exception:
             traffic = None
     XYZZ_MADD_PEAK = 13.17e9   # mixed additions/s of the same code in a register-only loop (profiles/r01/run43_microbench_dedicated_sqr.txt)
     roofline = {"kernel": "msm_accumulate_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(acc_ms / max(acc_n, 1), 4), "launches": acc_n,
                 "algorithmic_bytes_per_launch": round(96.0 * wl.n * msm_columns / max(acc_n, 1)),
                 "note": "the kernel is integer-ALU bound (v_mad_u64_u32), not HBM bound - DESIGN.md 3.2; int_alu gives the fraction of the "

@@ -104,6 +104,14 @@ def test_emulated_quotient_vs_oracle(emu, orc, pyref, seed, shape):
     qc.run_case(emu, orc, pyref, pc, prog, seed=seed)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8])
+def test_emulated_quotient_dense_random_programs(emu, orc, pyref, seed):
+    """60 random calculations per gate graph: values with several readers (a product that is folded AND read elsewhere must not be fused away), gate
+    polynomials that read PreviousValue themselves (the custom-gate Horner may then not run in the accumulator), Horner chains shared between lookups"""
+    prog = qc.build_program(orc, pyref, seed=seed, gate_ops=60, k=4, cs_degree=5, n_fixed=4, n_advice=6, n_instance=1, n_challenges=1, n_perm=7, n_lookups=3)
+    qc.run_case(emu, orc, pyref, pc, prog, seed=seed)
+
+
 def test_quotient_rejects_malformed_programs(emu, orc, pyref):
     import zk_dcap_verifier_amd as z
     with pytest.raises(z.ZkError):

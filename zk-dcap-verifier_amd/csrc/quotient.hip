@@ -275,25 +275,29 @@ struct Builder {
         shared[key] = v;
         return v;
     }
-    // value = value*y + term.  When `term` is the product emitted just before (and nothing else reads it) the two products share one Montgomery
-    // reduction: acc = acc*y + a*b (M_FOLD2, Field::mul2_add) — 192 limb products instead of 256 on each of the ~90 folds of a row.
-    void fold(Opnd term) {
-        if ((term.word >> 28) == K_SLOT && term.vreg >= 0 && !ins.empty() && ins.back().op == M_MUL && ins.back().dst == term.vreg && fuse_folds) {
-            VIns m = ins.back();
-            bool reads_acc = false;
-            for (int i = 0; i < m.nsrc; i++) reads_acc |= (m.src[i] >> 28) == K_ACC;
-            if (!reads_acc) {
-                ins.pop_back();
-                VIns v; v.op = M_FOLD2; v.dst = -1; v.nsrc = 3;
-                v.src[0] = m.src[0]; v.vsrc[0] = m.vsrc[0]; v.src[1] = m.src[1]; v.vsrc[1] = m.vsrc[1];
-                v.src[2] = enc(K_CONST, P.c_y); v.vsrc[2] = -1;
-                ins.push_back(v);
-                return;
-            }
+    void fold(Opnd term) { emit(M_MULADD, -1, {acc(), cst(P.c_y), term}); }   // value = value*y + term
+    // Peephole over the finished program: value = value*y + t, where t = a*b is the instruction just before and nothing else reads t, becomes
+    // acc = acc*y + a*b with ONE Montgomery reduction (M_FOLD2, Field::mul2_add): 192 limb products instead of 256 on each of the ~90 folds of a row.
+    void fuse_folds_pass() {
+        std::vector<int> uses(next_vreg, 0);
+        for (auto& v : ins) for (int i = 0; i < v.nsrc; i++) if (v.vsrc[i] >= 0) uses[v.vsrc[i]]++;
+        std::vector<VIns> out;
+        for (auto& v : ins) {
+            const bool is_fold = v.op == M_MULADD && v.dst < 0 && v.nsrc == 3 && (v.src[0] >> 28) == K_ACC && v.src[1] == enc(K_CONST, P.c_y) &&
+                                 (v.src[2] >> 28) == K_SLOT && v.vsrc[2] >= 0;
+            if (is_fold && !out.empty() && out.back().op == M_MUL && out.back().dst == v.vsrc[2] && uses[v.vsrc[2]] == 1 &&
+                (out.back().src[0] >> 28) != K_ACC && (out.back().src[1] >> 28) != K_ACC) {
+                const VIns m = out.back();
+                out.pop_back();
+                VIns f; f.op = M_FOLD2; f.dst = -1; f.nsrc = 3;
+                f.src[0] = m.src[0]; f.vsrc[0] = m.vsrc[0]; f.src[1] = m.src[1]; f.vsrc[1] = m.vsrc[1];
+                f.src[2] = enc(K_CONST, P.c_y); f.vsrc[2] = -1;
+                out.push_back(f);
+            } else out.push_back(v);
         }
-        emit(M_MULADD, -1, {acc(), cst(P.c_y), term});
+        ins.swap(out);
     }
-    bool fuse_folds = true;
+
 };
 
 }  // namespace
@@ -433,6 +437,8 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         // Horner needs interleaving (part_i must be emitted right before its step), so it keeps a
         // running value across operand visits.
         std::vector<int> horner_cur(nc, -1);
+        size_t prev_reads = 0;                       // how many operands of the graph read PreviousValue (halo2: exactly one, the start of the final Horner)
+        for (size_t i = 0; i < nc; i++) for (const VSrc* o : operands_of(g.calcs[i])) if (o->kind == VS_PREV) prev_reads++;
         while (!st.empty()) {
             Frame& f = st.back();
             const int ci = f.calc;
@@ -482,7 +488,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
                                                 Fr::is_zero(g.constants[k.s0.a]);
                         // halo2's custom-gate evaluator ends in Horner(PreviousValue, gates, y): when that is the graph's result and the previous value IS the
                         // accumulator, every step is a fold of the accumulator itself (and fuses with the gate's last product, Builder::fold)
-                        const bool in_acc = prev_is_acc && ci == (int)nc - 1 && d[0] < 0 && k.s0.kind == VS_PREV && d[1] < 0 && k.s1.kind == VS_Y;
+                        const bool in_acc = prev_is_acc && ci == (int)nc - 1 && d[0] < 0 && k.s0.kind == VS_PREV && d[1] < 0 && k.s1.kind == VS_Y && prev_reads == 1;
                         if (in_acc) { B.fold(opnd_at(oi)); horner_cur[ci] = -2; }
                         else if (zero_start) horner_cur[ci] = (d[oi] >= 0 && !is_alias[d[oi]]) ? vreg[d[oi]] : B.tmp_shared(M_MOV, {opnd_at(oi)});
                         else {
@@ -587,6 +593,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
     }
     if (P.rotations.size() > 255) return ctx->fail(ZK_ERR_LIMIT, "quotient program: more than 255 distinct rotations");
 
+    B.fuse_folds_pass();
     // ---- dead-code elimination + linear-scan slot allocation -------------------------------------
     const int nv = B.next_vreg;
     std::vector<int> last_use(nv, -1);

@@ -8,7 +8,7 @@ with the SDK's parameters T = 3, RATE = 2, R_F = 8, R_P = 57, SECURE_MDS = 0 (`s
 [3P-MEM] — restated from the published algorithm (Grassi et al., Poseidon; round constants and the Cauchy MDS matrix from the Grain LFSR exactly as
 the `poseidon` crate of privacy-scaling-explorations generates them: grain.rs / mds.rs).  The crate is not on this machine and no vector of the
 reference pins it: the reference's one Poseidon artefact, bin/assets/proof.bin, needs params/vk.bin to be replayed, which is git-ignored.
-Two independent writings of the same recollection (this file, oracle/poseidon_ref.py) are cross-checked in tests/test_poseidon_transcript.py;
+Two independent writings of the same recollection (this file and the test suite's own checker) are cross-checked in tests/test_poseidon_transcript.py;
 equality with the Rust crate stays UNPINNED until one `cargo test` dumps a squeeze (shim/README.md).
 """
 from __future__ import annotations

@@ -381,6 +381,11 @@ def cpu_baseline(cfg, threads, program_for=None, verify=None, ntt_checks=(), shi
     if shim is not None:
         try:
             out["a13_a16_cpu_port"] = cpu_a13_a16(orc, shim, threads)
+            # with the CPU loops of a13-a16 timed, the baseline proof is complete (round 1 left them out): fold them into `value`
+            total += out["a13_a16_cpu_port"]["total_ms"] * 1e-3
+            out["value"] = round(3600.0 / total, 3)
+            out["sample"] = out["sample"].replace("(grand products, lookup permutation, evaluations and SHPLONK of the CPU prover are NOT counted: the baseline is optimistic)",
+                                                  f"+ lookup permutation, grand products, evaluations and SHPLONK combinations on the port {out['a13_a16_cpu_port']['total_ms'] / 1e3:.2f}s")
         except Exception as e:
             out["a13_a16_cpu_port_error"] = repr(e)
     if ntt_checks:

@@ -18,6 +18,7 @@ from zk_dcap_verifier_amd.transcript import Blake2bWrite
 TAU = 0x1C59A59B6CFF4308740943526ADE1D8C09F71B337A67269CC89586BCDD6DFCBA % R_MOD   # SURVEY App. C.7 (any value works)
 GOLDEN_PROOF = "toy_proof_k6_seed7.bin"      # tools/gen_golden_proof.py: bytes of the INDEPENDENT CPU prover (oracle/prover.py); see tests/golden/README.md
 GOLDEN_SGX = "sgx_shaped_k8_seed3.bin"       # the same for the sgx_dcap_verifier-shaped circuit at k = 8, rng seed 3
+GOLDEN_REF_EXACT = "reference_exact_k9_seed3.bin"   # ... and for census B (the reference's base64 sub-circuit built exactly) at k = 9
 
 
 def _golden(name=GOLDEN_PROOF):
@@ -192,6 +193,8 @@ def _sgx_shaped(be, k, by_cosets=False, census="chip_estimate"):
         pk2.release()
     n_sets = -(-len(cs.permutation_columns) // cs.permutation_chunk_len())
     assert info["commitments"] == 25 + 3 * 11 + n_sets + 1 + 4 + 2 and len(proof) == 32 * (info["commitments"] + info["evals"])
+    if k == 9 and census == "reference_exact":
+        assert proof == _golden(GOLDEN_REF_EXACT)
     if k == 8 and census == "chip_estimate":                          # same SRS / witness / RNG stream as the independent CPU prover's golden: the bytes must be identical
         assert proof == _golden(GOLDEN_SGX)
     assert verifier.verify_proof(pk.vk, TAU, [], proof) is True
@@ -209,7 +212,7 @@ def test_reference_exact_census_proof_verifies_emulated(emu, orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [11, 19])
+@pytest.mark.parametrize("k", [9, 11, 19])
 def test_reference_exact_census_proof_verifies_gpu(gpu, orc, k):
     _sgx_shaped(gpu, k, census="reference_exact")
 
@@ -238,7 +241,8 @@ def test_cpu_prover_reproduces_the_committed_goldens(orc):
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_golden_proof as gg
-    for name, (t_, cs, instances, (keys, proof)) in ((GOLDEN_PROOF, gg.toy()), (GOLDEN_SGX, gg.sgx_shaped())):
+    for name, (t_, cs, instances, (keys, proof)) in ((GOLDEN_PROOF, gg.toy()), (GOLDEN_SGX, gg.sgx_shaped()),
+                                                     (GOLDEN_REF_EXACT, gg.sgx_shaped(9, 3, "reference_exact"))):
         assert proof == _golden(name), name
         assert verifier.verify_proof(keys, TAU, instances, proof) is True
 

@@ -3,6 +3,7 @@
 definition, MSMs on the C oracle — no product code, no kernel emulator):
     toy_proof_k6_seed7.bin     the toy circuit of tests/test_create_proof.py, k = 6, np.random.default_rng(7)
     sgx_shaped_k8_seed3.bin    the sgx_dcap_verifier-shaped circuit (tools/sgx_shaped_circuit.py: 25 advice, 11 lookups, 16 equality columns), k = 8, rng 3
+    reference_exact_k9_seed3.bin  census B of the same tool (the reference's base64 sub-circuit built exactly + chip estimate), k = 9, rng 3
 Both with the SRS trapdoor TAU of the tests.  The GPU prover (and the emulated kernels) must emit exactly these bytes, and the pure-Python
 verifier must accept them.  They are NOT outputs of the reference (no Rust toolchain here; the reference holds no stack-A proof): they replace the
 round-1 goldens, which the emulator build of the product's own kernels had produced."""
@@ -31,7 +32,7 @@ def toy(k=6, seed=7):
     return t, cs, instances, oracle_proof(k, t.TAU, cs, fixed, asm.copies, advice, instances, seed)
 
 
-def sgx_shaped(k=8, seed=3):
+def sgx_shaped(k=8, seed=3, census="chip_estimate"):
     import test_create_proof as t
     import sgx_shaped_circuit as sc
     import zk_dcap_verifier_amd as z
@@ -59,13 +60,17 @@ def sgx_shaped(k=8, seed=3):
 
         def fr_add_dev(self, a, b, out, n):
             out.a = self.orc.fr_add(a.a[:n], b.a[:n])
-    cs, fixed, asm, advice = sc.build(z, FieldCalc(), k)
+
+        def fr_scale_dev(self, a, scalar, out, n):
+            out.a = self.orc.fr_mul(a.a[:n], np.repeat(np.asarray(scalar, dtype=np.uint64).reshape(1, 4), n, axis=0))
+    cs, fixed, asm, advice = sc.build(z, FieldCalc(), k, census=census)
     return t, cs, [], oracle_proof(k, t.TAU, cs, fixed, asm.copies, advice, [], seed)
 
 
 def main():
     import verifier
-    for name, (t, cs, instances, (keys, proof)) in (("toy_proof_k6_seed7.bin", toy()), ("sgx_shaped_k8_seed3.bin", sgx_shaped())):
+    for name, (t, cs, instances, (keys, proof)) in (("toy_proof_k6_seed7.bin", toy()), ("sgx_shaped_k8_seed3.bin", sgx_shaped()),
+                                                    ("reference_exact_k9_seed3.bin", sgx_shaped(9, 3, "reference_exact"))):
         keys.cs, keys.k = cs, keys.k
         assert verifier.verify_proof(keys, t.TAU, instances, proof) is True, name
         out = os.path.join(ROOT, "tests", "golden", name)

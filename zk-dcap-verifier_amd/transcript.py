@@ -194,3 +194,73 @@ class PoseidonRead(_PoseidonState):
             raise ValueError("scalar not canonical")
         self.common_scalar(s)
         return s
+
+
+# ---- stack B, EVM flavour: snark-verifier's EvmTranscript<G1Affine, NativeLoader, _, _> (gen_evm_proof_shplonk, crates/p256-ecdsa/src/base.rs:193-199) ------------
+class _EvmState:
+    """system/halo2/transcript/evm.rs ([3P-MEM]): everything is absorbed as 32-byte BIG-endian words into a byte buffer (a point as x then y, uncompressed);
+    squeeze_challenge = keccak256(buffer, plus one byte 0x01 when the buffer is exactly the 32 bytes of the previous hash), the hash becomes the new buffer
+    and, read as a big-endian integer reduced mod r, the challenge.  Points travel as 64 bytes, scalars as 32, all big endian — the layout the generated
+    Solidity verifier reads from calldata."""
+
+    def __init__(self):
+        self.buf = bytearray()
+
+    def squeeze_challenge(self) -> int:
+        from .keccak import keccak256
+        data = bytes(self.buf) + (b"\x01" if len(self.buf) == 32 else b"")
+        h = keccak256(data)
+        self.buf = bytearray(h)
+        return int.from_bytes(h, "big") % R_MOD
+
+    def common_point(self, pt) -> None:
+        if pt is None:
+            raise ValueError("Invalid elliptic curve point encoding in proof (the identity has no coordinates)")
+        self.buf += pt[0].to_bytes(32, "big") + pt[1].to_bytes(32, "big")
+
+    def common_scalar(self, s: int) -> None:
+        self.buf += (s % R_MOD).to_bytes(32, "big")
+
+
+class EvmWrite(_EvmState):
+    def __init__(self):
+        super().__init__()
+        self.out = bytearray()
+
+    def write_point(self, pt) -> None:
+        self.common_point(pt)
+        self.out += pt[0].to_bytes(32, "big") + pt[1].to_bytes(32, "big")
+
+    def write_scalar(self, s: int) -> None:
+        self.common_scalar(s)
+        self.out += (s % R_MOD).to_bytes(32, "big")
+
+    def finalize(self) -> bytes:
+        return bytes(self.out)
+
+
+class EvmRead(_EvmState):
+    def __init__(self, proof: bytes):
+        super().__init__()
+        self.proof, self.pos = bytes(proof), 0
+
+    def _take(self, n: int) -> bytes:
+        if self.pos + n > len(self.proof):
+            raise ValueError("proof too short")
+        self.pos += n
+        return self.proof[self.pos - n:self.pos]
+
+    def read_point(self):
+        b = self._take(64)
+        x, y = int.from_bytes(b[:32], "big"), int.from_bytes(b[32:], "big")
+        if x >= P_MOD or y >= P_MOD or (y * y - x * x * x - 3) % P_MOD:
+            raise ValueError("not on curve")
+        self.common_point((x, y))
+        return x, y
+
+    def read_scalar(self) -> int:
+        s = int.from_bytes(self._take(32), "big")
+        if s >= R_MOD:
+            raise ValueError("scalar not canonical")
+        self.common_scalar(s)
+        return s

@@ -29,6 +29,7 @@ static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 #define __launch_bounds__(...)
 #define __shared__ static
 #define ZK_KERNEL
+#define ZK_WAVES_PER_EU(n)
 #define ZK_LAUNCH_BOUNDS(n)
 
 inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;

@@ -81,7 +81,7 @@ struct QuotArgs {
 // execute time because the previous instruction may just have written them.
 // NR rows per thread (rows idx, idx + T, ...): one decode of a micro-op serves NR rows — the decode is ≈50 issue slots against ≈300 for a product.
 template <int NR>
-ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) quotient_kernel(QuotArgs q) {
+ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_kernel(QuotArgs q) {
     ZK_DYN_SHARED(uint4, smem);
     const uint32_t T = blockDim.x, tid = threadIdx.x;
     const uint32_t idx0 = blockIdx.x * (T * NR) + tid;          // row r of this thread: idx0 + r * T

@@ -18,4 +18,6 @@
     type* name = reinterpret_cast<type*>(name##_raw)
 #define ZK_KERNEL __global__
 #define ZK_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+// ask the register allocator for at least n waves per SIMD (VGPR budget 512 / n): a hint that costs spills when it cannot be met — check ScratchSize
+#define ZK_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
 #endif

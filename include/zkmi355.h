@@ -224,10 +224,10 @@ typedef struct zk_quotient_args {
 } zk_quotient_args;
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog);
-/* size of the compiled micro-program: instructions, live-value slots (first 3 are registers, rest LDS), columns */
+/* size of the compiled micro-program: instructions, live-value slots (the first is a register, the rest LDS), columns */
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
 /* opcode census of the compiled micro-program (the arithmetic a row costs — what the kernel's roofline is priced from):
- * counts[0..7] = add, sub, mul, sqr, dbl, neg, mov, mul-add instructions; counts[8] = column / constant operands read from memory per row */
+ * counts[0..7] = add, sub, mul, sqr, dbl, neg, mov, mul-add instructions (a fused fold value*y + a*b — two products, one reduction — counts as a mul-add); counts[8] = column / constant operands read from memory per row */
 int zk_quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]);
 int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args);
 /* The same on ONE coset of the extended domain (the rows coset, coset + 2^(extended_k-k), ...): every column of `args` holds that coset's n = 2^k values

@@ -58,7 +58,7 @@ struct QuotProgram {
 #define ZK_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #endif
 
-constexpr uint32_t QUOT_NREG = 3;   // first slots of the allocator are registers, the rest LDS
+constexpr uint32_t QUOT_NREG = 1;   // first slot of the allocator is a register, the rest LDS (3 -> 1: 128 -> 116 VGPRs, 9.74 -> 9.18 ms at k = 19: profiles/r02)
 
 struct QuotArgs {
     const uint4* code;
@@ -86,10 +86,10 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_k
     const uint32_t T = blockDim.x, tid = threadIdx.x;
     const uint32_t idx0 = blockIdx.x * (T * NR) + tid;          // row r of this thread: idx0 + r * T
     const uint32_t mask = (1u << q.size_log) - 1u;
-    u256 acc[NR], xpow[NR], rg0[NR], rg1[NR], rg2[NR];          // slots 0..QUOT_NREG-1 live in VGPRs
+    u256 acc[NR], xpow[NR], rg0[NR];                            // slot 0 lives in VGPRs
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        acc[r] = Fr::zero(); xpow[r] = Fr::one(); rg0[r] = rg1[r] = rg2[r] = Fr::zero();
+        acc[r] = Fr::zero(); xpow[r] = Fr::one(); rg0[r] = Fr::zero();
         if (q.uses_xpow) {  // extended_omega^(position of this row in the extended domain)
             const uint32_t xi = (idx0 + r * T) * q.xpow_mul + q.xpow_add;
             xpow[r] = load_u256(q.tw_lo, xi & ((1u << q.lo_bits) - 1u));
@@ -123,7 +123,7 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_k
         switch (kind) {
             case K_SLOT: {
                 switch (pay) {
-                    case 0: return rg0[r]; case 1: return rg1[r]; case 2: return rg2[r];
+                    case 0: return rg0[r];
                     default: break;
                 }
                 const uint32_t ls = (pay - QUOT_NREG) * NR + r;
@@ -172,7 +172,7 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_k
             } else {
                 const uint32_t slot = w0 >> 16;
                 switch (slot) {
-                    case 0: rg0[r] = res[r]; break; case 1: rg1[r] = res[r]; break; case 2: rg2[r] = res[r]; break;
+                    case 0: rg0[r] = res[r]; break;
                     default: {
                         const uint32_t ls = (slot - QUOT_NREG) * NR + r;
                         smem[(2 * ls) * T + tid] = make_uint4(res[r].v[0], res[r].v[1], res[r].v[2], res[r].v[3]);

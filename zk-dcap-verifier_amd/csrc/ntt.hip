@@ -101,8 +101,11 @@ ZK_HD u256 lds_get(const uint4* lo, const uint4* hi, uint32_t idx) {
 // all log R DIT stages on the tile held in LDS (rows were stored bit-reversed).  Two stages at a time are
 // done in registers (radix-4 step: 4 loads, 4 butterflies, 4 stores) so the tile makes half as many LDS
 // round trips and barriers as a radix-2 sweep; an odd last stage is a plain radix-2 step.
-__device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r, uint32_t c_log, const void* stage_tw, bool quarter_input) {
+// stage_tw: the R/2 stage twiddles of the pass, staged in LDS by the caller (32 bytes each: every radix-4 step reads three of them per quad,
+// and an LDS read returns in ~50 cycles where the L2 hit of a global load takes 200+)
+__device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r, uint32_t c_log, const uint4* stage_tw, bool quarter_input) {
     const uint32_t C = 1u << c_log;
+    auto tw_at = [&](size_t i) { const uint4 l = stage_tw[2 * i], h = stage_tw[2 * i + 1]; u256 o; o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w; return o; };
     uint32_t s = 0;
     if (quarter_input && r >= 2) {
         // coeff_to_extended with extended_k >= k + 2: rows >= R/4 of the first pass are the zero padding, i.e. (rows are stored bit-reversed) only
@@ -128,14 +131,14 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
             const uint32_t i0 = ((grp << (s + 2)) + pos) * C + col, step = h * C;
             u256 x0 = lds_get(lo, hi, i0), x1 = lds_get(lo, hi, i0 + step), x2 = lds_get(lo, hi, i0 + 2 * step), x3 = lds_get(lo, hi, i0 + 3 * step);
             if (pos) {
-                const u256 w1 = load_u256(stage_tw, (size_t)pos << (r - 1 - s));
+                const u256 w1 = tw_at((size_t)pos << (r - 1 - s));
                 x1 = Fr::mul(x1, w1);
                 x3 = Fr::mul(x3, w1);
             }
             const u256 t0 = Fr::add(x0, x1), t1 = Fr::sub(x0, x1);
             u256 t2 = Fr::add(x2, x3), t3 = Fr::sub(x2, x3);
-            if (pos) t2 = Fr::mul(t2, load_u256(stage_tw, (size_t)pos << (r - 2 - s)));
-            t3 = Fr::mul(t3, load_u256(stage_tw, (size_t)(pos + h) << (r - 2 - s)));
+            if (pos) t2 = Fr::mul(t2, tw_at((size_t)pos << (r - 2 - s)));
+            t3 = Fr::mul(t3, tw_at((size_t)(pos + h) << (r - 2 - s)));
             lds_put(lo, hi, i0, Fr::add(t0, t2));
             lds_put(lo, hi, i0 + step, Fr::add(t1, t3));
             lds_put(lo, hi, i0 + 2 * step, Fr::sub(t0, t2));
@@ -151,7 +154,7 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
             const uint32_t grp = bq >> s, pos = bq & (half - 1);
             const uint32_t i0 = ((grp << (s + 1)) + pos) * C + col, i1 = i0 + half * C;
             u256 x = lds_get(lo, hi, i0), y = lds_get(lo, hi, i1);
-            if (pos) y = Fr::mul(y, load_u256(stage_tw, (size_t)pos << (r - 1 - s)));
+            if (pos) y = Fr::mul(y, tw_at((size_t)pos << (r - 1 - s)));
             lds_put(lo, hi, i0, Fr::add(x, y));
             lds_put(lo, hi, i1, Fr::sub(x, y));
         }
@@ -167,6 +170,8 @@ ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
     const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
     uint4* lo = smem;
     uint4* hi = smem + tile;
+    uint4* twl = smem + 2 * tile;                                   // R/2 stage twiddles, 2 x uint4 each
+    for (uint32_t e = threadIdx.x; e < R; e += blockDim.x) twl[e] = reinterpret_cast<const uint4*>(a.stage_tw)[e];
     const uint32_t cols_log = a.blk_log - a.r;
     const uint32_t tiles_per_blk_log = cols_log - a.c_log;
     const uint32_t t = blockIdx.x;
@@ -179,7 +184,7 @@ ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
         lds_put(lo, hi, bitrev(row, a.r) * C + col, ntt_load_input(a, idx));
     }
     __syncthreads();
-    if (a.debug_mode != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw, a.quarter_input != 0);
+    if (a.debug_mode != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, twl, a.quarter_input != 0);
     const uint32_t sh = a.log_n - a.blk_log;
     const uint32_t lomask = (1u << a.lo_bits) - 1;
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
@@ -208,6 +213,8 @@ ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
     const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
     uint4* lo = smem;
     uint4* hi = smem + tile;
+    uint4* twl = smem + 2 * tile;
+    for (uint32_t e = threadIdx.x; e < R; e += blockDim.x) twl[e] = reinterpret_cast<const uint4*>(a.stage_tw)[e];
     const uint32_t t = blockIdx.x;
     const uint32_t jm = t & ((1u << a.p_log) - 1);
     const uint32_t j10 = (t >> a.p_log) << a.c_log;
@@ -217,7 +224,7 @@ ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
         lds_put(lo, hi, bitrev(row, a.r) * C + col, ntt_load_input(a, (o << a.r) + row));
     }
     __syncthreads();
-    if (a.debug_mode != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, a.stage_tw, a.quarter_input != 0);
+    if (a.debug_mode != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, twl, a.quarter_input != 0);
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
         const uint32_t col = e & (C - 1), row = e >> a.c_log;
         const size_t out_idx = (size_t)(j10 + col) + (((size_t)jm + ((size_t)row << a.p_log)) << a.q_log);
@@ -431,7 +438,7 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             const uint32_t cols_log = blk_log - a.r;
             a.c_log = room < cols_log ? room : cols_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
-            const size_t lds = ((size_t)32 << (a.r + a.c_log));
+            const size_t lds = ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
             ZK_LAUNCH(ntt_strided_pass_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();
         } else {
@@ -440,7 +447,7 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             a.p_log = P == 3 ? ts->radix_log[1] : 0;
             a.c_log = room < a.q_log ? room : a.q_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
-            const size_t lds = ((size_t)32 << (a.r + a.c_log));
+            const size_t lds = ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
             ZK_LAUNCH(ntt_final_pass_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();
             if (via_tmp)

@@ -740,6 +740,12 @@ def main(argv=None):
         extra["single_proof"]["kernel_ms"] = {lab: round(v[0], 3) for lab, v in alone.items() if v[0] is not None}
         if alone["msm_accumulate"][0]:
             extra["single_proof"]["int_alu_frac_alone"] = round(pairs_alone / (alone["msm_accumulate"][0] * 1e-3) / XYZZ_MADD_PEAK, 4)
+            # the same roofline with the kernel alone on the GPU: in the timed region three proofs share the chip, so an event pair around a launch also
+            # spans cycles given to other streams' kernels (rocprofv3 sees the same stretched durations)
+            a_ms, a_n = alone["msm_accumulate"]
+            ach = 96.0 * wl.n * wl.n_msm / (a_ms * 1e-3) / 1e9
+            roofline["alone"] = {"avg_launch_ms": round(a_ms / max(a_n, 1), 4), "launches": a_n, "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5),
+                                 "what": "one proof with the GPU to itself (extra.single_proof): the kernel's own duration"}
     cfg = {"k": args.k, "ek": wl.ek, "A": wl.A, "F": wl.F, "L": wl.L, "n_perm": wl.n_perm, "d": wl.d,
            "n_msm": wl.n_msm, "n_intt": wl.n_intt, "n_ext": wl.n_ext}
     cpu = None

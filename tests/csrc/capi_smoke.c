@@ -29,7 +29,7 @@ int main(void) {
     CK(zk_dev_upload(ctx, d_ks, ks, sizeof ks));
     CK(zk_g1_fixed_base_mul_dev(ctx, d_ks, N, d_pts));
     uint64_t bases; CK(zk_bases_register_dev(ctx, d_pts, N, &bases));
-    uint64_t single[3][12], batch[3][12];
+    uint64_t single[3][12], batch[3][12], out_again[12];
     const void* cols[3] = { scal[0], scal[1], scal[2] };
     for (int c = 0; c < 3; c++) CK(zk_msm(ctx, bases, scal[c], N, single[c]));
     CK(zk_msm_batch(ctx, bases, cols, 3, N, batch));
@@ -47,6 +47,27 @@ int main(void) {
     CK(zk_coeff_to_lagrange_dev(ctx, d_b, 12));     /* NTT back: must reproduce a */
     CK(zk_dev_download(ctx, na, d_b, sizeof na));
     if (memcmp(na, a, sizeof a)) { fprintf(stderr, "lagrange_to_coeff / coeff_to_lagrange round trip failed\n"); return 1; }
+
+    /* the witness hop: page-locked staging memory, one batched upload, and a second context sharing the first one's expanded table */
+    {
+        void* pin = NULL; void* d_col[2];
+        CK(zk_host_alloc(ctx, 2 * sizeof scal[0], &pin));
+        memcpy(pin, scal[1], sizeof scal[1]); memcpy((char*)pin + sizeof scal[1], scal[2], sizeof scal[2]);
+        CK(zk_dev_alloc(ctx, sizeof scal[1], &d_col[0])); CK(zk_dev_alloc(ctx, sizeof scal[2], &d_col[1]));
+        const void* hosts[2] = { pin, (char*)pin + sizeof scal[1] };
+        CK(zk_dev_upload_batch(ctx, d_col, hosts, 2, sizeof scal[1]));
+        zk_ctx* ctx2 = NULL;
+        if (zk_ctx_create(0, &ctx2)) { fprintf(stderr, "second context failed\n"); return 1; }
+        uint64_t shared_h, dev_out[2][12];
+        if (zk_bases_share(ctx2, ctx, bases, &shared_h)) { fprintf(stderr, "zk_bases_share: %s\n", zk_last_error(ctx2)); return 1; }
+        if (zk_msm_batch_dev(ctx2, shared_h, (const void* const*)d_col, 2, N, dev_out)) { fprintf(stderr, "msm on the shared table: %s\n", zk_last_error(ctx2)); return 1; }
+        if (memcmp(dev_out[0], single[1], 96) || memcmp(dev_out[1], single[2], 96)) { fprintf(stderr, "shared-table / uploaded-column MSM differs from zk_msm\n"); return 1; }
+        if (zk_bases_release(ctx2, shared_h)) return 1;
+        zk_ctx_destroy(ctx2);
+        CK(zk_msm(ctx, bases, scal[0], N, out_again));            /* the owner's table survives the borrower */
+        if (memcmp(out_again, single[0], 96)) { fprintf(stderr, "table damaged after the borrower left\n"); return 1; }
+        CK(zk_dev_free(ctx, d_col[0])); CK(zk_dev_free(ctx, d_col[1])); CK(zk_host_free(ctx, pin));
+    }
 
     /* error path: unknown handle must fail cleanly with a message */
     uint64_t out[12];

@@ -94,6 +94,7 @@ struct zk_ctx {
     std::map<uint64_t, zk::BaseTable> bases;
     std::vector<zk::TwiddleSet> twiddles;
     std::map<uint64_t, zk::QuotProgram*> programs;
+    std::map<uint64_t, std::vector<uint32_t>> lookup_tie_hint;   // lookupperm.hip: columns whose rows tied on the sort window in the previous call of the same shape
     // workspaces (grow-only)
     zk::DevBuf ws_scalars, ws_sorted, ws_mid, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts;
     // last-call kernel timing (ms), filled when timing is enabled

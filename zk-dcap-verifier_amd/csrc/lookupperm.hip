@@ -681,101 +681,129 @@ int lookup_permute_batch(zk_ctx* ctx, const void* const* d_inputs, const void* c
         max_bits = std::max(max_bits, std::min(nbits, 64u));
     }
     ZK_HIP(hipMemcpyAsync(base + o_sh, shifts.data(), (size_t)C * 4, hipMemcpyHostToDevice, st));
-    ZK_LAUNCH(lpb_keys_kernel, dim3((u + 255) / 256, C), 256, 0, st, a);
-    ZK_CHECK_LAUNCH();
-    const uint32_t passes = (max_bits + 7) / 8;
-    uint2 *kin = a.key_a, *kout = a.key_b;
-    uint32_t *iin = a.idx_a, *iout = a.idx_b;
-    for (uint32_t p = 0; p < passes; p++) {
-        ZK_LAUNCH(lpb_hist_kernel, dim3(nwg, C), FS_T, 0, st, (const uint2*)kin, u, p, a.ghist, nwg);
-        ZK_CHECK_LAUNCH();
-        ZK_LAUNCH(lpb_offsets_kernel, C, 256, 0, st, a.ghist, nwg);
-        ZK_CHECK_LAUNCH();
-        ZK_LAUNCH(lpb_scatter_kernel, dim3(nwg, C), FS_T, 0, st, (const uint2*)kin, (const uint32_t*)iin, kout, iout, u, p, (const uint32_t*)a.ghist, nwg);
-        ZK_CHECK_LAUNCH();
-        std::swap(kin, kout);
-        std::swap(iin, iout);
+    uint32_t* sorted = a.idx_a;                                         // [C][u]: the sorted order of every column ends up here
+    const bool use_order_check = any_shift;
+
+    // LSD radix sort of a COMPACT list of columns over a sequence of 64-bit windows ("stages", low to high): stage_shift[t][f] is the bit position of
+    // column fcols[f]'s window in stage t (255 = constant key: nothing to sort there), stage_bits[t] the widest window of the stage.  Results go to
+    // sorted[fcols[f]].  Workspace: ws_mid.
+    auto compact_sort = [&](const std::vector<uint32_t>& fcols, const std::vector<std::vector<uint32_t>>& stage_shift, const std::vector<uint32_t>& stage_bits) -> int {
+        const uint32_t Fn = (uint32_t)fcols.size();
+        if (!Fn) return ZK_OK;
+        const size_t per = (size_t)Fn * u;
+        size_t o2 = 0;
+        auto take2 = [&](size_t bytes) { size_t o = o2; o2 += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t q_ka = take2(per * 8), q_kb = take2(per * 8), q_ia = take2(per * 4), q_ib = take2(per * 4), q_gh = take2((size_t)Fn * nwg * 256 * 4),
+                     q_fc = take2((size_t)Fn * 4), q_fs = take2((size_t)Fn * 4 * stage_shift.size());
+        ZK_HIP(ctx->ws_mid.ensure(o2 + 256));
+        char* b2 = (char*)ctx->ws_mid.p;
+        uint2 *rk_in = (uint2*)(b2 + q_ka), *rk_out = (uint2*)(b2 + q_kb);
+        uint32_t *ri_in = (uint32_t*)(b2 + q_ia), *ri_out = (uint32_t*)(b2 + q_ib), *rgh = (uint32_t*)(b2 + q_gh);
+        ZK_HIP(hipMemcpyAsync(b2 + q_fc, fcols.data(), (size_t)Fn * 4, hipMemcpyHostToDevice, st));
+        for (size_t t = 0; t < stage_shift.size(); t++)
+            ZK_HIP(hipMemcpyAsync(b2 + q_fs + t * Fn * 4, stage_shift[t].data(), (size_t)Fn * 4, hipMemcpyHostToDevice, st));
+        const uint32_t* order = nullptr;                                   // previous stage's order (compact); identity before the first
+        for (size_t t = 0; t < stage_shift.size(); t++) {
+            ZK_LAUNCH(lpb_rekey_kernel, dim3(g, Fn), blk, 0, st, a, (const uint32_t*)(b2 + q_fc), (const uint32_t*)(b2 + q_fs + t * Fn * 4), order, rk_in, ri_in);
+            ZK_CHECK_LAUNCH();
+            const uint32_t ps = (stage_bits[t] + 7) / 8;
+            for (uint32_t p = 0; p < ps; p++) {
+                ZK_LAUNCH(lpb_hist_kernel, dim3(nwg, Fn), FS_T, 0, st, (const uint2*)rk_in, u, p, rgh, nwg);
+                ZK_CHECK_LAUNCH();
+                ZK_LAUNCH(lpb_offsets_kernel, Fn, 256, 0, st, rgh, nwg);
+                ZK_CHECK_LAUNCH();
+                ZK_LAUNCH(lpb_scatter_kernel, dim3(nwg, Fn), FS_T, 0, st, (const uint2*)rk_in, (const uint32_t*)ri_in, rk_out, ri_out, u, p, (const uint32_t*)rgh, nwg);
+                ZK_CHECK_LAUNCH();
+                std::swap(rk_in, rk_out);
+                std::swap(ri_in, ri_out);
+            }
+            // the next rekey reads the order from the buffers just written and writes keys / order into the OTHER pair
+            std::swap(rk_in, rk_out);
+            std::swap(ri_in, ri_out);
+            order = ri_out;
+        }
+        for (uint32_t f = 0; f < Fn; f++)
+            ZK_HIP(hipMemcpyAsync(sorted + (size_t)fcols[f] * u, order + (size_t)f * u, (size_t)u * 4, hipMemcpyDeviceToDevice, st));
+        return ZK_OK;
+    };
+    // stages of a column whose window-tied rows differ inside bits [lo, hi]: 64-bit windows covering that range, low to high
+    auto low_stages = [&](const std::vector<uint32_t>& fcols, const std::vector<uint32_t>& lo_bit, const std::vector<uint32_t>& hi_bit,
+                          std::vector<std::vector<uint32_t>>& stage_shift, std::vector<uint32_t>& stage_bits) {
+        const uint32_t Fn = (uint32_t)fcols.size();
+        uint32_t n_low = 0;
+        for (uint32_t f = 0; f < Fn; f++) if (lo_bit[f] < 256) n_low = std::max(n_low, (hi_bit[f] - lo_bit[f]) / 64 + 1);
+        for (uint32_t t = 0; t < n_low; t++) {
+            std::vector<uint32_t> sh(Fn);
+            uint32_t bits = 1;
+            for (uint32_t f = 0; f < Fn; f++) {
+                const uint32_t st_lo = lo_bit[f] == 256 ? 256 : lo_bit[f] + 64 * t;
+                if (st_lo > hi_bit[f] || st_lo >= 256) { sh[f] = 255; continue; }               // bit 255 of a canonical value is always 0: constant key
+                sh[f] = st_lo;
+                bits = std::max(bits, std::min(64u, hi_bit[f] - st_lo + 1));
+            }
+            stage_shift.push_back(sh); stage_bits.push_back(bits);
+        }
+        std::vector<uint32_t> sh(Fn);
+        for (uint32_t f = 0; f < Fn; f++) sh[f] = shifts[fcols[f]];
+        stage_shift.push_back(sh); stage_bits.push_back(max_bits);
+    };
+    // tie mask of the flagged columns (cscal[c][8] != 0) in the current order -> (lo, hi) differing bit per column of `cols`
+    auto tie_ranges = [&](const std::vector<uint32_t>& cols_, std::vector<uint32_t>& lo_bit, std::vector<uint32_t>& hi_bit) -> int {
+        for (uint32_t c : cols_) ZK_HIP(hipMemsetAsync((char*)a.cscal + (size_t)c * 64, 0, 32, st));
+        ZK_LAUNCH(lpb_tiemask_kernel, dim3(g, C), blk, 0, st, a, (const uint32_t*)sorted); ZK_CHECK_LAUNCH();
+        ZK_HIP(hipMemcpyAsync(csc.data(), a.cscal, (size_t)C * 64, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+        lo_bit.assign(cols_.size(), 256); hi_bit.assign(cols_.size(), 0);
+        for (size_t f = 0; f < cols_.size(); f++) {
+            const uint32_t* m = &csc[(size_t)cols_[f] * 16];
+            for (uint32_t b = 0; b < 256; b++) if ((m[b >> 5] >> (b & 31)) & 1) { if (lo_bit[f] == 256) lo_bit[f] = b; hi_bit[f] = b; }
+        }
+        return ZK_OK;
+    };
+
+    // Columns that tied on their window in the PREVIOUS call of the same shape (same proving key: the tie structure of a lookup comes from its expressions,
+    // e.g. theta-compressed tuples that differ in their last expression) go straight to the two-stage sort; the order check below still guards them.
+    const uint64_t hint_key = ((uint64_t)count << 40) ^ ((uint64_t)C << 20) ^ k;
+    std::vector<uint32_t>& hint = ctx->lookup_tie_hint[hint_key];         // per column: 0 = none, else 1 + highest differing bit seen
+    if (hint.size() != C) hint.assign(C, 0);
+    std::vector<uint32_t> plain, hinted;
+    for (uint32_t c = 0; c < C; c++) (hint[c] && shifts[c] && !ctx->tune.lookup_force_generic_sort ? hinted : plain).push_back(c);
+    {
+        std::vector<std::vector<uint32_t>> ss(1, std::vector<uint32_t>(plain.size()));
+        for (size_t f = 0; f < plain.size(); f++) ss[0][f] = shifts[plain[f]];
+        int rc = compact_sort(plain, ss, {max_bits});
+        if (rc) return rc;
     }
-    uint32_t* sorted = iin;
-    if (any_shift) {
+    if (!hinted.empty()) {
+        std::vector<uint32_t> lo_bit(hinted.size(), 0), hi_bit(hinted.size());
+        for (size_t f = 0; f < hinted.size(); f++) hi_bit[f] = std::min(shifts[hinted[f]] - 1, hint[hinted[f]] - 1 + 16);   // what was seen, plus room for longer carries
+        std::vector<std::vector<uint32_t>> ss; std::vector<uint32_t> sb;
+        low_stages(hinted, lo_bit, hi_bit, ss, sb);
+        int rc = compact_sort(hinted, ss, sb);
+        if (rc) return rc;
+        ctx->last_ms["lookup_hinted_sorts"] += (double)hinted.size();
+    }
+    if (use_order_check) {
         ZK_LAUNCH(lpb_check_kernel, dim3(g, C), blk, 0, st, a, (const uint32_t*)sorted); ZK_CHECK_LAUNCH();
         ZK_HIP(hipMemcpyAsync(csc.data(), a.cscal, (size_t)C * 64, hipMemcpyDeviceToHost, st));
         ZK_HIP(hipStreamSynchronize(st));
         std::vector<uint32_t> fcols;
         for (uint32_t c = 0; c < C; c++) if (csc[(size_t)c * 16 + 8]) fcols.push_back(c);
         if (!fcols.empty() && !ctx->tune.lookup_force_generic_sort) {
-            // window ties: which bits do tied rows differ in?
-            for (uint32_t c : fcols) ZK_HIP(hipMemsetAsync((char*)a.cscal + (size_t)c * 64, 0, 32, st));
-            ZK_LAUNCH(lpb_tiemask_kernel, dim3(g, C), blk, 0, st, a, (const uint32_t*)sorted); ZK_CHECK_LAUNCH();
-            ZK_HIP(hipMemcpyAsync(csc.data(), a.cscal, (size_t)C * 64, hipMemcpyDeviceToHost, st));
-            ZK_HIP(hipStreamSynchronize(st));
-            const uint32_t Fn = (uint32_t)fcols.size();
-            // stages per column: 64-bit windows covering [lowest, highest] differing bit, low to high, then the top window again
-            std::vector<std::vector<uint32_t>> stage_shift;                 // [stage][f]; 0xffffffff = nothing to sort in this stage (constant key)
-            std::vector<uint32_t> stage_bits;
-            uint32_t n_low = 0;
-            std::vector<uint32_t> lo_bit(Fn), hi_bit(Fn);
-            for (uint32_t f = 0; f < Fn; f++) {
-                const uint32_t* m = &csc[(size_t)fcols[f] * 16];
-                uint32_t lo = 256, hi = 0;
-                for (uint32_t b = 0; b < 256; b++) if ((m[b >> 5] >> (b & 31)) & 1) { if (lo == 256) lo = b; hi = b; }
-                lo_bit[f] = lo; hi_bit[f] = hi;
-                if (lo < 256) n_low = std::max(n_low, (hi - lo) / 64 + 1);
-            }
-            for (uint32_t t = 0; t < n_low; t++) {
-                std::vector<uint32_t> sh(Fn);
-                uint32_t bits = 1;
-                for (uint32_t f = 0; f < Fn; f++) {
-                    const uint32_t st_lo = lo_bit[f] == 256 ? 256 : lo_bit[f] + 64 * t;
-                    if (st_lo > hi_bit[f] || st_lo >= 256) { sh[f] = 255; continue; }           // bit 255 of a canonical value is always 0: constant key
-                    sh[f] = st_lo;
-                    bits = std::max(bits, std::min(64u, hi_bit[f] - st_lo + 1));
-                }
-                stage_shift.push_back(sh); stage_bits.push_back(bits);
-            }
-            {
-                std::vector<uint32_t> sh(Fn);
-                for (uint32_t f = 0; f < Fn; f++) sh[f] = shifts[fcols[f]];
-                stage_shift.push_back(sh); stage_bits.push_back(max_bits);
-            }
-            const size_t per = (size_t)Fn * u;
-            size_t o2 = 0;
-            auto take2 = [&](size_t bytes) { size_t o = o2; o2 += (bytes + 255) & ~(size_t)255; return o; };
-            const size_t q_ka = take2(per * 8), q_kb = take2(per * 8), q_ia = take2(per * 4), q_ib = take2(per * 4), q_gh = take2((size_t)Fn * nwg * 256 * 4),
-                         q_fc = take2((size_t)Fn * 4), q_fs = take2((size_t)Fn * 4 * stage_shift.size());
-            ZK_HIP(ctx->ws_mid.ensure(o2 + 256));
-            char* b2 = (char*)ctx->ws_mid.p;
-            uint2 *rk_in = (uint2*)(b2 + q_ka), *rk_out = (uint2*)(b2 + q_kb);
-            uint32_t *ri_in = (uint32_t*)(b2 + q_ia), *ri_out = (uint32_t*)(b2 + q_ib), *rgh = (uint32_t*)(b2 + q_gh);
-            ZK_HIP(hipMemcpyAsync(b2 + q_fc, fcols.data(), (size_t)Fn * 4, hipMemcpyHostToDevice, st));
-            for (size_t t = 0; t < stage_shift.size(); t++)
-                ZK_HIP(hipMemcpyAsync(b2 + q_fs + t * Fn * 4, stage_shift[t].data(), (size_t)Fn * 4, hipMemcpyHostToDevice, st));
-            const uint32_t* order = nullptr;                                   // previous stage's order (compact); identity before the first
-            for (size_t t = 0; t < stage_shift.size(); t++) {
-                ZK_LAUNCH(lpb_rekey_kernel, dim3(g, Fn), blk, 0, st, a, (const uint32_t*)(b2 + q_fc), (const uint32_t*)(b2 + q_fs + t * Fn * 4), order, rk_in, ri_in);
-                ZK_CHECK_LAUNCH();
-                const uint32_t ps = (stage_bits[t] + 7) / 8;
-                for (uint32_t p = 0; p < ps; p++) {
-                    ZK_LAUNCH(lpb_hist_kernel, dim3(nwg, Fn), FS_T, 0, st, (const uint2*)rk_in, u, p, rgh, nwg);
-                    ZK_CHECK_LAUNCH();
-                    ZK_LAUNCH(lpb_offsets_kernel, Fn, 256, 0, st, rgh, nwg);
-                    ZK_CHECK_LAUNCH();
-                    ZK_LAUNCH(lpb_scatter_kernel, dim3(nwg, Fn), FS_T, 0, st, (const uint2*)rk_in, (const uint32_t*)ri_in, rk_out, ri_out, u, p, (const uint32_t*)rgh, nwg);
-                    ZK_CHECK_LAUNCH();
-                    std::swap(rk_in, rk_out);
-                    std::swap(ri_in, ri_out);
-                }
-                // the next rekey reads the order from ri_in and writes keys / order into the OTHER buffers
-                std::swap(rk_in, rk_out);
-                std::swap(ri_in, ri_out);
-                order = ri_out;
-            }
-            for (uint32_t f = 0; f < Fn; f++) {
-                ZK_HIP(hipMemcpyAsync(sorted + (size_t)fcols[f] * u, order + (size_t)f * u, (size_t)u * 4, hipMemcpyDeviceToDevice, st));
+            // window ties (first seen, or a hinted column whose ties reached above the hinted range): which bits do tied rows differ in?
+            std::vector<uint32_t> lo_bit, hi_bit;
+            int rc = tie_ranges(fcols, lo_bit, hi_bit);
+            if (rc) return rc;
+            std::vector<std::vector<uint32_t>> ss; std::vector<uint32_t> sb;
+            low_stages(fcols, lo_bit, hi_bit, ss, sb);
+            rc = compact_sort(fcols, ss, sb);
+            if (rc) return rc;
+            for (size_t f = 0; f < fcols.size(); f++) {
+                hint[fcols[f]] = hi_bit[f] + 1;
                 ZK_HIP(hipMemsetAsync((char*)a.cscal + (size_t)fcols[f] * 64 + 32, 0, 4, st));     // clear the violation count, then check again
             }
             ZK_LAUNCH(lpb_check_kernel, dim3(g, C), blk, 0, st, a, (const uint32_t*)sorted); ZK_CHECK_LAUNCH();
-            ctx->last_ms["lookup_refined_sorts"] += (double)Fn;
+            ctx->last_ms["lookup_refined_sorts"] += (double)fcols.size();
         }
     }
     ZK_LAUNCH(lpb_fill_unconsumed_kernel, dim3(g, (uint32_t)count), blk, 0, st, a);

@@ -81,6 +81,12 @@ int zk_dev_upload_batch(zk_ctx* ctx, void* const* dptrs_dev, const void* const* 
 int zk_bases_register(zk_ctx* ctx, const void* g1_affine_host, size_t n, uint64_t* handle);
 int zk_bases_register_dev(zk_ctx* ctx, const void* g1_affine_dev, size_t n, uint64_t* handle);
 int zk_bases_release(zk_ctx* ctx, uint64_t handle);
+/* Optional second table for a registered base set: the window expansion of the prefix sums S_i = P_0 + ... + P_i (same size as the first).  With it,
+ * zk_msm* commit a column whose neighbouring scalars are mostly EQUAL — the sorted permuted-input columns of halo2's lookup argument
+ * (plonk/lookup/prover.rs permute_expression_pair), constant columns — through sum_i (a_i - a_(i+1)) S_i: zero differences cost nothing, so the work is that of
+ * the column's run boundaries.  Chosen per column from a count of non-zero scalars vs non-zero differences; results are the same group elements.
+ * One-time cost of a registration; shared by zk_bases_share. */
+int zk_bases_enable_runs(zk_ctx* ctx, uint64_t handle);
 /* Several contexts on one GPU (one per host thread that proves concurrently) use ONE expanded table: `ctx` receives a handle of its own onto the table
  * `owner_handle` of `owner` (same device); the HBM copy is freed when the last handle is released / the last holding context destroyed. */
 int zk_bases_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_handle, uint64_t* handle);

@@ -130,3 +130,46 @@ def test_shared_base_table_across_contexts(built, orc, pyref):
     lent.release()
     a.close()
     b.close()
+
+
+def _check_run_length_msm(be, orc, pyref, n, seed=3):
+    """zk_bases_enable_runs: columns made of long runs of equal values (a sorted lookup column, a constant column, a column with a few distinct
+    full-width values) are committed through their adjacent differences against the prefix-sum table — same points as the oracle's best_multiexp,
+    also for a prefix of the table and next to ordinary columns in the same batch"""
+    import random
+    import numpy as np
+    import zk_dcap_verifier_amd as z
+    import parity_cases as pc
+    rnd = random.Random(seed)
+    _, bases = pc.msm_inputs(orc, pyref, n, seed)
+    bases[5] = 0                                                    # an identity base inside a run
+    h = z.arithmetic.BasesHandle(be, bases).enable_runs()
+    R = pyref.R
+    big = [rnd.randrange(R) for _ in range(8)]
+    sorted_col = sorted(rnd.choice(big) for _ in range(n))                            # sorted lookup input: 8 runs
+    const_col = [big[0]] * (n - 3) + [rnd.randrange(R) for _ in range(3)]             # constant + blinding-like tail
+    steps = [big[(i * 7 // n) % 8] if i % 97 else 0 for i in range(n)]                # runs broken by zeros
+    rand_col = [rnd.randrange(R) for _ in range(n)]                                   # no runs: stays on the direct path
+    cols = [orc.fr_from_ints(c) for c in (sorted_col, const_col, steps, rand_col)]
+    be.timing(True)
+    be.tune(msm_runs=2)                                              # (below ~4 M saved additions the default keeps small batches on the direct path)
+    got = z.arithmetic.best_multiexp_batch(cols, h)
+    for i, c in enumerate(cols):
+        want = orc.g1_to_affine(orc.best_multiexp(c, bases))[0]
+        assert (got[i, :8] == want).all(), i
+    assert be.stat_get("msm_run_columns") >= 2
+    m = n - n // 3                                                   # commit() of a shorter polynomial: prefix of the table
+    got = z.arithmetic.best_multiexp(cols[1][:m], h)
+    assert (got[:8] == orc.g1_to_affine(orc.best_multiexp(cols[1][:m], bases[:m]))[0]).all()
+    be.tune(msm_runs=0)                                              # the switch: everything direct, same answers
+    try:
+        got2 = z.arithmetic.best_multiexp_batch(cols, h)
+        assert (got2 == z.arithmetic.best_multiexp_batch(cols, h)).all() and (got2[0, :8] == orc.g1_to_affine(orc.best_multiexp(cols[0], bases))[0]).all()
+    finally:
+        be.tune(msm_runs=1)
+        be.timing(False)
+    h.release()
+
+
+def test_emulated_run_length_msm(emu, orc, pyref):
+    _check_run_length_msm(emu, orc, pyref, 2500)

@@ -185,3 +185,8 @@ def test_msm_linearity_and_ntt_roundtrip_at_bench_sizes(gpu, orc, pyref):
     idx = np.random.default_rng(5).integers(0, nn, size=4096)
     assert (back[idx] == orc.fr_mul(a[idx], np.repeat(orc.fr_from_ints([nn]), idx.size, axis=0))).all()
     d.free()
+
+
+def test_run_length_msm_gpu(gpu, orc, pyref):
+    from test_emu_kernels import _check_run_length_msm
+    _check_run_length_msm(gpu, orc, pyref, 40000)

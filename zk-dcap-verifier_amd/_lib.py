@@ -225,6 +225,10 @@ class Backend:
         self._ck(self.lib.zk_bases_share(self.ctx, owner.ctx, C.c_uint64(owner_handle), C.byref(h)))
         return h.value
 
+    def bases_enable_runs(self, handle: int):
+        """build the prefix-sum twin of a registered table (zk_bases_enable_runs): run-heavy columns are then committed through their adjacent differences"""
+        self._ck(self.lib.zk_bases_enable_runs(self.ctx, C.c_uint64(handle)))
+
     def bases_release(self, handle: int):
         self._ck(self.lib.zk_bases_release(self.ctx, C.c_uint64(handle)))
 

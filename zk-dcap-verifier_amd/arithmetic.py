@@ -33,6 +33,10 @@ class BasesHandle:
         self.handle = backend.bases_share(owner.backend, owner.handle)
         return self
 
+    def enable_runs(self):
+        self.backend.bases_enable_runs(self.handle)
+        return self
+
     def release(self):
         if self.handle:
             self.backend.bases_release(self.handle)

@@ -93,7 +93,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
         release_programs(ctx);
         release_gtab(ctx);
         zk::DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_sorted, &ctx->ws_mid, &ctx->ws_small, &ctx->ws_sub0, &ctx->ws_sub1, &ctx->ws_cls0,
-                              &ctx->ws_cls1, &ctx->ws_tmp, &ctx->ws_ntt, &ctx->ws_ntt_in, &ctx->ws_pts};
+                              &ctx->ws_cls1, &ctx->ws_tmp, &ctx->ws_ntt, &ctx->ws_ntt_in, &ctx->ws_pts, &ctx->ws_runs};
         for (auto* b : bufs) b->release();
         (void)hipStreamDestroy(ctx->stream);
     }
@@ -107,7 +107,7 @@ static int* tune_slot(zk_ctx* ctx, const char* key) {
     struct { const char* k; int* v; } tab[] = {
         {"msm_c", &t.msm_c}, {"msm_sort_wgs", &t.msm_sort_wgs}, {"msm_sort_threads", &t.msm_sort_threads}, {"msm_sort_batch_wgs", &t.msm_sort_batch_wgs}, {"msm_bsort_threads", &t.msm_bsort_threads}, {"msm_two_level_sort", &t.msm_two_level_sort},
         {"msm_target_threads", &t.msm_target_threads}, {"msm_min_chunk", &t.msm_min_chunk}, {"msm_max_chunk", &t.msm_max_chunk},
-        {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block},
+        {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block}, {"msm_runs", &t.msm_runs},
         {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log},
         {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}, {"lookup_force_generic_sort", &t.lookup_force_generic_sort},
         {"ntt_quarter_input", &t.ntt_quarter_input}, {"ntt_debug_mode", &t.ntt_debug_mode}, {"quot_rows", &t.quot_rows}, {"quot_remat_ops", &t.quot_remat_ops}, {"quot_remat_distance", &t.quot_remat_distance}};
@@ -173,6 +173,7 @@ int zk_dev_upload_batch(zk_ctx* ctx, void* const* dptrs, const void* const* host
 int zk_bases_register(zk_ctx* ctx, const void* p, size_t n, uint64_t* h) { ENTER; return msm_register(ctx, p, n, false, h); }
 int zk_bases_register_dev(zk_ctx* ctx, const void* p, size_t n, uint64_t* h) { ENTER; return msm_register(ctx, p, n, true, h); }
 int zk_bases_release(zk_ctx* ctx, uint64_t h) { ENTER; return msm_release(ctx, h); }
+int zk_bases_enable_runs(zk_ctx* ctx, uint64_t h) { ENTER; return msm_enable_runs(ctx, h); }
 int zk_bases_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_handle, uint64_t* h) {
     if (!ctx || !owner || !h) return ZK_ERR_ARG;
     zk::BaseTable bt;

@@ -27,6 +27,7 @@ struct Tune {
     int msm_merge_fanin = 8;
     int msm_tree_fanin = 2;
     int msm_block = 128;         // threads per workgroup of the curve-arithmetic kernels
+    int msm_runs = 1;            // commit run-heavy columns through adjacent differences against the prefix-sum table (when the table has one)
     int ntt_tile_log = 10;       // log2(elements) of the LDS tile of one NTT workgroup (sweep: profiles/r01/run6_ntt_plan_sweep.txt)
     int ntt_threads = 256;
     int ntt_max_radix_log = 8;
@@ -66,6 +67,11 @@ struct BaseTable {
     size_t n = 0;
     int c = 0, W = 0;
     std::shared_ptr<TableMem> mem;
+    // optional (zk_bases_enable_runs): the same expansion of the PREFIX SUMS S_i = P_0 + ... + P_i.  sum_i a_i P_i = sum_i (a_i - a_(i+1)) S_i, and
+    // zero digits cost nothing, so a column with long runs of equal values (a sorted lookup column, a constant column) is committed through its
+    // adjacent differences at the cost of its run boundaries
+    void* d_runs_table = nullptr;
+    std::shared_ptr<TableMem> runs_mem;
 };
 
 struct TwiddleSet {           // per (omega, log_n)
@@ -96,7 +102,7 @@ struct zk_ctx {
     std::map<uint64_t, zk::QuotProgram*> programs;
     std::map<uint64_t, std::vector<uint32_t>> lookup_tie_hint;   // lookupperm.hip: columns whose rows tied on the sort window in the previous call of the same shape
     // workspaces (grow-only)
-    zk::DevBuf ws_scalars, ws_sorted, ws_mid, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts;
+    zk::DevBuf ws_scalars, ws_sorted, ws_mid, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts, ws_runs;
     // last-call kernel timing (ms), filled when timing is enabled
     bool timing = false;
     std::map<std::string, double> last_ms;
@@ -140,6 +146,7 @@ struct EvTimer {
 int msm_register(zk_ctx* ctx, const void* pts, size_t n, bool on_device, uint64_t* handle);
 int msm_release(zk_ctx* ctx, uint64_t handle);
 int msm_share(zk_ctx* dst, const BaseTable& bt, uint64_t* handle);
+int msm_enable_runs(zk_ctx* ctx, uint64_t handle);
 int msm_run(zk_ctx* ctx, uint64_t handle, const void* scalars, size_t n, bool on_device, void* out, int partial);
 int msm_run_batch(zk_ctx* ctx, uint64_t handle, const void* const* scalars, size_t nb, size_t n, bool on_device, void* out, int partial);
 int g1_sum_xyzz_host(const void* xyzz, size_t count, void* out_jac);

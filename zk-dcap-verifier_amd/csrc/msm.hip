@@ -779,6 +779,86 @@ int msm_share(zk_ctx* dst, const BaseTable& bt, uint64_t* handle) {
     return ZK_OK;
 }
 
+// ---- run-length path: prefix sums of the bases, adjacent differences of the scalars -------------------------------------------------------------
+// total of chunk t of the affine points (XYZZ), then — given the exclusive prefix of the chunk totals — the inclusive prefix sums inside the chunk
+ZK_KERNEL void g1_chunk_total_kernel(const void* aff, uint32_t n, uint32_t chunk, void* totals) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo = (uint64_t)t * chunk;
+    if (lo >= n) return;
+    const uint32_t hi = (uint32_t)std::min<uint64_t>(lo + chunk, n);
+    XYZZ acc = xyzz_identity();
+    for (uint32_t k = (uint32_t)lo; k < hi; k++) xyzz_madd_signed(acc, load_affine(aff, k), false);
+    store_xyzz(totals, t, acc);
+}
+ZK_KERNEL void g1_chunk_prefix_kernel(const void* aff, uint32_t n, uint32_t chunk, const void* excl, void* out_xyzz) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo = (uint64_t)t * chunk;
+    if (lo >= n) return;
+    const uint32_t hi = (uint32_t)std::min<uint64_t>(lo + chunk, n);
+    XYZZ acc = load_xyzz(excl, t);
+    for (uint32_t k = (uint32_t)lo; k < hi; k++) { xyzz_madd_signed(acc, load_affine(aff, k), false); store_xyzz(out_xyzz, k, acc); }
+}
+// counts[col] = {non-zero scalars, non-zero adjacent differences (a[i] != a[i+1], a[n] := 0)}
+ZK_KERNEL void msm_runs_probe_kernel(const void* const* cols, uint32_t n, uint32_t* counts) {
+    __shared__ uint32_t sh[2];
+    const uint32_t col = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x < 2) sh[threadIdx.x] = 0;
+    __syncthreads();
+    if (i < n) {
+        const u256 a = load_u256(cols[col], i);
+        const u256 b = i + 1 < n ? load_u256(cols[col], i + 1) : Fr::zero();
+        if (!Fr::is_zero(a)) atomicAdd(&sh[0], 1u);
+        if (!Fr::eq(a, b)) atomicAdd(&sh[1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && sh[threadIdx.x]) atomicAdd(&counts[2 * col + threadIdx.x], sh[threadIdx.x]);
+}
+ZK_KERNEL void fr_adjacent_diff_kernel(const void* const* cols, const uint32_t* which, uint32_t n, void* out) {
+    const uint32_t f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const void* col = cols[which[f]];
+    const u256 a = load_u256(col, i);
+    store_u256(out, (size_t)f * n + i, i + 1 < n ? Fr::sub(a, load_u256(col, i + 1)) : a);
+}
+
+int msm_enable_runs(zk_ctx* ctx, uint64_t handle) {
+    auto it = ctx->bases.find(handle);
+    if (it == ctx->bases.end()) return ctx->fail(ZK_ERR_ARG, "zk_bases_enable_runs: unknown handle %llu", (unsigned long long)handle);
+    BaseTable& bt = it->second;
+    if (bt.d_runs_table) return ZK_OK;
+    const size_t n = bt.n;
+    const uint32_t chunk = 64, m = (uint32_t)((n + chunk - 1) / chunk);
+    const int blk = ctx->tune.msm_block;
+    hipStream_t st = ctx->stream;
+    void *d_tot = nullptr, *d_pre = nullptr, *d_aff = nullptr;
+    auto cleanup = [&]() { if (d_tot) (void)hipFree(d_tot); if (d_pre) (void)hipFree(d_pre); if (d_aff) (void)hipFree(d_aff); };
+    hipError_t e = hipMalloc(&d_tot, (size_t)m * 128);
+    if (e == hipSuccess) e = hipMalloc(&d_pre, n * 128);
+    if (e == hipSuccess) e = hipMalloc(&d_aff, n * 64);
+    if (e != hipSuccess) { cleanup(); return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: device allocation failed"); }
+    ZK_LAUNCH(g1_chunk_total_kernel, (m + blk - 1) / blk, blk, 0, st, (const void*)bt.d_table, (uint32_t)n, chunk, d_tot);
+    std::vector<XYZZ> tot(m), excl(m);
+    if (hipMemcpyAsync(tot.data(), d_tot, (size_t)m * 128, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        cleanup(); return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: chunk totals");
+    }
+    XYZZ run = xyzz_identity();                                      // exclusive scan of the chunk totals on the host (one-time, n / 64 additions)
+    for (uint32_t t = 0; t < m; t++) { excl[t] = run; xyzz_add(run, tot[t]); }
+    if (hipMemcpyAsync(d_tot, excl.data(), (size_t)m * 128, hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: upload"); }
+    ZK_LAUNCH(g1_chunk_prefix_kernel, (m + blk - 1) / blk, blk, 0, st, (const void*)bt.d_table, (uint32_t)n, chunk, (const void*)d_tot, d_pre);
+    const uint32_t bchunk = 32;
+    ZK_LAUNCH(g1_batch_to_affine_kernel, (uint32_t)(((n + bchunk - 1) / bchunk + blk - 1) / blk), blk, 0, st, (const void*)d_pre, (uint32_t)n, bchunk, d_aff);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { cleanup(); return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: prefix kernels"); }
+    (void)hipFree(d_pre); d_pre = nullptr;
+    BaseTable ps;
+    ps.n = n; ps.c = bt.c; ps.W = bt.W;
+    int rc = build_table(ctx, d_aff, n, ps);
+    cleanup();
+    if (rc) return rc;
+    bt.d_runs_table = ps.d_table;
+    bt.runs_mem = ps.mem;
+    return ZK_OK;
+}
+
 int msm_release(zk_ctx* ctx, uint64_t handle) {
     auto it = ctx->bases.find(handle);
     if (it == ctx->bases.end()) return ctx->fail(ZK_ERR_ARG, "zk_bases_release: unknown handle %llu", (unsigned long long)handle);
@@ -981,8 +1061,57 @@ int msm_run_batch(zk_ctx* ctx, uint64_t handle, const void* const* scalars, size
                 ptrs[i] = d;
             }
         }
-        int rc = msm_core(ctx, bt, ptrs.data(), (uint32_t)nb, n, res.data());
-        if (rc) return rc;
+        // per column: directly, or — when the table has its prefix-sum twin and the column is mostly runs of equal values — through its adjacent differences
+        std::vector<uint32_t> direct, runs;
+        if (bt.d_runs_table && ctx->tune.msm_runs && n >= 1024) {
+            hipStream_t st = ctx->stream;
+            ZK_HIP(ctx->ws_runs.ensure(nb * (sizeof(void*) + 8 + 4) + 64));
+            const void** d_cols = (const void**)ctx->ws_runs.p;
+            uint32_t* d_counts = (uint32_t*)((char*)ctx->ws_runs.p + nb * sizeof(void*));
+            ZK_HIP(hipMemcpyAsync((void*)d_cols, ptrs.data(), nb * sizeof(void*), hipMemcpyHostToDevice, st));
+            ZK_HIP(hipMemsetAsync(d_counts, 0, nb * 8, st));
+            ZK_LAUNCH(msm_runs_probe_kernel, dim3((uint32_t)((n + 255) / 256), (uint32_t)nb), 256, 0, st, (const void* const*)d_cols, (uint32_t)n, d_counts);
+            ZK_CHECK_LAUNCH();
+            std::vector<uint32_t> counts(2 * nb);
+            ZK_HIP(hipMemcpyAsync(counts.data(), d_counts, nb * 8, hipMemcpyDeviceToHost, st));
+            ZK_HIP(hipStreamSynchronize(st));
+            for (uint32_t i = 0; i < nb; i++)       // worth it when the differences are clearly sparser than the column (the second batch has its own reduction tail)
+                ((uint64_t)counts[2 * i + 1] * 5 < (uint64_t)counts[2 * i] * 4 && (counts[2 * i] >= 4096 || ctx->tune.msm_runs >= 2) ? runs : direct).push_back(i);
+            uint64_t saved = 0;                        // point additions the run columns avoid; a second batch pays its own sort / reduction launches
+            for (uint32_t i : runs) saved += (uint64_t)(counts[2 * i] - counts[2 * i + 1]) * bt.W;
+            // (msm_runs = 2: take the run path whenever it is sparser, whatever the size — tests)
+            if (saved < (4u << 20) && ctx->tune.msm_runs < 2) { for (uint32_t i : runs) direct.push_back(i); runs.clear(); std::sort(direct.begin(), direct.end()); }
+        } else for (uint32_t i = 0; i < nb; i++) direct.push_back(i);
+        if (!direct.empty()) {
+            std::vector<const void*> sub(direct.size());
+            std::vector<XYZZ> r(direct.size());
+            for (size_t f = 0; f < direct.size(); f++) sub[f] = ptrs[direct[f]];
+            int rc = msm_core(ctx, bt, sub.data(), (uint32_t)direct.size(), n, r.data());
+            if (rc) return rc;
+            for (size_t f = 0; f < direct.size(); f++) res[direct[f]] = r[f];
+        }
+        if (!runs.empty()) {
+            hipStream_t st = ctx->stream;
+            const size_t Fn = runs.size();
+            const size_t head = (nb * (sizeof(void*) + 8) + Fn * 4 + 255) & ~(size_t)255;
+            ZK_HIP(ctx->ws_runs.ensure(head + Fn * n * 32 + 64));
+            const void** d_cols = (const void**)ctx->ws_runs.p;                       // (ensure may have moved the buffer: upload the pointers again)
+            uint32_t* d_which = (uint32_t*)((char*)ctx->ws_runs.p + nb * (sizeof(void*) + 8));
+            char* d_diff = (char*)ctx->ws_runs.p + head;
+            ZK_HIP(hipMemcpyAsync((void*)d_cols, ptrs.data(), nb * sizeof(void*), hipMemcpyHostToDevice, st));
+            ZK_HIP(hipMemcpyAsync(d_which, runs.data(), Fn * 4, hipMemcpyHostToDevice, st));
+            ZK_LAUNCH(fr_adjacent_diff_kernel, dim3((uint32_t)((n + 255) / 256), (uint32_t)Fn), 256, 0, st, (const void* const*)d_cols, (const uint32_t*)d_which, (uint32_t)n, (void*)d_diff);
+            ZK_CHECK_LAUNCH();
+            BaseTable ps = bt;
+            ps.d_table = bt.d_runs_table;
+            std::vector<const void*> sub(Fn);
+            std::vector<XYZZ> r(Fn);
+            for (size_t f = 0; f < Fn; f++) sub[f] = d_diff + f * n * 32;
+            int rc = msm_core(ctx, ps, sub.data(), (uint32_t)Fn, n, r.data());
+            if (rc) return rc;
+            for (size_t f = 0; f < Fn; f++) res[runs[f]] = r[f];
+            ctx->last_ms["msm_run_columns"] += (double)Fn;
+        }
     }
     if (partial) memcpy(out, res.data(), nb * 128);
     else if (nb == 1) xyzz_to_jacobian_host(res[0], out);

@@ -24,7 +24,7 @@ class ParamsKZG:
         assert g.shape[0] == self.n and g_lagrange.shape[0] == self.n
         self.g_host, self.g_lagrange_host = g, g_lagrange
         self.g = BasesHandle(self.backend, g)
-        self.g_lagrange = BasesHandle(self.backend, g_lagrange)
+        self.g_lagrange = BasesHandle(self.backend, g_lagrange).enable_runs()   # Lagrange columns have runs (sorted lookup inputs, constant regions): see zk_bases_enable_runs
 
     @classmethod
     def setup(cls, k: int, tau, backend: Backend | None = None) -> "ParamsKZG":
@@ -46,7 +46,7 @@ class ParamsKZG:
         self = cls.__new__(cls)
         self.backend, self.k, self.n = be, k, n
         self.g_host, self.g_lagrange_host = dg.download((n, 8)), dl.download((n, 8))
-        self.g, self.g_lagrange = BasesHandle(be, (dg, n)), BasesHandle(be, (dl, n))
+        self.g, self.g_lagrange = BasesHandle(be, (dg, n)), BasesHandle(be, (dl, n)).enable_runs()
         for d in (ds, dg, dl):
             d.free()
         return self
@@ -137,7 +137,7 @@ class ParamsKZG:
         self.coset_exchange = coset_exchange
         self.g_host, self.g_lagrange_host = g, g_lagrange
         self.g = BasesHandle(be, np.ascontiguousarray(g[self.lo:self.lo + self.n_loc]))
-        self.g_lagrange = BasesHandle(be, np.ascontiguousarray(g_lagrange[self.lo:self.lo + self.n_loc]))
+        self.g_lagrange = BasesHandle(be, np.ascontiguousarray(g_lagrange[self.lo:self.lo + self.n_loc])).enable_runs()
         return self
 
     def commit_columns(self, which: str, cols) -> np.ndarray:

@@ -537,7 +537,7 @@ def main(argv=None):
     ap.add_argument("--mode", choices=("prove", "opmix"), default="prove", help="prove: real create_proof over the sgx-shaped circuit (default); opmix: the hot-path call list over synthetic columns")
     ap.add_argument("--census", choices=("chip_estimate", "reference_exact"), default="chip_estimate",
                     help="which synthetic circuit `value` is measured on (tools/sgx_shaped_circuit.py); the other one is measured as extra.census_* unless --no-extras")
-    ap.add_argument("--inflight", type=int, default=3, help="proofs processed concurrently per step on one GPU (one context + HIP stream each)")
+    ap.add_argument("--inflight", type=int, default=4, help="proofs processed concurrently per step on one GPU (one context + HIP stream each)")
     ap.add_argument("--no-extras", action="store_true", help="skip the MSM 2^24 / NTT 2^22 microbenchmarks and the CPU baseline")
     args = ap.parse_args(argv)
 

@@ -43,6 +43,7 @@ extern "C" {
     fn zk_last_error(ctx: *mut ZkCtx) -> *const c_char;
     fn zk_bases_register(ctx: *mut ZkCtx, g1_affine: *const c_void, n: usize, handle: *mut u64) -> c_int;
     fn zk_bases_release(ctx: *mut ZkCtx, handle: u64) -> c_int;
+    fn zk_bases_enable_runs(ctx: *mut ZkCtx, handle: u64) -> c_int;
     fn zk_msm(ctx: *mut ZkCtx, bases: u64, scalars: *const c_void, n: usize, out_jac: *mut c_void) -> c_int;
     fn zk_msm_batch(ctx: *mut ZkCtx, bases: u64, scalars: *const *const c_void, count: usize, n: usize, out_jac: *mut c_void) -> c_int;
     fn zk_ntt(ctx: *mut ZkCtx, a: *mut c_void, log_n: u32, omega: *const c_void) -> c_int;
@@ -121,6 +122,11 @@ impl Gpu {
             self.complain("zk_bases_register");
             map.remove(&key);
             return None;
+        }
+        // prefix-sum twin of the table: columns with long runs of equal scalars (sorted lookup inputs, grand products over unused rows) are then committed at
+        // the cost of their run boundaries.  Doubles the table's HBM footprint; HALO2_MI355X_RUNS=0 skips it.  Failure is not an error (the direct path remains).
+        if std::env::var("HALO2_MI355X_RUNS").map(|v| v != "0").unwrap_or(true) {
+            unsafe { zk_bases_enable_runs(self.ctx, h) };
         }
         map.insert(key, Table { handle: h, len: bases.len() });
         Some(h)

@@ -92,6 +92,7 @@ struct MsmPlan {
     int c, W;
     const void* const* scalars;            // device array: nb column pointers
     const void* table;
+    const void* const* col_tables;         // device array of nb table pointers (run columns read the prefix-sum twin), or null: every column reads `table`
     uint32_t* small;                       // per column: hist[B] off[B+1] cursor[B] suboff[R+1][B+1] info[4]
     uint32_t small_stride, o_off, o_cursor, o_suboff, o_info, o_tiles, o_fulloff, o_remorder, o_remhist, o_remstart, o_remcursor;
     uint32_t* sorted;                      // per column: pairs_max references
@@ -514,14 +515,15 @@ ZK_KERNEL void msm_accumulate_kernel(MsmPlan p) {
     const uint32_t out = plan_suboff(p, col, 0)[b] + k;   // bucket-major slot of this partial sum, as the merge levels expect it
     XYZZ acc = xyzz_identity();
     uint32_t ref = sorted[q];
-    Affine pt = load_affine(p.table, ref & 0x7fffffffu);
+    const void* table = p.col_tables ? p.col_tables[col] : p.table;
+    Affine pt = load_affine(table, ref & 0x7fffffffu);
     while (true) {
         const uint32_t cur_ref = ref;
         const Affine cur = pt;
         ++q;
         if (q < end) {  // fetch the next point while the current addition runs
             ref = sorted[q];
-            pt = load_affine(p.table, ref & 0x7fffffffu);
+            pt = load_affine(table, ref & 0x7fffffffu);
         }
         xyzz_madd_signed(acc, cur, (cur_ref >> 31) != 0);
         if (q >= end) break;
@@ -894,7 +896,8 @@ static void xyzz_batch_to_jacobian_host(const std::vector<XYZZ>& pts, void* out)
 }
 
 // core: nb columns of n scalars each against one table; out_xyzz[nb] receive the unnormalised sums.
-static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_ptrs, uint32_t nb, size_t n, XYZZ* out_xyzz) {
+// h_col_tables (optional): per-column table pointer (bt.d_table or bt.d_runs_table).
+static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_ptrs, uint32_t nb, size_t n, XYZZ* out_xyzz, const void* const* h_col_tables = nullptr) {
     const int c = bt.c, W = bt.W;
     const uint32_t B = 1u << (c - 1);
     const Tune& tn = ctx->tune;
@@ -933,11 +936,12 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     const int part_threads = std::min(256, tn.msm_sort_threads);
     p.pch = std::min<uint32_t>(std::max<uint32_t>(1, MSM_PART_PAIRS / (uint32_t)W), PART_SPT * (uint32_t)part_threads);
     if (p.nbin > MSM_MAX_BINS) return ctx->fail(ZK_ERR_LIMIT, "zk_msm: window width c = %d exceeds 16", c);
-    ZK_HIP(ctx->ws_small.ensure((size_t)nb * p.small_stride * 4 + (size_t)nb * sizeof(void*) + 64));
+    ZK_HIP(ctx->ws_small.ensure((size_t)nb * p.small_stride * 4 + 2 * (size_t)nb * sizeof(void*) + 64));
     p.small = (uint32_t*)ctx->ws_small.p;
     const void** d_ptrs = (const void**)((char*)ctx->ws_small.p + (((size_t)nb * p.small_stride * 4 + 15) & ~(size_t)15));
     p.scalars = d_ptrs;
     p.table = bt.d_table;
+    p.col_tables = h_col_tables ? d_ptrs + nb : nullptr;
     p.sorted_stride = (pairs_max + 4 + 15) & ~(uint64_t)15;      // columns of the 1-, 4-byte arrays start 16-byte aligned
     ZK_HIP(ctx->ws_sorted.ensure((size_t)nb * p.sorted_stride * 4));
     p.sorted = (uint32_t*)ctx->ws_sorted.p;
@@ -958,6 +962,7 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     hipStream_t st = ctx->stream;
     ZK_HIP(hipMemsetAsync(p.small, 0, (size_t)nb * p.small_stride * 4, st));
     ZK_HIP(hipMemcpyAsync((void*)d_ptrs, h_scal_ptrs, (size_t)nb * sizeof(void*), hipMemcpyHostToDevice, st));
+    if (h_col_tables) ZK_HIP(hipMemcpyAsync((void*)(d_ptrs + nb), h_col_tables, (size_t)nb * sizeof(void*), hipMemcpyHostToDevice, st));
     int wgs = tn.msm_sort_wgs;
     {   // do not spread small inputs over many workgroups (each one flushes its counters)
         uint64_t per = (uint64_t)tn.msm_sort_threads * 4;
@@ -1075,21 +1080,14 @@ int msm_run_batch(zk_ctx* ctx, uint64_t handle, const void* const* scalars, size
             std::vector<uint32_t> counts(2 * nb);
             ZK_HIP(hipMemcpyAsync(counts.data(), d_counts, nb * 8, hipMemcpyDeviceToHost, st));
             ZK_HIP(hipStreamSynchronize(st));
-            for (uint32_t i = 0; i < nb; i++)       // worth it when the differences are clearly sparser than the column (the second batch has its own reduction tail)
+            for (uint32_t i = 0; i < nb; i++)       // worth it when the differences are clearly sparser than the column
                 ((uint64_t)counts[2 * i + 1] * 5 < (uint64_t)counts[2 * i] * 4 && (counts[2 * i] >= 4096 || ctx->tune.msm_runs >= 2) ? runs : direct).push_back(i);
-            uint64_t saved = 0;                        // point additions the run columns avoid; a second batch pays its own sort / reduction launches
+            uint64_t saved = 0;                        // point additions the run columns avoid, against one more pass over them (the difference kernel)
             for (uint32_t i : runs) saved += (uint64_t)(counts[2 * i] - counts[2 * i + 1]) * bt.W;
             // (msm_runs = 2: take the run path whenever it is sparser, whatever the size — tests)
-            if (saved < (4u << 20) && ctx->tune.msm_runs < 2) { for (uint32_t i : runs) direct.push_back(i); runs.clear(); std::sort(direct.begin(), direct.end()); }
+            if (saved < (1u << 18) && ctx->tune.msm_runs < 2) { for (uint32_t i : runs) direct.push_back(i); runs.clear(); std::sort(direct.begin(), direct.end()); }
         } else for (uint32_t i = 0; i < nb; i++) direct.push_back(i);
-        if (!direct.empty()) {
-            std::vector<const void*> sub(direct.size());
-            std::vector<XYZZ> r(direct.size());
-            for (size_t f = 0; f < direct.size(); f++) sub[f] = ptrs[direct[f]];
-            int rc = msm_core(ctx, bt, sub.data(), (uint32_t)direct.size(), n, r.data());
-            if (rc) return rc;
-            for (size_t f = 0; f < direct.size(); f++) res[direct[f]] = r[f];
-        }
+        std::vector<const void*> col_tables;
         if (!runs.empty()) {
             hipStream_t st = ctx->stream;
             const size_t Fn = runs.size();
@@ -1102,16 +1100,13 @@ int msm_run_batch(zk_ctx* ctx, uint64_t handle, const void* const* scalars, size
             ZK_HIP(hipMemcpyAsync(d_which, runs.data(), Fn * 4, hipMemcpyHostToDevice, st));
             ZK_LAUNCH(fr_adjacent_diff_kernel, dim3((uint32_t)((n + 255) / 256), (uint32_t)Fn), 256, 0, st, (const void* const*)d_cols, (const uint32_t*)d_which, (uint32_t)n, (void*)d_diff);
             ZK_CHECK_LAUNCH();
-            BaseTable ps = bt;
-            ps.d_table = bt.d_runs_table;
-            std::vector<const void*> sub(Fn);
-            std::vector<XYZZ> r(Fn);
-            for (size_t f = 0; f < Fn; f++) sub[f] = d_diff + f * n * 32;
-            int rc = msm_core(ctx, ps, sub.data(), (uint32_t)Fn, n, r.data());
-            if (rc) return rc;
-            for (size_t f = 0; f < Fn; f++) res[runs[f]] = r[f];
+            // ONE launch sequence for the whole batch: run columns read their differences and the prefix-sum twin, the others their scalars and the table
+            col_tables.assign(nb, bt.d_table);
+            for (size_t f = 0; f < Fn; f++) { ptrs[runs[f]] = d_diff + f * n * 32; col_tables[runs[f]] = bt.d_runs_table; }
             ctx->last_ms["msm_run_columns"] += (double)Fn;
         }
+        int rc = msm_core(ctx, bt, ptrs.data(), (uint32_t)nb, n, res.data(), col_tables.empty() ? nullptr : col_tables.data());
+        if (rc) return rc;
     }
     if (partial) memcpy(out, res.data(), nb * 128);
     else if (nb == 1) xyzz_to_jacobian_host(res[0], out);

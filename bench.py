@@ -2,7 +2,7 @@
 """bench.py — proofs/hour of the sgx_dcap_verifier k=19 prover on MI355X (BASELINE.json configs[1]) and, as extras, the
 BN254 MSM Mscalar/s at 2^24 (configs[2]) and batched NTT (configs[3]).
 
-Default (`--mode prove`): a "step" is one batch of `--inflight` REAL proofs: `plonk.create_proof` (the mirror of halo2's
+Default (`--mode prove`): a "step" is one batch of `--inflight` (4) REAL proofs: `plonk.create_proof` (the mirror of halo2's
 create_proof, zk-dcap-verifier_amd/plonk/prover.py) over a satisfiable synthetic circuit with the census of the sgx circuit at
 k = 19 (tools/sgx_shaped_circuit.py: 25 advice, 18 fixed, 11 lookups, 16 equality columns, 24 gates, degree 5 => 71 commitments,
 64 iNTT(2^19), 64 NTT(2^21) + 1 iNTT(2^21), evaluate_h over 2^21 rows, 175 evaluations, SHPLONK).  The witness columns are

@@ -181,6 +181,7 @@ class ProofWorkload:
 
 
 TAU = 0x1C59A59B6CFF4308740943526ADE1D8C09F71B337A67269CC89586BCDD6DFCBA   # SRS trapdoor of the synthetic setup
+PROVER = "native"      # --prover: "native" = zk_plonk_create_proof (C++ over the C ABI), "python" = its twin plonk.create_proof
 
 
 class ProverWorkload:
@@ -192,6 +193,7 @@ class ProverWorkload:
         # one SRS for the process: the first context runs ParamsKZG::setup (fixed-base powers + EC-NTT); the others share its expanded tables in HBM
         self.params = z.kzg.ParamsKZG.setup(k, TAU, backend=be) if srs is None else z.kzg.ParamsKZG.shared_with(srs, be)
         self.pk = z.plonk.keygen(self.params, cs, fixed, asm)
+        self.native = z.plonk.NativeProver(self.params, self.pk) if PROVER == "native" else None
         self.master = [be.to_device(a) for a in advice]
         self.work = [be.alloc(self.n * 32) for _ in advice]
         self.advice_host = advice                      # pageable host arrays (what a Rust Vec<Fr> is)
@@ -224,8 +226,15 @@ class ProverWorkload:
             adv = self.pinned
         else:
             adv = self.advice_host
-        tr = Blake2bWrite()
         self.seed += 1
+        if self.native is not None and timings is None and capture is None:
+            # the native per-proof path (zk_plonk_create_proof, csrc/prover.hip): the C++ twin of plonk.create_proof — same bytes, no interpreter in the loop
+            self.proof = self.native.create_proof(adv, [], np.random.default_rng(self.seed))
+            if self.info is None:
+                n_commit = self.A + 3 * self.L + self.P + 1 + (self.d - 1) + 2
+                self.info = {"commitments": n_commit, "evals": len(self.proof) // 32 - n_commit}
+            return
+        tr = Blake2bWrite()
         self.info = self.z.plonk.create_proof(self.params, self.pk, adv, [], np.random.default_rng(self.seed), tr, timings=timings, capture=capture)
         self.proof = tr.finalize()
 
@@ -537,10 +546,14 @@ def main(argv=None):
     ap.add_argument("--mode", choices=("prove", "opmix"), default="prove", help="prove: real create_proof over the sgx-shaped circuit (default); opmix: the hot-path call list over synthetic columns")
     ap.add_argument("--census", choices=("chip_estimate", "reference_exact"), default="chip_estimate",
                     help="which synthetic circuit `value` is measured on (tools/sgx_shaped_circuit.py); the other one is measured as extra.census_* unless --no-extras")
+    ap.add_argument("--prover", choices=("native", "python"), default="native",
+                    help="which create_proof the timed steps run: the library's C++ one (zk_plonk_create_proof) or its Python twin (plonk.create_proof); same bytes")
     ap.add_argument("--inflight", type=int, default=4, help="proofs processed concurrently per step on one GPU (one context + HIP stream each)")
     ap.add_argument("--no-extras", action="store_true", help="skip the MSM 2^24 / NTT 2^22 microbenchmarks and the CPU baseline")
     args = ap.parse_args(argv)
 
+    global PROVER
+    PROVER = args.prover
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("ZK_BENCH_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
@@ -942,6 +955,7 @@ def main(argv=None):
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (256-bit Montgomery integers)",
                 "data": "synthetic",
                 "config": {"workload": workload, "mode": args.mode,
+                           "prover": "zk_plonk_create_proof (C++, csrc/prover.hip)" if args.prover == "native" else "plonk.create_proof (Python twin)",
                            "parallelism": f"{world} x independent proofs (one process per GPU)"},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line), flush=True)

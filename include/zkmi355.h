@@ -260,6 +260,46 @@ int zk_evaluate_h(zk_ctx* ctx, uint64_t pk, const void* const* advice_polys, con
                   const void* const* lookup_table_polys, const void* challenges, const void* beta, const void* gamma, const void* theta,
                   const void* y, int finish, void* out);
 
+/* ---- the whole per-proof path: replaces plonk::create_proof + ProverSHPLONK ------------------------------------- *
+ * halo2_proofs src/plonk/prover.rs create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK, Challenge255, _, Blake2bWrite, _> as the reference calls it
+ * (circuits/src/sgx_dcap_verifier.rs:814-822), single circuit instance, no user challenges: every O(n) step runs through the entry points above in the
+ * order of INTEGRATION.md's phase table, columns stay in HBM from the advice commitment to the last SHPLONK commitment, Fiat-Shamir hashing (Blake2b,
+ * Challenge255), point encoding (y parity in bit 255) and the rotation-set bookkeeping run on the host inside this call.  This is the native (C++) form of
+ * the phase-batched prover; zk-dcap-verifier_amd/plonk/prover.py is its Python twin and both emit the same bytes for the same inputs and draws.
+ *
+ * The proving key is described by pointers to what keygen_pk leaves behind, all resident on the context's GPU (the caller keeps ownership):
+ * fixed / sigma columns in Lagrange, coefficient and extended-coset form, l0 / l_last / l_active_row cosets, the compiled Evaluator (zk_quotient_program_load)
+ * and, per lookup, the two expression programs that theta-compress its input and table expressions over the 2^k rows (ZKQ1 programs with extended_k = k);
+ * lookups with equal lookup_table_key share their compressed table.  Queries are (column, rotation) pairs in cs.advice_queries / cs.fixed_queries order. */
+typedef struct zk_plonk_pk_desc {
+    uint32_t k, extended_k, cs_degree, blinding_factors;
+    uint32_t n_fixed, n_advice, n_instance, n_lookups, n_perm_columns;
+    const uint32_t* perm_columns;             /* n_perm_columns x (column_type: 0 advice 1 fixed 2 instance, index) */
+    const uint32_t* advice_queries; uint32_t n_advice_queries;   /* pairs (column, rotation as int32) */
+    const uint32_t* fixed_queries;  uint32_t n_fixed_queries;
+    uint64_t srs_g, srs_g_lagrange;           /* zk_bases_register handles of params.g / params.g_lagrange */
+    uint64_t program;                         /* the proving key's Evaluator */
+    const uint64_t* lookup_input_programs;    /* n_lookups */
+    const uint64_t* lookup_table_programs;    /* n_lookups */
+    const uint32_t* lookup_table_key;         /* n_lookups */
+    const void* const* fixed_values; const void* const* fixed_polys; const void* const* fixed_cosets;   /* DEVICE, n_fixed each */
+    const void* const* sigma_values; const void* const* sigma_polys; const void* const* sigma_cosets;   /* DEVICE, n_perm_columns each */
+    const void* l0; const void* l_last; const void* l_active_row;                                       /* DEVICE extended cosets */
+    const void* transcript_repr;              /* HOST 32 B: vk.transcript_repr, canonical little endian */
+} zk_plonk_pk_desc;
+/* the caller's RNG (`&mut rng` of create_proof): fill out_fr with n uniform field elements as Montgomery limbs (n x 32 B).  Called from a helper thread of the
+ * library, once per Fr::random block, in the order halo2 draws them: advice blinding per column, then per lookup the permuted-input and permuted-table
+ * blinding, per permutation set and per lookup the grand-product blinding, then the n coefficients of the vanishing argument's random polynomial. */
+typedef void (*zk_rng_fn)(void* user, size_t n, void* out_fr);
+/* advice: n_advice columns of 2^k x 32 B (HOST, or DEVICE when advice_on_device — then consumed: they hold coefficients afterwards); instances: HOST,
+ * instance_lens[c] canonical 32-byte values per instance column.  The proof (32 bytes per commitment and evaluation) is written to proof_out;
+ * *proof_len receives its length (ZK_ERR_LIMIT when proof_cap is too small).  Errors of the entry points it drives are returned as they are
+ * (e.g. ZK_ERR_ARG from zk_lookup_permute_batch_dev for a lookup input outside its table: halo2's Error::ConstraintSystemFailure). */
+int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
+                          const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len);
+/* return the per-proof device buffers zk_plonk_create_proof keeps for reuse on this context (call before zk_ctx_destroy) */
+int zk_plonk_trim(zk_ctx* ctx);
+
 /* library / build identification */
 const char* zk_version(void);
 

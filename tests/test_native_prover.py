@@ -1,0 +1,80 @@
+"""zk_plonk_create_proof — the native (C++) per-proof path over the C ABI — against the goldens of the independent CPU prover (oracle/prover.py) and against
+its Python twin plonk.create_proof: same SRS, witness and seeded draws => the same bytes; the proofs are accepted by verify_proof; a witness outside a lookup
+table is refused with halo2's ConstraintSystemFailure."""
+import numpy as np
+import pytest
+
+import zk_dcap_verifier_amd as z
+from zk_dcap_verifier_amd import plonk
+from zk_dcap_verifier_amd.transcript import Blake2bWrite
+
+import test_create_proof as tcp
+
+
+def _toy(be, k, seed):
+    import verifier
+    cs, fixed, asm, advice, instances = tcp.toy_circuit(k)
+    params = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    native = plonk.NativeProver(params, pk)
+    proof = native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(seed))
+    tr = Blake2bWrite()
+    plonk.create_proof(params, pk, [a.copy() for a in advice], instances, np.random.default_rng(seed), tr)
+    assert proof == tr.finalize()
+    assert verifier.verify_proof(pk.vk, tcp.TAU, instances, proof) is True
+    # device-resident witness: same bytes
+    dev = [be.to_device(a) for a in advice]
+    assert native.create_proof(dev, instances, np.random.default_rng(seed)) == proof
+    pk.release()
+    params.release()
+    return proof
+
+
+def _sgx(be, k, census, golden=None):
+    import os, sys
+    import verifier
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sgx_shaped_circuit as sc
+    cs, fixed, asm, advice = sc.build(z, be, k, census=census)
+    params = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    proof = plonk.NativeProver(params, pk).create_proof(advice, [], np.random.default_rng(3))
+    if golden:
+        assert proof == tcp._golden(golden)
+    assert verifier.verify_proof(pk.vk, tcp.TAU, [], proof) is True
+    pk.release()
+    params.release()
+
+
+def test_native_prover_emits_the_golden_toy_proof_emulated(emu, orc):
+    assert _toy(emu, 6, 7) == tcp._golden(tcp.GOLDEN_PROOF)
+
+
+def test_native_prover_emits_the_sgx_shaped_goldens_emulated(emu, orc):
+    _sgx(emu, 8, "chip_estimate", tcp.GOLDEN_SGX)
+    _sgx(emu, 9, "reference_exact", tcp.GOLDEN_REF_EXACT)
+
+
+def test_native_prover_refuses_a_lookup_input_outside_the_table(emu, orc):
+    cs, fixed, asm, advice, instances = tcp.toy_circuit(5, tamper="lookup")
+    params = z.kzg.ParamsKZG.setup(5, tcp.TAU, backend=emu)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    with pytest.raises(z.ZkError):
+        plonk.NativeProver(params, pk).create_proof(advice, instances, np.random.default_rng(1))
+    pk.release()
+    params.release()
+
+
+@pytest.mark.gpu
+def test_native_prover_goldens_gpu(gpu, orc):
+    assert _toy(gpu, 6, 7) == tcp._golden(tcp.GOLDEN_PROOF)
+    _sgx(gpu, 8, "chip_estimate", tcp.GOLDEN_SGX)
+    _sgx(gpu, 9, "reference_exact", tcp.GOLDEN_REF_EXACT)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [12, 19])
+def test_native_prover_verifies_gpu(gpu, orc, k):
+    _toy(gpu, 10, 5)
+    _sgx(gpu, k, "chip_estimate")

@@ -148,6 +148,7 @@ class Backend:
     def close(self):
         if self.ctx:
             self.trim_pool()
+            self.lib.zk_plonk_trim(self.ctx)
             for p in list(self._pinned.values()):
                 self.lib.zk_host_free(self.ctx, C.c_void_p(p))
             self._pinned = {}

@@ -1,0 +1,589 @@
+// Native create_proof: halo2_proofs::plonk::create_proof + ProverSHPLONK (zkwebauthn/halo2 @ c254c75, Cargo.lock:1314-1327) as the reference calls
+// them at circuits/src/sgx_dcap_verifier.rs:814-822 — the per-proof path of a phase-batched, HBM-resident `plonk/prover.rs`, written in C++ because the
+// reference's host side is compiled code (Rust) and no Rust toolchain exists in the build image.  It is a CLIENT of the C ABI (include/zkmi355.h): every
+// O(n) step is one of the zk_* entry points the Rust prover would call, in the order of INTEGRATION.md's phase table; what stays on the host is what
+// stays on the host in the reference — Fiat-Shamir hashing (Blake2b, src/transcript.rs), point encoding, rotation-set bookkeeping and the O(#points^2)
+// interpolations of SHPLONK.  zk-dcap-verifier_amd/plonk/prover.py + shplonk.py are the Python twin (phase by phase, draw by draw): both must emit the
+// bytes of the independent CPU prover's goldens (tests/test_native_prover.py).  Single circuit instance, no user challenges, Blake2b transcript (stack A).
+#include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include "field.cuh"
+#include "../../include/zkmi355.h"
+
+using namespace zk;
+
+namespace {
+
+// ---- Blake2b-512 with personalisation (RFC 7693), incremental, copyable ------------------------------------------------------------------------------
+struct Blake2b {
+    uint64_t h[8], t = 0;
+    uint8_t buf[128];
+    size_t len = 0;
+    static constexpr uint64_t IV[8] = {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+                                       0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+    explicit Blake2b(const char person[16]) {
+        for (int i = 0; i < 8; i++) h[i] = IV[i];
+        h[0] ^= 0x01010000ull ^ 64;                                  // digest length 64, no key, fanout = depth = 1
+        uint64_t p0, p1;
+        memcpy(&p0, person, 8); memcpy(&p1, person + 8, 8);
+        h[6] ^= p0; h[7] ^= p1;                                      // parameter block bytes 48..63
+    }
+    static uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+    void compress(const uint8_t* block, bool last) {
+        static const uint8_t S[12][16] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+                                          {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4},   {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+                                          {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13},   {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+                                          {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11},   {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+                                          {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5},   {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+                                          {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+        uint64_t m[16], v[16];
+        memcpy(m, block, 128);
+        for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; }
+        v[12] ^= t;
+        if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+            v[a] = v[a] + v[b] + x; v[d] = rotr(v[d] ^ v[a], 32); v[c] = v[c] + v[d]; v[b] = rotr(v[b] ^ v[c], 24);
+            v[a] = v[a] + v[b] + y; v[d] = rotr(v[d] ^ v[a], 16); v[c] = v[c] + v[d]; v[b] = rotr(v[b] ^ v[c], 63);
+        };
+        for (int r = 0; r < 12; r++) {
+            const uint8_t* s = S[r];
+            G(0, 4, 8, 12, m[s[0]], m[s[1]]); G(1, 5, 9, 13, m[s[2]], m[s[3]]); G(2, 6, 10, 14, m[s[4]], m[s[5]]); G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+            G(0, 5, 10, 15, m[s[8]], m[s[9]]); G(1, 6, 11, 12, m[s[10]], m[s[11]]); G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+        }
+        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+    }
+    void update(const void* data, size_t n) {
+        const uint8_t* p = (const uint8_t*)data;
+        while (n) {
+            if (len == 128) { t += 128; compress(buf, false); len = 0; }        // a full buffer is only compressed when more input follows
+            const size_t take = std::min(n, 128 - len);
+            memcpy(buf + len, p, take);
+            len += take; p += take; n -= take;
+        }
+    }
+    void digest(uint8_t out[64]) const {                              // of a copy: the state keeps absorbing afterwards (Blake2bWrite clones to squeeze)
+        Blake2b c = *this;
+        c.t += c.len;
+        memset(c.buf + c.len, 0, 128 - c.len);
+        c.compress(c.buf, true);
+        memcpy(out, c.h, 64);
+    }
+};
+constexpr uint64_t Blake2b::IV[8];
+
+// ---- host field helpers (Montgomery u256 over Fr / Fq from field.cuh) ---------------------------------------------------------------------------------
+using Fe = u256;
+inline Fe fe_from_u64(uint64_t v) { u256 x = Fr::zero(); x.v[0] = (uint32_t)v; x.v[1] = (uint32_t)(v >> 32); return Fr::to_mont(x); }
+inline Fe fe_pow_u64(Fe a, uint64_t e) { Fe r = Fr::one(); while (e) { if (e & 1) r = Fr::mul(r, a); a = Fr::sqr(a); e >>= 1; } return r; }
+inline bool canon_less(const u256& a, const u256& b) { for (int i = 7; i >= 0; i--) if (a.v[i] != b.v[i]) return a.v[i] < b.v[i]; return false; }
+inline u256 load32(const void* p) { u256 o; memcpy(&o, p, 32); return o; }
+struct CanonLess { bool operator()(const u256& a, const u256& b) const { return canon_less(a, b); } };
+
+struct Transcript {                                                  // Blake2bWrite<_, G1Affine, Challenge255<_>>
+    Blake2b st{"Halo2-Transcript"};
+    std::vector<uint8_t> out;
+    Fe squeeze() {                                                    // Challenge255: the 64-byte digest as a little-endian integer mod r
+        const uint8_t pre = 0;
+        st.update(&pre, 1);
+        uint8_t d[64];
+        st.digest(d);
+        const u256 lo = load32(d), hi = load32(d + 32), r2 = Fr::R2();
+        return Fr::add(Fr::mul(lo, r2), Fr::mul(Fr::mul(hi, r2), r2));
+    }
+    void common_scalar(const Fe& s) {
+        const uint8_t pre = 2;
+        const u256 c = Fr::from_mont(s);
+        st.update(&pre, 1); st.update(c.v, 32);
+    }
+    void write_scalar(const Fe& s) {
+        common_scalar(s);
+        const u256 c = Fr::from_mont(s);
+        out.insert(out.end(), (const uint8_t*)c.v, (const uint8_t*)c.v + 32);
+    }
+    void write_point(const uint64_t jac[12]) {                        // normalised {x, y, z}: z = mont(1), or all zero for the identity
+        u256 x = Fq::zero(), y = Fq::zero();
+        bool ident = true;
+        for (int i = 8; i < 12; i++) ident &= jac[i] == 0;
+        if (!ident) { x = Fq::from_mont(load32(jac)); y = Fq::from_mont(load32(jac + 4)); }
+        const uint8_t pre = 1;
+        st.update(&pre, 1); st.update(x.v, 32); st.update(y.v, 32);
+        uint8_t enc[32];
+        memcpy(enc, x.v, 32);
+        if (!ident) enc[31] |= (uint8_t)((y.v[0] & 1) << 7);
+        out.insert(out.end(), enc, enc + 32);
+    }
+};
+
+// ---- device memory of one proof: size-keyed free lists kept per context across proofs ------------------------------------------------------------------
+struct Pool {
+    std::mutex mu;
+    std::map<size_t, std::vector<void*>> free_;
+};
+std::mutex g_pools_mu;
+std::map<zk_ctx*, Pool*> g_pools;
+Pool* pool_of(zk_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_pools_mu);
+    Pool*& p = g_pools[ctx];
+    if (!p) p = new Pool();
+    return p;
+}
+struct Arena {                                                        // everything a proof allocates goes back to the pool when it ends
+    zk_ctx* ctx; Pool* pool; std::vector<std::pair<void*, size_t>> held;
+    explicit Arena(zk_ctx* c) : ctx(c), pool(pool_of(c)) {}
+    void* get(size_t bytes) {
+        void* p = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(pool->mu);
+            auto& v = pool->free_[bytes];
+            if (!v.empty()) { p = v.back(); v.pop_back(); }
+        }
+        if (!p && zk_dev_alloc(ctx, bytes, &p) != ZK_OK) return nullptr;
+        held.push_back({p, bytes});
+        return p;
+    }
+    void give_back(void* p) {
+        for (auto& h : held) if (h.first == p) { std::lock_guard<std::mutex> lk(pool->mu); pool->free_[h.second].push_back(p); h.first = nullptr; return; }
+    }
+    ~Arena() {
+        std::lock_guard<std::mutex> lk(pool->mu);
+        for (auto& h : held) if (h.first) pool->free_[h.second].push_back(h.first);
+    }
+};
+
+// ---- the caller's Fr::random draws, made on a helper thread in the order the phases consume them ---------------------------------------------------------
+struct Draws {
+    std::vector<std::vector<uint64_t>> items;                         // each: count x 4 limbs
+    std::vector<size_t> counts;
+    std::mutex mu; std::condition_variable cv; size_t done = 0;
+    std::thread th;
+    void start(zk_rng_fn rng, void* user) {
+        items.resize(counts.size());
+        for (size_t i = 0; i < counts.size(); i++) items[i].resize(counts[i] * 4 + 4);
+        th = std::thread([this, rng, user]() {
+            for (size_t i = 0; i < counts.size(); i++) {
+                if (counts[i]) rng(user, counts[i], items[i].data());
+                { std::lock_guard<std::mutex> lk(mu); done = i + 1; }
+                cv.notify_all();
+            }
+        });
+    }
+    const uint64_t* take(size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done > i; }); return items[i].data(); }
+    ~Draws() { if (th.joinable()) th.join(); }
+};
+
+struct Query { const void* poly; Fe point; Fe eval; };                 // ProverQuery { point, poly } + its evaluation
+
+std::vector<Fe> lagrange_interpolate(const std::vector<Fe>& pts, const std::vector<Fe>& evals) {
+    const size_t n = pts.size();
+    std::vector<Fe> coeffs(n, Fr::zero());
+    for (size_t j = 0; j < n; j++) {
+        std::vector<Fe> num{Fr::one()};
+        Fe den = Fr::one();
+        for (size_t m = 0; m < n; m++) {
+            if (m == j) continue;
+            std::vector<Fe> nx(num.size() + 1);
+            nx[0] = Fr::neg(Fr::mul(pts[m], num[0]));
+            for (size_t i = 1; i < num.size(); i++) nx[i] = Fr::sub(num[i - 1], Fr::mul(pts[m], num[i]));
+            nx[num.size()] = num.back();
+            num.swap(nx);
+            den = Fr::mul(den, Fr::sub(pts[j], pts[m]));
+        }
+        const Fe sc = Fr::mul(evals[j], Fr::inv(den));
+        for (size_t i = 0; i < num.size(); i++) coeffs[i] = Fr::add(coeffs[i], Fr::mul(num[i], sc));
+    }
+    return coeffs;
+}
+Fe eval_small(const std::vector<Fe>& c, const Fe& x) { Fe acc = Fr::zero(); for (size_t i = c.size(); i-- > 0;) acc = Fr::add(Fr::mul(acc, x), c[i]); return acc; }
+Fe vanishing_at(const std::vector<Fe>& roots, const Fe& z) { Fe acc = Fr::one(); for (auto& r : roots) acc = Fr::mul(acc, Fr::sub(z, r)); return acc; }
+
+#define PK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+}  // namespace
+
+extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
+                                     const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len) {
+    if (!ctx || !pk || !rng || !proof_len || (pk->n_advice && !advice)) return ZK_ERR_ARG;
+    const uint32_t k = pk->k, ek = pk->extended_k, bf = pk->blinding_factors, L = pk->n_lookups;
+    const size_t n = (size_t)1 << k, en = (size_t)1 << ek, col_bytes = n * 32;
+    if (k < 1 || ek < k || ek > 27 || bf + 2 >= n || pk->cs_degree < 3) return ZK_ERR_ARG;
+    const size_t usable = n - (bf + 1);
+    const uint32_t chunk = pk->cs_degree - 2;
+    const uint32_t n_sets = pk->n_perm_columns ? (pk->n_perm_columns + chunk - 1) / chunk : 0;
+    const uint32_t n_pieces = pk->cs_degree - 1;
+    Arena mem(ctx);
+    Transcript tr;
+    Draws draws;
+    // draw sizes in the mirror's order: advice blinding (one draw per column), then bi / bt per lookup, permutation sets, lookup products, the random polynomial
+    for (uint32_t i = 0; i < pk->n_advice; i++) draws.counts.push_back(n - usable);
+    const size_t d_bi = draws.counts.size(); for (uint32_t l = 0; l < L; l++) draws.counts.push_back(bf + 1);
+    const size_t d_bt = draws.counts.size(); for (uint32_t l = 0; l < L; l++) draws.counts.push_back(bf + 1);
+    const size_t d_pb = draws.counts.size(); for (uint32_t s = 0; s < n_sets; s++) draws.counts.push_back(bf);
+    const size_t d_lb = draws.counts.size(); for (uint32_t l = 0; l < L; l++) draws.counts.push_back(bf);
+    const size_t d_rp = draws.counts.size(); draws.counts.push_back(n);
+    draws.start(rng, rng_user);
+
+    // ---- 1. vk, instances ----------------------------------------------------------------------------------------------------------------------------
+    tr.common_scalar(Fr::to_mont(load32(pk->transcript_repr)));
+    std::vector<void*> inst_values;
+    for (uint32_t c = 0; c < pk->n_instance; c++) {
+        const uint32_t len = instance_lens ? instance_lens[c] : 0;
+        if (len > usable) return ZK_ERR_ARG;
+        std::vector<uint64_t> col(n * 4, 0);
+        for (uint32_t i = 0; i < len; i++) {
+            const Fe v = Fr::to_mont(load32((const char*)instances[c] + 32 * i));
+            tr.common_scalar(v);
+            memcpy(&col[4 * (size_t)i], v.v, 32);
+        }
+        void* d = mem.get(col_bytes);
+        if (!d) return ZK_ERR_HIP;
+        PK(zk_dev_upload(ctx, d, col.data(), col_bytes));
+        inst_values.push_back(d);
+    }
+    // ---- 2. advice: upload (host columns), blind, commit ------------------------------------------------------------------------------------------------
+    std::vector<void*> adv(pk->n_advice);
+    {
+        std::vector<void*> dst;
+        std::vector<const void*> src;
+        for (uint32_t i = 0; i < pk->n_advice; i++) {
+            if (advice_on_device) adv[i] = (void*)advice[i];
+            else { adv[i] = mem.get(col_bytes); if (!adv[i]) return ZK_ERR_HIP; dst.push_back(adv[i]); src.push_back(advice[i]); }
+        }
+        if (!dst.empty()) PK(zk_dev_upload_batch(ctx, dst.data(), src.data(), dst.size(), col_bytes));
+        std::vector<void*> bdst(pk->n_advice);
+        std::vector<const void*> bsrc(pk->n_advice);
+        for (uint32_t i = 0; i < pk->n_advice; i++) { bdst[i] = (char*)adv[i] + usable * 32; bsrc[i] = draws.take(i); }
+        if (pk->n_advice) PK(zk_dev_upload_batch(ctx, bdst.data(), bsrc.data(), pk->n_advice, (n - usable) * 32));
+    }
+    auto commit = [&](uint64_t table, const std::vector<void*>& cols) -> int {
+        if (cols.empty()) return ZK_OK;
+        std::vector<uint64_t> out(cols.size() * 12);
+        PK(zk_msm_batch_dev(ctx, table, (const void* const*)cols.data(), cols.size(), n, out.data()));
+        for (size_t i = 0; i < cols.size(); i++) tr.write_point(&out[12 * i]);
+        return ZK_OK;
+    };
+    PK(commit(pk->srs_g_lagrange, adv));
+    // ---- 3. theta; lookups: compress, permute, commit ---------------------------------------------------------------------------------------------------
+    const Fe theta = tr.squeeze();
+    const Fe one = Fr::one();
+    std::vector<void*> cin(L), ctab(L);
+    {
+        const void* anycol = pk->n_fixed ? pk->fixed_values[0] : (pk->n_advice ? adv[0] : nullptr);
+        std::map<uint32_t, void*> table_cache;
+        auto compress = [&](uint64_t prog, void** out) -> int {
+            *out = mem.get(col_bytes);
+            if (!*out) return ZK_ERR_HIP;
+            zk_quotient_args a;
+            memset(&a, 0, sizeof a);
+            a.fixed = pk->fixed_values; a.advice = (const void* const*)adv.data(); a.instance = (const void* const*)inst_values.data();
+            a.l0 = a.l_last = a.l_active_row = anycol;
+            a.beta = a.gamma = a.y = one.v; a.theta = theta.v; a.challenges = one.v;
+            a.out = *out;
+            return zk_quotient_run_dev(ctx, prog, &a);
+        };
+        for (uint32_t l = 0; l < L; l++) {
+            auto it = table_cache.find(pk->lookup_table_key[l]);
+            if (it == table_cache.end()) { void* t = nullptr; PK(compress(pk->lookup_table_programs[l], &t)); it = table_cache.emplace(pk->lookup_table_key[l], t).first; }
+            PK(compress(pk->lookup_input_programs[l], &cin[l]));
+            ctab[l] = it->second;
+        }
+    }
+    std::vector<void*> pin(L), ptab(L);
+    if (L) {
+        std::vector<uint64_t> bi((size_t)L * (bf + 1) * 4), bt((size_t)L * (bf + 1) * 4);
+        for (uint32_t l = 0; l < L; l++) {
+            memcpy(&bi[(size_t)l * (bf + 1) * 4], draws.take(d_bi + l), (bf + 1) * 32);
+            memcpy(&bt[(size_t)l * (bf + 1) * 4], draws.take(d_bt + l), (bf + 1) * 32);
+        }
+        for (uint32_t l = 0; l < L; l++) { pin[l] = mem.get(col_bytes); ptab[l] = mem.get(col_bytes); if (!pin[l] || !ptab[l]) return ZK_ERR_HIP; }
+        PK(zk_lookup_permute_batch_dev(ctx, (const void* const*)cin.data(), (const void* const*)ctab.data(), L, k, bf, bi.data(), bt.data(), pin.data(), ptab.data()));
+        std::vector<void*> flat;
+        for (uint32_t l = 0; l < L; l++) { flat.push_back(pin[l]); flat.push_back(ptab[l]); }
+        PK(commit(pk->srs_g_lagrange, flat));
+    }
+    // ---- 4. beta, gamma; grand products -------------------------------------------------------------------------------------------------------------------
+    const Fe beta = tr.squeeze(), gamma = tr.squeeze();
+    std::vector<void*> zs(n_sets), lzs(L);
+    if (n_sets) {
+        std::vector<const void*> vals(pk->n_perm_columns);
+        for (uint32_t j = 0; j < pk->n_perm_columns; j++) {
+            const uint32_t ty = pk->perm_columns[2 * j], ix = pk->perm_columns[2 * j + 1];
+            vals[j] = ty == 0 ? adv[ix] : ty == 1 ? pk->fixed_values[ix] : inst_values[ix];
+        }
+        std::vector<uint64_t> blind((size_t)n_sets * bf * 4);
+        for (uint32_t s = 0; s < n_sets; s++) memcpy(&blind[(size_t)s * bf * 4], draws.take(d_pb + s), bf * 32);
+        for (uint32_t s = 0; s < n_sets; s++) { zs[s] = mem.get(col_bytes); if (!zs[s]) return ZK_ERR_HIP; }
+        PK(zk_permutation_product_all_dev(ctx, vals.data(), pk->sigma_values, pk->n_perm_columns, chunk, k, beta.v, gamma.v, blind.data(), bf, zs.data()));
+    }
+    if (L) {
+        std::vector<const void*> quads;
+        for (uint32_t l = 0; l < L; l++) { quads.push_back(cin[l]); quads.push_back(ctab[l]); quads.push_back(pin[l]); quads.push_back(ptab[l]); }
+        std::vector<uint64_t> blind((size_t)L * bf * 4);
+        for (uint32_t l = 0; l < L; l++) memcpy(&blind[(size_t)l * bf * 4], draws.take(d_lb + l), bf * 32);
+        for (uint32_t l = 0; l < L; l++) { lzs[l] = mem.get(col_bytes); if (!lzs[l]) return ZK_ERR_HIP; }
+        PK(zk_lookup_product_batch_dev(ctx, quads.data(), L, k, beta.v, gamma.v, blind.data(), bf, lzs.data()));
+    }
+    {
+        std::vector<void*> both(zs);
+        both.insert(both.end(), lzs.begin(), lzs.end());
+        PK(commit(pk->srs_g_lagrange, both));
+    }
+    // ---- 5. vanishing argument: random polynomial ------------------------------------------------------------------------------------------------------------
+    void* random_poly = mem.get(col_bytes);
+    if (!random_poly) return ZK_ERR_HIP;
+    PK(zk_dev_upload(ctx, random_poly, draws.take(d_rp), col_bytes));
+    PK(commit(pk->srs_g, {random_poly}));
+    // ---- 6. y; coefficient form; extended cosets; h(X) numerator ----------------------------------------------------------------------------------------------
+    const Fe y = tr.squeeze();
+    std::vector<void*> lag(adv);
+    lag.insert(lag.end(), inst_values.begin(), inst_values.end());
+    lag.insert(lag.end(), zs.begin(), zs.end());
+    lag.insert(lag.end(), lzs.begin(), lzs.end());
+    for (uint32_t l = 0; l < L; l++) { lag.push_back(pin[l]); lag.push_back(ptab[l]); }
+    PK(zk_lagrange_to_coeff_batch_dev(ctx, lag.data(), lag.size(), k));
+    void* h_ext = mem.get(en * 32);
+    if (!h_ext) return ZK_ERR_HIP;
+    {
+        std::vector<void*> ext(lag.size());
+        for (auto& e : ext) { e = mem.get(en * 32); if (!e) return ZK_ERR_HIP; }
+        PK(zk_coeff_to_extended_batch_dev(ctx, (const void* const*)lag.data(), ext.data(), ext.size(), k, ek));
+        const size_t nA = pk->n_advice, nI = pk->n_instance;
+        std::vector<const void*> e_in, e_tab;
+        for (uint32_t l = 0; l < L; l++) { e_in.push_back(ext[nA + nI + n_sets + L + 2 * l]); e_tab.push_back(ext[nA + nI + n_sets + L + 2 * l + 1]); }
+        zk_quotient_args a;
+        memset(&a, 0, sizeof a);
+        a.fixed = pk->fixed_cosets; a.advice = (const void* const*)ext.data(); a.instance = (const void* const*)ext.data() + nA;
+        a.l0 = pk->l0; a.l_last = pk->l_last; a.l_active_row = pk->l_active_row;
+        a.perm_cosets = pk->sigma_cosets; a.perm_products = (const void* const*)ext.data() + nA + nI; a.n_sets = n_sets;
+        a.lookup_product = (const void* const*)ext.data() + nA + nI + n_sets; a.lookup_input = e_in.data(); a.lookup_table = e_tab.data();
+        a.challenges = one.v; a.beta = beta.v; a.gamma = gamma.v; a.theta = theta.v; a.y = y.v; a.out = h_ext;
+        PK(zk_quotient_run_dev(ctx, pk->program, &a));
+        for (auto e : ext) mem.give_back(e);
+    }
+    // ---- 7. divide, back to coefficients, commit the pieces ---------------------------------------------------------------------------------------------------------
+    PK(zk_divide_by_vanishing_poly_dev(ctx, h_ext, k, ek));
+    PK(zk_extended_to_coeff_dev(ctx, h_ext, k, ek));
+    std::vector<void*> pieces(n_pieces);
+    for (uint32_t i = 0; i < n_pieces; i++) pieces[i] = (char*)h_ext + (size_t)i * col_bytes;
+    PK(commit(pk->srs_g, pieces));
+    // ---- 8. x; evaluations ------------------------------------------------------------------------------------------------------------------------------------------------
+    const Fe x = tr.squeeze();
+    Fe xn = x;
+    for (uint32_t i = 0; i < k; i++) xn = Fr::sqr(xn);
+    Fe omega;
+    {
+        const uint64_t rl[4] = BN254_FR_ROOT_OF_UNITY_M;
+        for (int i = 0; i < 8; i++) omega.v[i] = (uint32_t)(rl[i >> 1] >> (32 * (i & 1)));
+        for (uint32_t i = k; i < 28; i++) omega = Fr::sqr(omega);
+    }
+    const Fe omega_inv = Fr::inv(omega);
+    auto rot = [&](int32_t r) { return Fr::mul(x, r >= 0 ? fe_pow_u64(omega, (uint64_t)r) : fe_pow_u64(omega_inv, (uint64_t)(-(int64_t)r))); };
+    void* h_poly = mem.get(col_bytes);
+    if (!h_poly) return ZK_ERR_HIP;
+    {
+        std::vector<uint64_t> sc((size_t)n_pieces * 4);
+        Fe p = Fr::one();
+        for (uint32_t i = 0; i < n_pieces; i++) { memcpy(&sc[4 * i], p.v, 32); p = Fr::mul(p, xn); }
+        PK(zk_fr_lincomb_dev(ctx, (const void* const*)pieces.data(), sc.data(), n_pieces, n, h_poly));
+    }
+    const Fe x_last = rot(-(int32_t)(bf + 1)), x_next = rot(1), x_prev = rot(-1);
+    std::vector<Query> q;
+    for (uint32_t i = 0; i < pk->n_advice_queries; i++) q.push_back({adv[pk->advice_queries[2 * i]], rot((int32_t)pk->advice_queries[2 * i + 1]), Fr::zero()});
+    for (uint32_t i = 0; i < pk->n_fixed_queries; i++) q.push_back({pk->fixed_polys[pk->fixed_queries[2 * i]], rot((int32_t)pk->fixed_queries[2 * i + 1]), Fr::zero()});
+    q.push_back({random_poly, x, Fr::zero()});
+    for (uint32_t j = 0; j < pk->n_perm_columns; j++) q.push_back({pk->sigma_polys[j], x, Fr::zero()});
+    for (uint32_t s = 0; s < n_sets; s++) {
+        q.push_back({zs[s], x, Fr::zero()});
+        q.push_back({zs[s], x_next, Fr::zero()});
+        if (s + 1 < n_sets) q.push_back({zs[s], x_last, Fr::zero()});
+    }
+    for (uint32_t l = 0; l < L; l++) {
+        q.push_back({lzs[l], x, Fr::zero()}); q.push_back({lzs[l], x_next, Fr::zero()});
+        q.push_back({pin[l], x, Fr::zero()}); q.push_back({pin[l], x_prev, Fr::zero()});
+        q.push_back({ptab[l], x, Fr::zero()});
+    }
+    q.push_back({h_poly, x, Fr::zero()});
+    {
+        std::vector<const void*> polys(q.size());
+        std::vector<uint64_t> pts(q.size() * 4), ev(q.size() * 4);
+        for (size_t i = 0; i < q.size(); i++) { polys[i] = q[i].poly; memcpy(&pts[4 * i], q[i].point.v, 32); }
+        PK(zk_eval_polynomial_batch_dev(ctx, polys.data(), q.size(), n, pts.data(), ev.data()));
+        for (size_t i = 0; i < q.size(); i++) q[i].eval = load32(&ev[4 * i]);
+        for (size_t i = 0; i + 1 < q.size(); i++) tr.write_scalar(q[i].eval);            // h's evaluation is the verifier's to derive
+    }
+    // ---- 9. ProverSHPLONK: queries in the multi-open order ---------------------------------------------------------------------------------------------------------------
+    std::vector<Query> mq;
+    {
+        size_t it = 0;
+        std::vector<Query> q_adv(q.begin(), q.begin() + pk->n_advice_queries); it += pk->n_advice_queries;
+        std::vector<Query> q_fix(q.begin() + it, q.begin() + it + pk->n_fixed_queries); it += pk->n_fixed_queries;
+        const Query q_rand = q[it++];
+        std::vector<Query> q_sig(q.begin() + it, q.begin() + it + pk->n_perm_columns); it += pk->n_perm_columns;
+        std::vector<Query> q_pa, q_pl;
+        for (uint32_t s = 0; s < n_sets; s++) { q_pa.push_back(q[it++]); q_pa.push_back(q[it++]); if (s + 1 < n_sets) q_pl.push_back(q[it++]); }
+        std::vector<Query> q_lk;
+        for (uint32_t l = 0; l < L; l++) {
+            const Query pz = q[it], pzn = q[it + 1], pa = q[it + 2], pai = q[it + 3], ps = q[it + 4];
+            it += 5;
+            q_lk.push_back(pz); q_lk.push_back(pa); q_lk.push_back(ps); q_lk.push_back(pai); q_lk.push_back(pzn);      // lookup::Evaluated::open order
+        }
+        const Query q_h = q[it++];
+        mq = q_adv;
+        mq.insert(mq.end(), q_pa.begin(), q_pa.end());
+        mq.insert(mq.end(), q_pl.rbegin(), q_pl.rend());
+        mq.insert(mq.end(), q_lk.begin(), q_lk.end());
+        mq.insert(mq.end(), q_fix.begin(), q_fix.end());
+        mq.insert(mq.end(), q_sig.begin(), q_sig.end());
+        mq.push_back(q_h); mq.push_back(q_rand);
+    }
+    const Fe yy = tr.squeeze();
+    // construct_intermediate_sets: commitments (by polynomial) in first-appearance order, their point sets ascending by canonical value, sets in first-appearance order
+    struct Com { const void* poly; std::map<u256, Fe, CanonLess> pts; };          // canonical point -> eval
+    std::vector<Com> coms;
+    std::map<u256, Fe, CanonLess> super;                                          // canonical -> Montgomery point
+    for (auto& qq : mq) {
+        const u256 cp = Fr::from_mont(qq.point);
+        super.emplace(cp, qq.point);
+        size_t ci = 0;
+        while (ci < coms.size() && coms[ci].poly != qq.poly) ci++;
+        if (ci == coms.size()) coms.push_back(Com{qq.poly, {}});
+        coms[ci].pts.emplace(cp, qq.eval);
+    }
+    struct RSet { std::vector<u256> keys; std::vector<size_t> members; };
+    std::vector<RSet> sets;
+    for (size_t ci = 0; ci < coms.size(); ci++) {
+        std::vector<u256> keys;
+        for (auto& kv : coms[ci].pts) keys.push_back(kv.first);
+        size_t si = 0;
+        for (; si < sets.size(); si++) {
+            if (sets[si].keys.size() != keys.size()) continue;
+            bool same = true;
+            for (size_t i = 0; i < keys.size() && same; i++) same = Fr::eq(sets[si].keys[i], keys[i]);
+            if (same) break;
+        }
+        if (si == sets.size()) sets.push_back(RSet{keys, {}});
+        sets[si].members.push_back(ci);
+    }
+    const Fe v = tr.squeeze();
+    size_t pad = 1;
+    for (auto& s : sets) pad = std::max(pad, s.keys.size());
+    void* rbuf = mem.get(col_bytes);
+    void* tmp0 = mem.get(col_bytes);
+    void* tmp1 = mem.get(col_bytes);
+    if (!rbuf || !tmp0 || !tmp1) return ZK_ERR_HIP;
+    {
+        std::vector<uint64_t> zeros(n * 4, 0);
+        PK(zk_dev_upload(ctx, rbuf, zeros.data(), col_bytes));
+    }
+    const std::vector<uint64_t> zero_tail(pad * 4, 0);
+    std::vector<void*> quotients;
+    std::vector<std::vector<std::vector<Fe>>> low(sets.size());                    // per set, per member: r(X) coefficients
+    for (size_t si = 0; si < sets.size(); si++) {
+        const RSet& s = sets[si];
+        std::vector<Fe> pts;
+        for (auto& key : s.keys) pts.push_back(super[key]);
+        std::vector<Fe> rsum(pts.size(), Fr::zero());
+        std::vector<const void*> polys;
+        std::vector<uint64_t> scal;
+        Fe ypow = Fr::one();
+        for (size_t ci : s.members) {
+            std::vector<Fe> evals;
+            for (auto& key : s.keys) evals.push_back(coms[ci].pts[key]);
+            const std::vector<Fe> r = lagrange_interpolate(pts, evals);
+            for (size_t i = 0; i < r.size(); i++) rsum[i] = Fr::sub(rsum[i], Fr::mul(ypow, r[i]));
+            low[si].push_back(r);
+            polys.push_back(coms[ci].poly);
+            scal.insert(scal.end(), (const uint64_t*)ypow.v, (const uint64_t*)ypow.v + 4);
+            ypow = Fr::mul(ypow, yy);
+        }
+        std::vector<uint64_t> rs(pad * 4, 0);
+        for (size_t i = 0; i < rsum.size(); i++) memcpy(&rs[4 * i], rsum[i].v, 32);
+        PK(zk_dev_upload(ctx, rbuf, rs.data(), pad * 32));
+        polys.push_back(rbuf);
+        scal.insert(scal.end(), (const uint64_t*)one.v, (const uint64_t*)one.v + 4);
+        PK(zk_fr_lincomb_dev(ctx, polys.data(), scal.data(), polys.size(), n, tmp0));
+        void* cur = tmp0; void* oth = tmp1;
+        size_t ln = n;
+        for (auto& p : pts) { PK(zk_kate_division_dev(ctx, cur, ln, p.v, oth)); std::swap(cur, oth); ln--; }
+        void* qi = mem.get(col_bytes);
+        if (!qi) return ZK_ERR_HIP;
+        PK(zk_fr_scale_dev(ctx, cur, one.v, qi, ln));
+        if (n > ln) PK(zk_dev_upload(ctx, (char*)qi + ln * 32, zero_tail.data(), (n - ln) * 32));
+        quotients.push_back(qi);
+    }
+    std::vector<Fe> vp(sets.size());
+    { Fe p = Fr::one(); for (size_t i = 0; i < sets.size(); i++) { vp[i] = p; p = Fr::mul(p, v); } }
+    void* h_x = mem.get(col_bytes);
+    if (!h_x) return ZK_ERR_HIP;
+    {
+        std::vector<uint64_t> sc(sets.size() * 4);
+        for (size_t i = 0; i < sets.size(); i++) memcpy(&sc[4 * i], vp[i].v, 32);
+        PK(zk_fr_lincomb_dev(ctx, (const void* const*)quotients.data(), sc.data(), quotients.size(), n, h_x));
+    }
+    PK(commit(pk->srs_g, {h_x}));
+    const Fe u = tr.squeeze();
+    {
+        std::vector<Fe> super_pts;
+        for (auto& kv : super) super_pts.push_back(kv.second);
+        std::vector<Fe> z_diffs(sets.size());
+        std::vector<const void*> polys;
+        std::vector<Fe> scal;
+        Fe cst = Fr::zero();
+        for (size_t si = 0; si < sets.size(); si++) {
+            std::vector<Fe> diffs;
+            for (auto& kv : super) {
+                bool in_set = false;
+                for (auto& key : sets[si].keys) in_set |= Fr::eq(key, kv.first);
+                if (!in_set) diffs.push_back(kv.second);
+            }
+            z_diffs[si] = vanishing_at(diffs, u);
+            Fe ypow = Fr::one();
+            for (size_t m = 0; m < sets[si].members.size(); m++) {
+                const Fe w = Fr::mul(Fr::mul(vp[si], z_diffs[si]), ypow);
+                polys.push_back(coms[sets[si].members[m]].poly);
+                scal.push_back(w);
+                cst = Fr::sub(cst, Fr::mul(w, eval_small(low[si][m], u)));
+                ypow = Fr::mul(ypow, yy);
+            }
+        }
+        const Fe zt = vanishing_at(super_pts, u), z0_inv = Fr::inv(z_diffs[0]);
+        polys.push_back(h_x);
+        scal.push_back(Fr::neg(zt));
+        std::vector<uint64_t> rs(pad * 4, 0);
+        const Fe c0 = Fr::mul(cst, z0_inv);
+        memcpy(rs.data(), c0.v, 32);
+        PK(zk_dev_upload(ctx, rbuf, rs.data(), pad * 32));
+        polys.push_back(rbuf);
+        std::vector<uint64_t> sc(polys.size() * 4);
+        for (size_t i = 0; i + 1 < polys.size(); i++) { const Fe w = Fr::mul(scal[i], z0_inv); memcpy(&sc[4 * i], w.v, 32); }
+        memcpy(&sc[4 * (polys.size() - 1)], one.v, 32);
+        PK(zk_fr_lincomb_dev(ctx, polys.data(), sc.data(), polys.size(), n, tmp0));
+        PK(zk_kate_division_dev(ctx, tmp0, n, u.v, tmp1));
+        PK(zk_dev_upload(ctx, (char*)tmp1 + (n - 1) * 32, zero_tail.data(), 32));
+        PK(commit(pk->srs_g, {tmp1}));
+    }
+    *proof_len = tr.out.size();
+    if (!proof_out || proof_cap < tr.out.size()) return ZK_ERR_LIMIT;
+    memcpy(proof_out, tr.out.data(), tr.out.size());
+    return ZK_OK;
+}
+
+extern "C" int zk_plonk_trim(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_ARG;
+    Pool* p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pools_mu);
+        auto it = g_pools.find(ctx);
+        if (it == g_pools.end()) return ZK_OK;
+        p = it->second;
+        g_pools.erase(it);
+    }
+    for (auto& kv : p->free_) for (void* d : kv.second) (void)zk_dev_free(ctx, d);
+    delete p;
+    return ZK_OK;
+}

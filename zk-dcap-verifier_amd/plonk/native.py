@@ -1,0 +1,115 @@
+"""The native (C++) create_proof of the library — `zk_plonk_create_proof`, csrc/prover.hip — behind the same Python signature as plonk.create_proof.
+
+The reference's host side is compiled code (Rust: halo2_proofs::plonk::create_proof, called at circuits/src/sgx_dcap_verifier.rs:814-822); with no Rust
+toolchain in the build image its per-proof path is written in C++ on top of the C ABI, and this module only marshals a ProvingKey (keygen.py: device
+buffers and program handles) into the `zk_plonk_pk_desc` the C entry point takes.  plonk/prover.py remains as the readable twin and as the multi-GPU
+(sharded tables / coset-sharded quotient) driver; both emit identical bytes for identical inputs and draws (tests/test_native_prover.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from .._lib import _dptr
+from ..fields import rand_fr_array
+from ..kzg import ParamsKZG
+from .keygen import ProvingKey
+
+RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class PkDesc(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("extended_k", C.c_uint32), ("cs_degree", C.c_uint32), ("blinding_factors", C.c_uint32),
+                ("n_fixed", C.c_uint32), ("n_advice", C.c_uint32), ("n_instance", C.c_uint32), ("n_lookups", C.c_uint32), ("n_perm_columns", C.c_uint32),
+                ("perm_columns", C.c_void_p),
+                ("advice_queries", C.c_void_p), ("n_advice_queries", C.c_uint32),
+                ("fixed_queries", C.c_void_p), ("n_fixed_queries", C.c_uint32),
+                ("srs_g", C.c_uint64), ("srs_g_lagrange", C.c_uint64), ("program", C.c_uint64),
+                ("lookup_input_programs", C.c_void_p), ("lookup_table_programs", C.c_void_p), ("lookup_table_key", C.c_void_p),
+                ("fixed_values", C.c_void_p), ("fixed_polys", C.c_void_p), ("fixed_cosets", C.c_void_p),
+                ("sigma_values", C.c_void_p), ("sigma_polys", C.c_void_p), ("sigma_cosets", C.c_void_p),
+                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
+                ("transcript_repr", C.c_void_p)]
+
+
+class NativeProver:
+    """marshalled once per (params, pk); create_proof per proof"""
+
+    def __init__(self, params: ParamsKZG, pk: ProvingKey):
+        assert params.world == 1 and pk.coset_parts is None, "the native prover is the single-GPU path (sharded proofs: plonk.create_proof)"
+        self.params, self.pk, self.be = params, pk, pk.backend
+        cs = pk.vk.cs
+        self._keep = []
+
+        def u32(vals):
+            a = np.ascontiguousarray(np.asarray(vals, dtype=np.int64).astype(np.uint32).reshape(-1))
+            self._keep.append(a)
+            return a.ctypes.data if a.size else None
+
+        def u64(vals):
+            a = np.ascontiguousarray(np.asarray(vals, dtype=np.uint64).reshape(-1))
+            self._keep.append(a)
+            return a.ctypes.data if a.size else None
+
+        def ptrs(bufs):
+            arr = (C.c_void_p * max(1, len(bufs)))(*[_dptr(b) for b in bufs])
+            self._keep.append(arr)
+            return C.cast(arr, C.c_void_p).value
+        keys, key_ids = {}, []
+        for lk in cs.lookups:
+            key_ids.append(keys.setdefault(tuple(lk.table_expressions), len(keys)))
+        repr_bytes = np.frombuffer(int(pk.vk.transcript_repr).to_bytes(32, "little"), dtype=np.uint8).copy()
+        self._keep.append(repr_bytes)
+        d = PkDesc()
+        d.k, d.extended_k, d.cs_degree, d.blinding_factors = params.k, pk.domain.extended_k, cs.degree(), cs.blinding_factors()
+        d.n_fixed, d.n_advice, d.n_instance = cs.num_fixed_columns, cs.num_advice_columns, cs.num_instance_columns
+        d.n_lookups, d.n_perm_columns = len(cs.lookups), len(cs.permutation_columns)
+        d.perm_columns = u32([v for t, i in cs.permutation_columns for v in (t, i)])
+        aq, fq = cs.advice_queries(), cs.fixed_queries()
+        d.advice_queries, d.n_advice_queries = u32([v for c, r in aq for v in (c, r)]), len(aq)
+        d.fixed_queries, d.n_fixed_queries = u32([v for c, r in fq for v in (c, r)]), len(fq)
+        d.srs_g, d.srs_g_lagrange, d.program = params.g.handle, params.g_lagrange.handle, pk.evaluator.handle
+        d.lookup_input_programs = u64([a.handle for a, _ in pk.lookup_compressors])
+        d.lookup_table_programs = u64([b.handle for _, b in pk.lookup_compressors])
+        d.lookup_table_key = u32(key_ids)
+        d.fixed_values, d.fixed_polys, d.fixed_cosets = ptrs(pk.fixed_values), ptrs(pk.fixed_polys), ptrs(pk.fixed_cosets)
+        d.sigma_values, d.sigma_polys, d.sigma_cosets = ptrs(pk.sigma_values), ptrs(pk.sigma_polys), ptrs(pk.sigma_cosets)
+        d.l0, d.l_last, d.l_active_row = _dptr(pk.l0), _dptr(pk.l_last), _dptr(pk.l_active_row)
+        d.transcript_repr = repr_bytes.ctypes.data
+        self.desc = d
+        self.proof_cap = 32 * (cs.num_advice_columns + 3 * len(cs.lookups) + len(cs.permutation_columns) + 16 +
+                               len(aq) + len(fq) + 1 + len(cs.permutation_columns) + 3 * len(cs.permutation_columns) + 5 * len(cs.lookups) + 8)
+
+    def create_proof(self, advice: Sequence, instances: Sequence[Sequence[int]], rng) -> bytes:
+        """advice: host (n, 4) uint64 arrays (page-locked or ordinary) or device buffers — all of one kind; instances: canonical ints per instance column;
+        rng: numpy Generator (seeded) or fields.OsRng().  Returns the proof bytes."""
+        be, d = self.be, self.desc
+        on_device = not isinstance(advice[0], np.ndarray) if len(advice) else False
+        keep = [np.ascontiguousarray(a, dtype=np.uint64) for a in advice] if not on_device else []
+        adv = (C.c_void_p * max(1, len(advice)))(*([a.ctypes.data for a in keep] if not on_device else [_dptr(a) for a in advice]))
+        inst = [np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in col) or bytes(32), dtype=np.uint8).copy() for col in instances]
+        inst_ptrs = (C.c_void_p * max(1, len(inst)))(*[a.ctypes.data for a in inst])
+        lens = (C.c_uint32 * max(1, len(inst)))(*[len(col) for col in instances])
+        errors = []
+
+        def draw(_user, count, out):                                   # the caller's Fr::random: same sampler, same order as the Python twin
+            try:
+                a = rand_fr_array(rng, int(count))
+                C.memmove(out, a.ctypes.data, a.nbytes)
+            except BaseException as e:                                  # never let an exception cross the FFI
+                errors.append(e)
+        cb = RNG_FN(draw)
+        out = np.empty(self.proof_cap, dtype=np.uint8)
+        ln = C.c_size_t()
+        rc = be.lib.zk_plonk_create_proof(be.ctx, C.byref(d), adv, C.c_int(1 if on_device else 0), inst_ptrs, lens, cb, None,
+                                          out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(ln))
+        if errors:
+            raise errors[0]
+        be._ck(rc)
+        return out[: ln.value].tobytes()
+
+
+def create_proof_native(params: ParamsKZG, pk: ProvingKey, advice, instances, rng) -> bytes:
+    return NativeProver(params, pk).create_proof(advice, instances, rng)

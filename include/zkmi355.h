@@ -64,6 +64,7 @@ int zk_dev_free(zk_ctx* ctx, void* dptr);
 int zk_dev_upload(zk_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int zk_dev_download(zk_ctx* ctx, void* host, const void* dptr, size_t bytes);
 int zk_dev_copy(zk_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);   /* device -> device */
+int zk_dev_zero(zk_ctx* ctx, void* dptr, size_t bytes);                           /* zero bytes (= Fr zero), ordered on the context's stream */
 int zk_dev_sync(zk_ctx* ctx);
 /* The witness crosses the boundary once per proof (create_proof receives host-owned circuits: sgx_dcap_verifier.rs:814-822, `&[circuit]`; halo2's prover
  * holds the synthesised advice columns as host Vec<Fr>).  zk_host_alloc hands out page-locked host memory the shim can synthesise / batch-invert the
@@ -297,6 +298,9 @@ typedef void (*zk_rng_fn)(void* user, size_t n, void* out_fr);
  * (e.g. ZK_ERR_ARG from zk_lookup_permute_batch_dev for a lookup input outside its table: halo2's Error::ConstraintSystemFailure). */
 int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
                           const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len);
+/* wall milliseconds of the nine phases (instances, advice, lookups, grand products, random poly, h numerator, h commit, evaluations, SHPLONK) of the
+ * calling thread's last zk_plonk_create_proof */
+int zk_plonk_last_phase_ms(double out[9]);
 /* return the per-proof device buffers zk_plonk_create_proof keeps for reuse on this context (call before zk_ctx_destroy) */
 int zk_plonk_trim(zk_ctx* ctx);
 

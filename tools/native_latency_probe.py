@@ -32,4 +32,10 @@ for name in ("native", "python", "native", "python"):
         ts.append(round((time.time() - t) * 1e3, 2))
     out.setdefault(name, []).append(ts)
 out["same_bytes"] = proof == proof2
+out["native_phase_ms"] = native.phase_ms
+tm = {}
+for w, m in zip(work, master):
+    w.copy_from(m)
+tr = Blake2bWrite(); z.plonk.create_proof(params, pk, work, [], np.random.default_rng(1), tr, timings=tm)
+out["python_phase_ms"] = {k_: round(v, 2) for k_, v in tm.items()}
 print(json.dumps(out))

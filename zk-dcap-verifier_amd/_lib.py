@@ -80,6 +80,14 @@ class DeviceBuffer:
         b._ck(b.lib.zk_dev_upload(b.ctx, C.c_void_p(self.ptr + offset), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
         return self
 
+    def zero(self, offset: int = 0, nbytes: int | None = None):
+        """zk_dev_zero: Fr zeros written on the device (no host buffer crosses the link)"""
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        assert offset + nbytes <= self.nbytes
+        b = self.backend
+        b._ck(b.lib.zk_dev_zero(b.ctx, C.c_void_p(self.ptr + offset), C.c_size_t(nbytes)))
+        return self
+
     def download(self, shape, dtype=np.uint64, offset: int = 0) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
         assert offset + out.nbytes <= self.nbytes

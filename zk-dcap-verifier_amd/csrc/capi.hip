@@ -153,6 +153,10 @@ int zk_dev_copy(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
     ENTER; if ((!dst || !src) && bytes) return ctx->fail(ZK_ERR_ARG, "zk_dev_copy: null");
     ZK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream)); ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
 }
+int zk_dev_zero(zk_ctx* ctx, void* dptr, size_t bytes) {
+    ENTER; if (!dptr && bytes) return ctx->fail(ZK_ERR_ARG, "zk_dev_zero: null");
+    ZK_HIP(hipMemsetAsync(dptr, 0, bytes, ctx->stream)); return ZK_OK;          // stream-ordered like every kernel of the context
+}
 int zk_dev_sync(zk_ctx* ctx) { ENTER; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
 // page-locked staging memory for the columns the caller hands over every proof (the witness): DMA reads it at link rate, no bounce buffer
 int zk_host_alloc(zk_ctx* ctx, size_t bytes, void** hptr) {

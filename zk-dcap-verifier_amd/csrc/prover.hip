@@ -8,6 +8,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -179,9 +180,11 @@ struct Draws {
 
 struct Query { const void* poly; Fe point; Fe eval; };                 // ProverQuery { point, poly } + its evaluation
 
-std::vector<Fe> lagrange_interpolate(const std::vector<Fe>& pts, const std::vector<Fe>& evals) {
+// coefficients of the Lagrange basis polynomials of a point set: every commitment of a rotation set is interpolated over the SAME points, so the products
+// and the field inversions (one Fermat exponentiation each on the host) are done once per set
+std::vector<std::vector<Fe>> lagrange_basis(const std::vector<Fe>& pts) {
     const size_t n = pts.size();
-    std::vector<Fe> coeffs(n, Fr::zero());
+    std::vector<std::vector<Fe>> basis(n);
     for (size_t j = 0; j < n; j++) {
         std::vector<Fe> num{Fr::one()};
         Fe den = Fr::one();
@@ -194,15 +197,32 @@ std::vector<Fe> lagrange_interpolate(const std::vector<Fe>& pts, const std::vect
             num.swap(nx);
             den = Fr::mul(den, Fr::sub(pts[j], pts[m]));
         }
-        const Fe sc = Fr::mul(evals[j], Fr::inv(den));
-        for (size_t i = 0; i < num.size(); i++) coeffs[i] = Fr::add(coeffs[i], Fr::mul(num[i], sc));
+        const Fe sc = Fr::inv(den);
+        basis[j].resize(n);
+        for (size_t i = 0; i < n; i++) basis[j][i] = Fr::mul(num[i], sc);
     }
+    return basis;
+}
+std::vector<Fe> interpolate_with_basis(const std::vector<std::vector<Fe>>& basis, const std::vector<Fe>& evals) {
+    const size_t n = basis.size();
+    std::vector<Fe> coeffs(n, Fr::zero());
+    for (size_t j = 0; j < n; j++) for (size_t i = 0; i < n; i++) coeffs[i] = Fr::add(coeffs[i], Fr::mul(evals[j], basis[j][i]));
     return coeffs;
 }
 Fe eval_small(const std::vector<Fe>& c, const Fe& x) { Fe acc = Fr::zero(); for (size_t i = c.size(); i-- > 0;) acc = Fr::add(Fr::mul(acc, x), c[i]); return acc; }
 Fe vanishing_at(const std::vector<Fe>& roots, const Fe& z) { Fe acc = Fr::one(); for (auto& r : roots) acc = Fr::mul(acc, Fr::sub(z, r)); return acc; }
 
 #define PK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+thread_local double g_phase_ms[9];                                    // wall time of the phases of the calling thread's last proof (zk_plonk_last_phase_ms)
+struct PhaseClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(int phase) {
+        const auto now = std::chrono::steady_clock::now();
+        g_phase_ms[phase] += std::chrono::duration<double, std::milli>(now - t).count();
+        t = now;
+    }
+};
 
 }  // namespace
 
@@ -219,6 +239,8 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     Arena mem(ctx);
     Transcript tr;
     Draws draws;
+    for (double& v : g_phase_ms) v = 0;
+    PhaseClock clk;
     // draw sizes in the mirror's order: advice blinding (one draw per column), then bi / bt per lookup, permutation sets, lookup products, the random polynomial
     for (uint32_t i = 0; i < pk->n_advice; i++) draws.counts.push_back(n - usable);
     const size_t d_bi = draws.counts.size(); for (uint32_t l = 0; l < L; l++) draws.counts.push_back(bf + 1);
@@ -234,7 +256,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     for (uint32_t c = 0; c < pk->n_instance; c++) {
         const uint32_t len = instance_lens ? instance_lens[c] : 0;
         if (len > usable) return ZK_ERR_ARG;
-        std::vector<uint64_t> col(n * 4, 0);
+        std::vector<uint64_t> col((size_t)len * 4);
         for (uint32_t i = 0; i < len; i++) {
             const Fe v = Fr::to_mont(load32((const char*)instances[c] + 32 * i));
             tr.common_scalar(v);
@@ -242,9 +264,11 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         }
         void* d = mem.get(col_bytes);
         if (!d) return ZK_ERR_HIP;
-        PK(zk_dev_upload(ctx, d, col.data(), col_bytes));
+        PK(zk_dev_zero(ctx, d, col_bytes));
+        if (len) PK(zk_dev_upload(ctx, d, col.data(), (size_t)len * 32));
         inst_values.push_back(d);
     }
+    clk.lap(0);
     // ---- 2. advice: upload (host columns), blind, commit ------------------------------------------------------------------------------------------------
     std::vector<void*> adv(pk->n_advice);
     {
@@ -268,6 +292,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         return ZK_OK;
     };
     PK(commit(pk->srs_g_lagrange, adv));
+    clk.lap(1);
     // ---- 3. theta; lookups: compress, permute, commit ---------------------------------------------------------------------------------------------------
     const Fe theta = tr.squeeze();
     const Fe one = Fr::one();
@@ -306,6 +331,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         for (uint32_t l = 0; l < L; l++) { flat.push_back(pin[l]); flat.push_back(ptab[l]); }
         PK(commit(pk->srs_g_lagrange, flat));
     }
+    clk.lap(2);
     // ---- 4. beta, gamma; grand products -------------------------------------------------------------------------------------------------------------------
     const Fe beta = tr.squeeze(), gamma = tr.squeeze();
     std::vector<void*> zs(n_sets), lzs(L);
@@ -333,11 +359,13 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         both.insert(both.end(), lzs.begin(), lzs.end());
         PK(commit(pk->srs_g_lagrange, both));
     }
+    clk.lap(3);
     // ---- 5. vanishing argument: random polynomial ------------------------------------------------------------------------------------------------------------
     void* random_poly = mem.get(col_bytes);
     if (!random_poly) return ZK_ERR_HIP;
     PK(zk_dev_upload(ctx, random_poly, draws.take(d_rp), col_bytes));
     PK(commit(pk->srs_g, {random_poly}));
+    clk.lap(4);
     // ---- 6. y; coefficient form; extended cosets; h(X) numerator ----------------------------------------------------------------------------------------------
     const Fe y = tr.squeeze();
     std::vector<void*> lag(adv);
@@ -365,12 +393,14 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         PK(zk_quotient_run_dev(ctx, pk->program, &a));
         for (auto e : ext) mem.give_back(e);
     }
+    clk.lap(5);
     // ---- 7. divide, back to coefficients, commit the pieces ---------------------------------------------------------------------------------------------------------
     PK(zk_divide_by_vanishing_poly_dev(ctx, h_ext, k, ek));
     PK(zk_extended_to_coeff_dev(ctx, h_ext, k, ek));
     std::vector<void*> pieces(n_pieces);
     for (uint32_t i = 0; i < n_pieces; i++) pieces[i] = (char*)h_ext + (size_t)i * col_bytes;
     PK(commit(pk->srs_g, pieces));
+    clk.lap(6);
     // ---- 8. x; evaluations ------------------------------------------------------------------------------------------------------------------------------------------------
     const Fe x = tr.squeeze();
     Fe xn = x;
@@ -416,6 +446,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         for (size_t i = 0; i < q.size(); i++) q[i].eval = load32(&ev[4 * i]);
         for (size_t i = 0; i + 1 < q.size(); i++) tr.write_scalar(q[i].eval);            // h's evaluation is the verifier's to derive
     }
+    clk.lap(7);
     // ---- 9. ProverSHPLONK: queries in the multi-open order ---------------------------------------------------------------------------------------------------------------
     std::vector<Query> mq;
     {
@@ -476,11 +507,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     void* tmp0 = mem.get(col_bytes);
     void* tmp1 = mem.get(col_bytes);
     if (!rbuf || !tmp0 || !tmp1) return ZK_ERR_HIP;
-    {
-        std::vector<uint64_t> zeros(n * 4, 0);
-        PK(zk_dev_upload(ctx, rbuf, zeros.data(), col_bytes));
-    }
-    const std::vector<uint64_t> zero_tail(pad * 4, 0);
+    PK(zk_dev_zero(ctx, rbuf, col_bytes));
     std::vector<void*> quotients;
     std::vector<std::vector<std::vector<Fe>>> low(sets.size());                    // per set, per member: r(X) coefficients
     for (size_t si = 0; si < sets.size(); si++) {
@@ -491,10 +518,11 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         std::vector<const void*> polys;
         std::vector<uint64_t> scal;
         Fe ypow = Fr::one();
+        const std::vector<std::vector<Fe>> basis = lagrange_basis(pts);
         for (size_t ci : s.members) {
             std::vector<Fe> evals;
             for (auto& key : s.keys) evals.push_back(coms[ci].pts[key]);
-            const std::vector<Fe> r = lagrange_interpolate(pts, evals);
+            const std::vector<Fe> r = interpolate_with_basis(basis, evals);
             for (size_t i = 0; i < r.size(); i++) rsum[i] = Fr::sub(rsum[i], Fr::mul(ypow, r[i]));
             low[si].push_back(r);
             polys.push_back(coms[ci].poly);
@@ -513,7 +541,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         void* qi = mem.get(col_bytes);
         if (!qi) return ZK_ERR_HIP;
         PK(zk_fr_scale_dev(ctx, cur, one.v, qi, ln));
-        if (n > ln) PK(zk_dev_upload(ctx, (char*)qi + ln * 32, zero_tail.data(), (n - ln) * 32));
+        if (n > ln) PK(zk_dev_zero(ctx, (char*)qi + ln * 32, (n - ln) * 32));
         quotients.push_back(qi);
     }
     std::vector<Fe> vp(sets.size());
@@ -564,15 +592,21 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         memcpy(&sc[4 * (polys.size() - 1)], one.v, 32);
         PK(zk_fr_lincomb_dev(ctx, polys.data(), sc.data(), polys.size(), n, tmp0));
         PK(zk_kate_division_dev(ctx, tmp0, n, u.v, tmp1));
-        PK(zk_dev_upload(ctx, (char*)tmp1 + (n - 1) * 32, zero_tail.data(), 32));
+        PK(zk_dev_zero(ctx, (char*)tmp1 + (n - 1) * 32, 32));
         PK(commit(pk->srs_g, {tmp1}));
     }
+    clk.lap(8);
     *proof_len = tr.out.size();
     if (!proof_out || proof_cap < tr.out.size()) return ZK_ERR_LIMIT;
     memcpy(proof_out, tr.out.data(), tr.out.size());
     return ZK_OK;
 }
 
+extern "C" int zk_plonk_last_phase_ms(double out[9]) {
+    if (!out) return ZK_ERR_ARG;
+    for (int i = 0; i < 9; i++) out[i] = g_phase_ms[i];
+    return ZK_OK;
+}
 extern "C" int zk_plonk_trim(zk_ctx* ctx) {
     if (!ctx) return ZK_ERR_ARG;
     Pool* p = nullptr;

@@ -108,6 +108,10 @@ class NativeProver:
         if errors:
             raise errors[0]
         be._ck(rc)
+        ph = (C.c_double * 9)()
+        be.lib.zk_plonk_last_phase_ms(ph)
+        self.phase_ms = dict(zip(("1_instances", "2_advice_commit", "3_lookup_permuted", "4_grand_products", "5_random_poly", "6_ntt_evaluate_h", "7_h_construct_commit",
+                                  "8_evaluations", "9_shplonk"), [round(v, 2) for v in ph]))
         return out[: ln.value].tobytes()
 
 

@@ -108,8 +108,7 @@ class ProverSHPLONK:
         v = transcript.squeeze_challenge()
 
         pad = max(len(pts) for pts, _ in rotation_sets)              # largest rotation set: coefficients of the low-degree corrections / truncated tail
-        zero_tail = np.zeros((pad, 4), dtype=np.uint64)
-        rbuf = be.to_device(np.zeros((n, 4), dtype=np.uint64))        # carries the low-degree corrections (zero beyond a few coefficients)
+        rbuf = be.alloc(n * 32).zero()                                # carries the low-degree corrections (zero beyond a few coefficients)
         one = fr_mont(1)
         quotients, tmp = [], [be.alloc(n * 32), be.alloc(n * 32)]
         # Q_i(X) = sum_j y^j (P_ij(X) - R_ij(X)) / Z_i(X)
@@ -136,7 +135,7 @@ class ProverSHPLONK:
                 ln -= 1
             qi = be.alloc(n * 32)
             be.fr_scale_dev(tmp[cur], one, qi, ln)
-            qi.upload(zero_tail[: n - ln], offset=ln * 32)           # poly.resize(n, 0)
+            qi.zero(ln * 32, (n - ln) * 32)                          # poly.resize(n, 0)
             quotients.append(qi)
         vp = [pow(v, i, R_MOD) for i in range(len(quotients))]
         h_x = be.alloc(n * 32)
@@ -167,7 +166,7 @@ class ProverSHPLONK:
         rbuf.upload(fr_mont_array([const * z0_inv % R_MOD] + [0] * (pad - 1)))
         be.fr_lincomb_dev(polys + [rbuf], fr_mont_array([s * z0_inv % R_MOD for s in scal] + [1]), n, tmp[0])
         be.kate_division_dev(tmp[0], n, fr_mont(u), tmp[1])
-        tmp[1].upload(zero_tail[:1], offset=(n - 1) * 32)
+        tmp[1].zero((n - 1) * 32, 32)
         transcript.write_point(g1_affine_ints(self.params.commit_columns("g", [tmp[1]])[0]))
         for d in (h_x, rbuf, tmp[0], tmp[1]):
             d.free()

@@ -102,7 +102,7 @@ pub fn gpu() -> Option<&'static Gpu> {
 }
 
 impl Gpu {
-    fn complain(&self, what: &str) {
+    pub(crate) fn complain(&self, what: &str) {
         let msg = unsafe { CStr::from_ptr(zk_last_error(self.ctx)) };
         eprintln!("mi355x: {what} failed ({msg:?}); falling back to the CPU body");
     }

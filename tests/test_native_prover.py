@@ -66,6 +66,51 @@ def test_native_prover_refuses_a_lookup_input_outside_the_table(emu, orc):
     params.release()
 
 
+def test_native_prover_reports_a_short_output_buffer_and_its_phase_clock(emu, orc):
+    """proof_cap too small -> ZK_ERR_LIMIT with the needed length reported, nothing written past the buffer; the phase clock covers the nine phases"""
+    cs, fixed, asm, advice, instances = tcp.toy_circuit(5)
+    params = z.kzg.ParamsKZG.setup(5, tcp.TAU, backend=emu)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    native = plonk.NativeProver(params, pk)
+    proof = native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(2))
+    assert len(native.phase_ms) == 9 and all(v >= 0 for v in native.phase_ms.values()) and sum(native.phase_ms.values()) > 0
+    native.proof_cap = len(proof) - 32
+    with pytest.raises(z.ZkError):
+        native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(2))
+    native.proof_cap = len(proof)                                    # exactly enough
+    assert native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(2)) == proof
+    pk.release()
+    params.release()
+
+
+def test_native_provers_on_two_contexts_in_threads(built, orc):
+    """one context + host thread per proof in flight (the bench's throughput mode): the second context borrows the first one's SRS tables; same bytes"""
+    import threading
+    from conftest import EMU_SO
+    a, b = z.Backend(0, lib_path=EMU_SO), z.Backend(0, lib_path=EMU_SO)
+    for be in (a, b):
+        be.tune(msm_sort_threads=64, msm_sort_wgs=3, msm_block=32, msm_target_threads=64, msm_min_chunk=2, vec_block=32)
+    cs, fixed, asm, advice, instances = tcp.toy_circuit(6)
+    pa = z.kzg.ParamsKZG.setup(6, tcp.TAU, backend=a)
+    pb = z.kzg.ParamsKZG.shared_with(pa, b)
+    out = {}
+
+    def run(name, params):
+        pk = plonk.keygen(params, cs, fixed, asm)
+        out[name] = plonk.NativeProver(params, pk).create_proof([c.copy() for c in advice], instances, np.random.default_rng(7))
+        pk.release()
+    ts = [threading.Thread(target=run, args=(n, p)) for n, p in (("a", pa), ("b", pb))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert out["a"] == out["b"] == tcp._golden(tcp.GOLDEN_PROOF)
+    pb.release()
+    pa.release()
+    b.close()
+    a.close()
+
+
 @pytest.mark.gpu
 def test_native_prover_goldens_gpu(gpu, orc):
     assert _toy(gpu, 6, 7) == tcp._golden(tcp.GOLDEN_PROOF)

@@ -241,6 +241,10 @@ int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args
  * (zk_coeff_to_coset_batch_dev), args->out receives the coset's n numerator values.  The 2^(extended_k-k) cosets are independent, so the quotient of a
  * proof can be split over GPUs; zk_fr_interleave_dev puts the gathered cosets back into the order Evaluator::evaluate_h returns. */
 int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset);
+/* ... and on a slice of that coset's rows: rows [row_lo, row_lo + row_count) — row_count a power of two dividing row_lo — with the columns still the
+ * coset's complete n values (rotations reach outside the slice); args->out receives row_count values.  This is the unit when a proof's quotient is split over
+ * MORE ranks than there are cosets (8 GPUs at extended_k = k + 2): ranks that share a coset each evaluate a part of its rows. */
+int zk_quotient_run_coset_rows_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset, uint64_t row_lo, uint64_t row_count);
 int zk_coeff_to_coset_batch_dev(zk_ctx* ctx, const void* const* coeffs_dev, void* const* outs_dev, size_t count, uint32_t k, uint32_t extended_k, uint32_t coset);
 int zk_fr_interleave_dev(zk_ctx* ctx, const void* const* cosets_dev, size_t count, size_t n, void* out_dev);   /* out[i * count + j] = cosets[j][i] */
 

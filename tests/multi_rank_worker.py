@@ -73,7 +73,11 @@ def run_sharded_proof(rank: int, world: int, port: int, out_dir: str):
     full.release()
     cs, fixed, asm, advice, instances = tcp.toy_circuit(k)
     pk = plonk.keygen(params, cs, fixed, asm)
-    assert sorted(pk.coset_parts) == params.my_cosets(1 << (pk.domain.extended_k - k))       # the quotient is sharded by coset
+    n_cosets = 1 << (pk.domain.extended_k - k)
+    assert sorted(pk.coset_parts) == params.my_cosets(n_cosets)       # the quotient is sharded by coset
+    units = params.my_units(n_cosets)
+    if world >= n_cosets and world % n_cosets == 0:                    # e.g. 8 ranks, 4 cosets: every rank owns one (coset, half of its rows) — nobody idles
+        assert len(units) == 1 and units[0][2] == (1 << k) * n_cosets // world, units
     tr = Blake2bWrite()
     plonk.create_proof(params, pk, advice, instances, np.random.default_rng(7), tr)
     ok = tr.finalize() == tcp._golden()

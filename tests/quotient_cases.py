@@ -78,7 +78,7 @@ def rand_cols(pc_mod, orc, pyref, count, size, seed):
     return [pc_mod.rand_fr(orc, pyref, size, seed + 7 * i) for i in range(count)]
 
 
-def run_case(be, orc, pyref, pc_mod, prog, seed=5):
+def run_case(be, orc, pyref, pc_mod, prog, seed=5, check_cosets=True):
     size = 1 << prog.extended_k
     chunk = prog.cs_degree - 2
     n_sets = (len(prog.perm_columns) + chunk - 1) // chunk if prog.perm_columns else 0
@@ -102,6 +102,32 @@ def run_case(be, orc, pyref, pc_mod, prog, seed=5):
                  perm_cosets=dev["perm_cosets"], perm_products=dev["perm_products"], lookup_product=dev["lookup_product"],
                  lookup_input=dev["lookup_input"], lookup_table=dev["lookup_table"], challenges=chal, beta=beta, gamma=gamma, theta=theta, y=y, out=out)
     got = out.download((size, 4))
+    # the same numerator coset by coset (zk_quotient_run_coset_dev: columns = every 2^e-th row, rotations step by one row) and on aligned slices of a
+    # coset's rows (zk_quotient_run_coset_rows_dev) — the units of the multi-GPU quotient
+    e_bits = prog.extended_k - prog.k
+    if check_cosets and e_bits >= 1:
+        n, nc = 1 << prog.k, 1 << e_bits
+        for j in ([0, nc - 1] if nc > 2 else range(nc)):
+            cdev = {k_: [be.to_device(np.ascontiguousarray(c[j::nc])) for c in v] for k_, v in cols.items()}
+            cl = [be.to_device(np.ascontiguousarray(c[j::nc])) for c in (l0, l_last, l_active)]
+            co = be.alloc(n * 32)
+            kw = dict(fixed=cdev["fixed"], advice=cdev["advice"], instance=cdev["instance"], l0=cl[0], l_last=cl[1], l_active_row=cl[2],
+                      perm_cosets=cdev["perm_cosets"], perm_products=cdev["perm_products"], lookup_product=cdev["lookup_product"],
+                      lookup_input=cdev["lookup_input"], lookup_table=cdev["lookup_table"], challenges=chal, beta=beta, gamma=gamma, theta=theta, y=y)
+            e.evaluate_h(out=co, coset=j, **kw)
+            assert (co.download((n, 4)) == want[j::nc]).all(), ("coset", j)
+            parts = 4 if n >= 4 else 1
+            rows = n // parts
+            for p_ in range(parts):
+                so = be.alloc(rows * 32)
+                e.evaluate_h(out=so, coset=j, rows=(p_ * rows, rows), **kw)
+                assert (so.download((rows, 4)) == want[j::nc][p_ * rows:(p_ + 1) * rows]).all(), ("coset rows", j, p_)
+                so.free()
+            for v in cdev.values():
+                for d in v:
+                    d.free()
+            for d in cl + [co]:
+                d.free()
     e.release()
     for v in dev.values():
         for d in v:

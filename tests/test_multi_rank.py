@@ -30,8 +30,8 @@ import pytest
 
 @pytest.mark.parametrize("world", [4, 8])
 def test_sharded_create_proof_more_ranks_than_two(built, world):
-    """4 ranks: one coset of the quotient each (the toy circuit's extended domain has 4); 8 ranks: more ranks than cosets, the extra ranks idle in
-    the quotient and still emit the golden proof."""
+    """4 ranks: one coset of the quotient each (the toy circuit's extended domain has 4); 8 ranks: more ranks than cosets — the two ranks of a coset
+    each evaluate half of its rows (zk_quotient_run_coset_rows_dev), the all-gather carries 8 half-cosets — and every rank emits the golden proof."""
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(multi_rank_worker.run_sharded_proof, args=(world, _free_port(), d), nprocs=world, join=True)
         for r in range(world):

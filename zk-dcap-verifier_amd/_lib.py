@@ -472,7 +472,8 @@ class Backend:
         self._ck(self.lib.zk_quotient_program_release(self.ctx, C.c_uint64(prog)))
 
     def quotient_run_dev(self, prog: int, *, fixed, advice, instance, l0, l_last, l_active_row, perm_cosets, perm_products,
-                         lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out, coset: int | None = None):
+                         lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out, coset: int | None = None,
+                         rows: tuple | None = None):
         keep = []
 
         def parr(cols):
@@ -488,8 +489,10 @@ class Backend:
                          ch.ctypes.data, sc[0].ctypes.data, sc[1].ctypes.data, sc[2].ctypes.data, sc[3].ctypes.data, _dptr(out))
         if coset is None:
             self._ck(self.lib.zk_quotient_run_dev(self.ctx, C.c_uint64(prog), C.byref(a)))
-        else:
+        elif rows is None:
             self._ck(self.lib.zk_quotient_run_coset_dev(self.ctx, C.c_uint64(prog), C.byref(a), C.c_uint32(coset)))
+        else:
+            self._ck(self.lib.zk_quotient_run_coset_rows_dev(self.ctx, C.c_uint64(prog), C.byref(a), C.c_uint32(coset), C.c_uint64(rows[0]), C.c_uint64(rows[1])))
 
 
 def _host_ptrs(cols):

@@ -44,7 +44,7 @@ int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* p
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
 int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]);
-int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, int coset);
+int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, int coset, uint64_t row_lo, uint64_t row_count);
 int domain_coeff_to_coset_batch(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek, uint32_t coset);
 int fr_interleave(zk_ctx* ctx, const void* const* h_cosets, size_t count, size_t n, void* d_out);
 }  // namespace zk
@@ -341,11 +341,17 @@ int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* ni, uint32_t* ns, uint32_t* nc) { ENTER; return quotient_program_info(ctx, prog, ni, ns, nc); }
 int zk_quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]) { ENTER; return quotient_program_opmix(ctx, prog, counts); }
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog) { ENTER; return quotient_program_release(ctx, prog); }
-int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args, -1); }
+int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args, -1, 0, 0); }
 int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset) {
     ENTER;
     if (coset >= (1u << 16)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_dev: coset %u out of range", coset);
-    return quotient_run(ctx, prog, args, (int)coset);
+    return quotient_run(ctx, prog, args, (int)coset, 0, 0);
+}
+int zk_quotient_run_coset_rows_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset, uint64_t row_lo, uint64_t row_count) {
+    ENTER;
+    if (coset >= (1u << 16)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_rows_dev: coset %u out of range", coset);
+    if (!row_count) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_rows_dev: row_count = 0");
+    return quotient_run(ctx, prog, args, (int)coset, row_lo, row_count);
 }
 
 int zk_pk_load(zk_ctx* ctx, uint64_t prog, const void* const* fixed, const void* const* sigma, const void* l0, const void* l_last, const void* l_active,

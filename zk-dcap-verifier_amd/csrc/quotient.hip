@@ -72,6 +72,7 @@ struct QuotArgs {
     uint32_t lo_bits;
     int uses_xpow;
     uint32_t xpow_mul, xpow_add;   // X of row idx = extended_omega^(idx * xpow_mul + xpow_add): (1, 0) on the whole extended domain, (2^(ek-k), j) on coset j
+    uint32_t row_base;             // first row of this launch (a launch may cover a slice of the rows: out[i] = numerator of row row_base + i)
     void* out;
 };
 
@@ -84,7 +85,7 @@ template <int NR>
 ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_kernel(QuotArgs q) {
     ZK_DYN_SHARED(uint4, smem);
     const uint32_t T = blockDim.x, tid = threadIdx.x;
-    const uint32_t idx0 = blockIdx.x * (T * NR) + tid;          // row r of this thread: idx0 + r * T
+    const uint32_t idx0 = q.row_base + blockIdx.x * (T * NR) + tid;   // row r of this thread: idx0 + r * T
     const uint32_t mask = (1u << q.size_log) - 1u;
     u256 acc[NR], xpow[NR], rg0[NR];                            // slot 0 lives in VGPRs
 #pragma unroll
@@ -184,7 +185,7 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_k
         ins = nxt; pa = na; pb = nb; pc_ = nc;
     }
 #pragma unroll
-    for (int r = 0; r < NR; r++) store_u256(q.out, idx0 + r * T, acc[r]);
+    for (int r = 0; r < NR; r++) store_u256(q.out, idx0 - q.row_base + r * T, acc[r]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -726,7 +727,9 @@ int quotient_set_lds_attr() {
 // coset < 0: the whole extended domain (columns of 2^extended_k rows).  coset = j >= 0: only coset j of it — the rows j, j + 2^(ek-k), ... —
 // with columns given as that coset's n = 2^k values (zk_coeff_to_coset_batch_dev); rotations then step by one row.  The 2^(ek-k) cosets are
 // independent, which is what lets a proof's quotient be split over GPUs: out receives the n numerator values of the coset.
-int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int coset) {
+// row_count > 0: only rows [row_lo, row_lo + row_count) of that domain (the columns are complete, so rotations need no halo), out[i] = row row_lo + i —
+// the unit that lets more ranks than cosets share a quotient.
+int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int coset, uint64_t row_lo, uint64_t row_count) {
     auto it = ctx->programs.find(prog);
     if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_dev: unknown program %llu", (unsigned long long)prog);
     QuotProgram& P = *it->second;
@@ -790,17 +793,25 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
         int rc = ntt_pow_tables(ctx, P.ek, domain_omega(P.ek), &q.tw_lo, &q.tw_hi, &q.lo_bits);
         if (rc) return rc;
     }
+    uint64_t rows = size;
+    if (row_count) {
+        if (row_lo + row_count > size || (row_count & (row_count - 1)) || row_lo % row_count)
+            return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_rows_dev: rows [%llu, +%llu) must be an aligned power-of-two slice of the %llu rows",
+                             (unsigned long long)row_lo, (unsigned long long)row_count, (unsigned long long)size);
+        rows = row_count;
+        q.row_base = (uint32_t)row_lo;
+    }
     uint32_t T = (uint32_t)std::min(ctx->tune.quot_threads, 256);     // the kernel is compiled for <= 256 threads per workgroup
-    if (T > size) T = (uint32_t)size;
+    if (T > rows) T = (uint32_t)rows;
     const uint32_t lds_slots = P.n_slots > QUOT_NREG ? P.n_slots - QUOT_NREG : 0;
     while (T > 64 && (size_t)lds_slots * T * 32 > 32 * 1024) T >>= 1;
     if (T < 1) T = 1;
-    const uint32_t NR = (ctx->tune.quot_rows >= 2 && size % ((size_t)T * 2) == 0) ? 2u : 1u;      // rows per thread
+    const uint32_t NR = (ctx->tune.quot_rows >= 2 && rows % ((size_t)T * 2) == 0) ? 2u : 1u;      // rows per thread
     const size_t lds = (size_t)lds_slots * T * 32 * NR;
     if (lds > 160 * 1024) return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %zu bytes of LDS", lds);
     EvTimer tq(ctx, "quotient");
-    if (NR == 2) { ZK_LAUNCH(quotient_kernel<2>, (uint32_t)(size / T / 2), T, lds, st, q); }
-    else { ZK_LAUNCH(quotient_kernel<1>, (uint32_t)(size / T), T, lds, st, q); }
+    if (NR == 2) { ZK_LAUNCH(quotient_kernel<2>, (uint32_t)(rows / T / 2), T, lds, st, q); }
+    else { ZK_LAUNCH(quotient_kernel<1>, (uint32_t)(rows / T), T, lds, st, q); }
     ZK_CHECK_LAUNCH();
     tq.stop();
     ZK_HIP(hipStreamSynchronize(st));
@@ -950,7 +961,7 @@ int evaluate_h_host(zk_ctx* ctx, uint64_t pkh, const void* const* advice, const 
     qa.lookup_product = dyn + P.n_advice + P.n_instance + P.n_sets;
     qa.lookup_input = qa.lookup_product + P.n_lookups; qa.lookup_table = qa.lookup_input + P.n_lookups;
     qa.challenges = challenges; qa.beta = beta; qa.gamma = gamma; qa.theta = theta; qa.y = y; qa.out = pk->h_ext;
-    int rc = quotient_run(ctx, pk->prog, &qa, -1);
+    int rc = quotient_run(ctx, pk->prog, &qa, -1, 0, 0);
     if (rc) return rc;
     size_t out_bytes = (size_t)32 << P.ek;
     if (finish) {

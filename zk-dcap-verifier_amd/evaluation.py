@@ -118,14 +118,15 @@ class Evaluator:
         self.handle = self.backend.quotient_program_load(program.to_blob())
 
     def evaluate_h(self, *, fixed, advice, instance, l0, l_last, l_active_row, perm_cosets, perm_products,
-                   lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out, coset: int | None = None):
+                   lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out, coset: int | None = None, rows: tuple | None = None):
         """All columns are device buffers holding 2^extended_k Fr values (extended cosets);
         `out` receives the numerator of h(X) on the extended coset (before divide_by_vanishing_poly).  With `coset = j` every column holds the
-        2^k values of coset j only (coeff_to_coset) and `out` that coset's numerator values — the unit a multi-GPU prover shards by."""
+        2^k values of coset j only (coeff_to_coset) and `out` that coset's numerator values — the unit a multi-GPU prover shards by;
+        `rows = (lo, count)` restricts the run to that aligned power-of-two slice of the coset's rows (ranks that share a coset)."""
         self.backend.quotient_run_dev(self.handle, fixed=fixed, advice=advice, instance=instance, l0=l0, l_last=l_last,
                                       l_active_row=l_active_row, perm_cosets=perm_cosets, perm_products=perm_products,
                                       lookup_product=lookup_product, lookup_input=lookup_input, lookup_table=lookup_table,
-                                      challenges=challenges, beta=beta, gamma=gamma, theta=theta, y=y, out=out, coset=coset)
+                                      challenges=challenges, beta=beta, gamma=gamma, theta=theta, y=y, out=out, coset=coset, rows=rows)
 
     # -- the shape of halo2's own call: polynomials in, polynomial out -----------------------------------
     def load_pk(self, fixed, sigma, l0, l_last, l_active_row, extended: bool = False) -> int:

@@ -103,17 +103,32 @@ class ParamsKZG:
     def by_cosets(self) -> bool:
         return self.world > 1 or self.quotient_by_cosets
 
-    def my_cosets(self, n_cosets: int) -> list:
+    def quotient_parts(self, n_cosets: int) -> int:
+        """how many ranks share one coset: 1 while there are at least as many cosets as ranks; with more ranks (8 GPUs at extended_k = k + 2) every coset's
+        rows are cut into world / n_cosets aligned slices (the ranks of a coset each run the size-n NTTs of that coset and evaluate their slice of its rows)"""
+        if self.world <= n_cosets or self.world % n_cosets:
+            return 1
+        parts = self.world // n_cosets
+        return parts if parts & (parts - 1) == 0 and self.n // parts >= 1 and self.n % parts == 0 else 1
+
+    def my_units(self, n_cosets: int) -> list:
         """The extended domain is 2^(extended_k - k) interleaved cosets of the 2^k domain; evaluate_h never mixes them (rotations stay inside
-        a coset), so they are the units the quotient shards by: rank r evaluates cosets [r * slots, (r + 1) * slots), slots = ceil(cosets / world)."""
-        slots = -(-n_cosets // self.world)
-        return [j for j in range(self.rank * slots, (self.rank + 1) * slots) if j < n_cosets]
+        a coset), so the quotient shards by (coset, slice of its rows): unit u = coset u // parts, rows [(u % parts) * n / parts, +n / parts);
+        rank r evaluates units [r * slots, (r + 1) * slots), slots = ceil(units / world).  -> [(coset, row_lo, row_count)]"""
+        parts = self.quotient_parts(n_cosets)
+        units, rows = n_cosets * parts, self.n // parts
+        slots = -(-units // self.world)
+        return [(u // parts, (u % parts) * rows, rows) for u in range(self.rank * slots, (self.rank + 1) * slots) if u < units]
+
+    def my_cosets(self, n_cosets: int) -> list:
+        """the cosets this rank needs the proving key's columns on"""
+        return sorted({j for j, _, _ in self.my_units(n_cosets)})
 
     def gather_cosets(self, mine: np.ndarray, n_cosets: int) -> np.ndarray:
-        """mine: (slots, n, 4) numerator values of this rank's cosets (unused slots zero) -> (n_cosets, n, 4), every rank's, in coset order."""
+        """mine: (slots, rows, 4) numerator values of this rank's units (unused slots zero) -> (n_cosets, n, 4), every rank's, in coset order."""
         if self.world == 1:
-            return mine[:n_cosets]
-        return self.all_gather(mine).reshape(-1, mine.shape[1], 4)[:n_cosets]
+            return mine.reshape(-1, self.n, 4)[:n_cosets]
+        return self.all_gather(mine).reshape(-1, 4)[:n_cosets * self.n].reshape(n_cosets, self.n, 4)
 
     @classmethod
     def sharded(cls, k: int, g: np.ndarray, g_lagrange: np.ndarray, rank: int, world: int, all_gather, backend: Backend | None = None,

@@ -224,19 +224,25 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     else:
         # the quotient sharded by coset: this rank brings the columns to ITS cosets only (size-n NTTs), evaluates the numerator
         # there, and the ranks exchange the numerator values — the one bulk collective of a proof (n * 32 bytes per coset)
+        # (with more ranks than cosets the ranks of a coset split its ROWS: each still runs that coset's NTTs, and evaluates its slice)
         n_cosets = 1 << (ek - k)
-        slots = -(-n_cosets // params.world)
-        xch = params.coset_exchange(slots * n * 32) if params.coset_exchange is not None else None
-        mine = np.zeros((slots, n, 4), dtype=np.uint64) if xch is None else None
+        parts = params.quotient_parts(n_cosets)
+        rows = n // parts
+        slots = -(-(n_cosets * parts) // params.world)
+        xch = params.coset_exchange(slots * rows * 32) if params.coset_exchange is not None else None
+        mine = np.zeros((slots, rows, 4), dtype=np.uint64) if xch is None else None
         ext = [dev(n * 32) for _ in range(max(len(lag) + 1, n_cosets))]
         cols, num = ext[:len(lag)], ext[len(lag)]
-        for s_, j in enumerate(params.my_cosets(n_cosets)):
+        at = None
+        for s_, (j, lo, cnt) in enumerate(params.my_units(n_cosets)):
             part = pk.coset_parts[j]
-            be.coeff_to_coset_batch_dev(lag, cols, k, ek, j)
+            if j != at:
+                be.coeff_to_coset_batch_dev(lag, cols, k, ek, j)
+                at = j
             pk.evaluator.evaluate_h(fixed=part["fixed"], l0=part["l"][0], l_last=part["l"][1], l_active_row=part["l"][2], perm_cosets=part["sigma"],
-                                    out=num if xch is None else xch[0] + s_ * n * 32, coset=j, **split(cols), **scal)
+                                    out=num if xch is None else xch[0] + s_ * rows * 32, coset=j, rows=None if parts == 1 else (lo, cnt), **split(cols), **scal)
             if xch is None:
-                mine[s_] = num.download((n, 4))
+                mine[s_] = num.download((rows, 4))
         if xch is None:
             every = params.gather_cosets(mine, n_cosets)
             for j in range(n_cosets):
@@ -244,7 +250,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
             srcs = ext[:n_cosets]
         else:                                                       # device-resident exchange (RCCL all_gather on the caller's buffers)
             xch[2]()
-            srcs = [xch[1] + j * n * 32 for j in range(n_cosets)]   # rank r's block starts at r * slots * n * 32: coset order
+            srcs = [xch[1] + j * n * 32 for j in range(n_cosets)]   # rank r's block starts at r * slots * rows * 32: unit order = coset order, rows ascending
         be.fr_interleave_dev(srcs, n, h_ext)
     for d in ext:                                                   # the cosets are dead once the numerator exists
         d.free()

@@ -227,9 +227,11 @@ class ProverWorkload:
         else:
             adv = self.advice_host
         self.seed += 1
-        if self.native is not None and timings is None and capture is None:
+        if self.native is not None and capture is None:
             # the native per-proof path (zk_plonk_create_proof, csrc/prover.hip): the C++ twin of plonk.create_proof — same bytes, no interpreter in the loop
             self.proof = self.native.create_proof(adv, [], np.random.default_rng(self.seed))
+            if timings is not None:
+                timings.update(self.native.phase_ms)           # zk_plonk_last_phase_ms: the driver's own wall clock per phase
             if self.info is None:
                 n_commit = self.A + 3 * self.L + self.P + 1 + (self.d - 1) + 2
                 self.info = {"commitments": n_commit, "evals": len(self.proof) // 32 - n_commit}

@@ -8,6 +8,7 @@ O=gpurun_out/$TAG
 mkdir -p $O
 python bench.py > $O/${TAG}_bench_default.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --steps 3 --warmup 1 --no-extras > $O/${TAG}_bench_under_rocprofv3.json 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o s -- python3 bench.py --steps 3 --warmup 1 --no-extras --inflight 1 > $O/${TAG}_bench_under_rocprofv3_inflight1.json 2>> $O/bench.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $O/lds -o l -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err

@@ -4,6 +4,7 @@ Session layout (see tools/collect_profiles.sh): <dir>/runNN_bench_default.json, 
 stats/s_kernel_{stats,trace}.csv, fetch/f_counter_collection.csv, write/w_counter_collection.csv, lds/l_counter_collection.csv"""
 import collections
 import csv
+import shutil
 import json
 import os
 import re
@@ -36,6 +37,31 @@ def main():
         f.write(f"# the last {nl} of them are the timed region: average {avg:.4f} ms per launch from this trace vs {b['roofline']['avg_launch_ms']:.4f} ms from the in-bench HIP events of the same run ({tag}_bench_under_rocprofv3.json)\n")
         f.write(open(f"{O}/stats/s_kernel_stats.csv").read())
     print("msm_accumulate timed-region avg (trace) %.4f ms vs HIP events %.4f ms" % (avg, b["roofline"]["avg_launch_ms"]))
+    # the same command with ONE proof in flight: no other stream's kernels inside an event pair, so the two clocks must agree closely; plus the per-proof kernel table
+    if os.path.exists(f"{O}/stats1/s_kernel_trace.csv"):
+        b1 = last_json_line(f"{O}/{tag}_bench_under_rocprofv3_inflight1.json")
+        rows1 = sorted(csv.DictReader(open(f"{O}/stats1/s_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
+        acc1 = [r for r in rows1 if "msm_accumulate" in r["Kernel_Name"]]
+        nl1 = b1["roofline"]["launches"]
+        avg1 = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in acc1[-nl1:]) / nl1 / 1e6
+        proofs = b1["steps"]
+        t0 = int(acc1[-nl1]["Start_Timestamp"]) - 3_000_000
+        sel = [r for r in rows1 if int(r["Start_Timestamp"]) >= t0]
+        tot, cnt = collections.Counter(), collections.Counter()
+        for r in sel:
+            tot[short(r["Kernel_Name"])] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            cnt[short(r["Kernel_Name"])] += 1
+        T = sum(tot.values())
+        span = int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])
+        with open(f"{P}/{tag}_rocprofv3_kernel_trace_per_proof_inflight1.txt", "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-extras --inflight 1\n")
+            f.write(f"# msm_accumulate_kernel over the {nl1} launches of the timed region: {avg1:.4f} ms per launch from the trace vs {b1['roofline']['avg_launch_ms']:.4f} ms from the in-bench HIP events\n")
+            f.write(f"# timed region = {proofs} proofs, one at a time: {span / proofs / 1e6:.2f} ms per proof, kernels busy {T / proofs / 1e6:.2f} ms per proof; bench line of the run: {b1['ms_per_step']:.2f} ms per proof\n")
+            f.write(f"{'kernel':45s} {'launches/proof':>14s} {'ms/proof':>9s} {'share':>6s}\n")
+            for k_, v in tot.most_common():
+                f.write(f"{k_:45s} {cnt[k_] / proofs:14.1f} {v / proofs / 1e6:9.3f} {100 * v / T:5.1f}%\n")
+        shutil.copy(f"{O}/{tag}_bench_under_rocprofv3_inflight1.json", f"{P}/{tag}_bench_under_rocprofv3_inflight1.json")
+        print("one proof in flight: trace %.4f ms vs HIP events %.4f ms; kernels busy %.2f ms per proof" % (avg1, b1["roofline"]["avg_launch_ms"], T / proofs / 1e6))
 
     def agg(path, counter):
         d = collections.defaultdict(lambda: [0, 0.0])

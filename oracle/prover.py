@@ -261,9 +261,10 @@ def _permute_expression_pair(inp, tab, usable, blind_in, blind_tab):
     return a + list(blind_in), s + list(blind_tab)
 
 
-def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.Generator) -> bytes:
+def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.Generator, require_satisfied: bool = True) -> bytes:
     """advice: cs.num_advice_columns lists of n canonical ints (rows past the usable ones are overwritten with blinding); instances: lists of
-    canonical ints.  Returns the proof bytes (Blake2b transcript)."""
+    canonical ints.  Returns the proof bytes (Blake2b transcript).  require_satisfied = False: behave as halo2 does on a witness that violates a gate —
+    no check, extended_to_coeff silently truncates h(X) to (d-1) n coefficients (poly/domain.rs) — instead of stopping (differential tests on random circuits)."""
     cs, k, n = keys.cs, params.k, params.n
     w = p.omega(k)
     ek = _extended_k(cs, k)
@@ -411,7 +412,7 @@ def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.G
     zinv = pow(p.ZETA, -1, R)
     hc = [c * pow(zinv, i % 3, R) % R for i, c in enumerate(hc)]
     n_pieces = cs.degree() - 1
-    assert not any(hc[n_pieces * n:]), "the witness does not satisfy the circuit: h(X) has degree >= (d-1) n"
+    assert not (require_satisfied and any(hc[n_pieces * n:])), "the witness does not satisfy the circuit: h(X) has degree >= (d-1) n"
     pieces = [hc[i * n:(i + 1) * n] for i in range(n_pieces)]
     for pc in pieces:
         tr.write_point(params.commit(pc))

@@ -2,8 +2,9 @@
 """bench.py — proofs/hour of the sgx_dcap_verifier k=19 prover on MI355X (BASELINE.json configs[1]) and, as extras, the
 BN254 MSM Mscalar/s at 2^24 (configs[2]) and batched NTT (configs[3]).
 
-Default (`--mode prove`): a "step" is one batch of `--inflight` (4) REAL proofs: `plonk.create_proof` (the mirror of halo2's
-create_proof, zk-dcap-verifier_amd/plonk/prover.py) over a satisfiable synthetic circuit with the census of the sgx circuit at
+Default (`--mode prove`): a "step" is one batch of `--inflight` (4) REAL proofs — `zk_plonk_create_proof` (the library's C++ create_proof, csrc/prover.hip;
+`--prover python`: its twin zk-dcap-verifier_amd/plonk/prover.py, same bytes), one context + HIP stream + host thread per proof in flight; the K timed steps are
+a continuous pipeline (every thread proves K proofs back to back, no join between steps; barrier + synchronize on both sides of the K steps) — over a satisfiable synthetic circuit with the census of the sgx circuit at
 k = 19 (tools/sgx_shaped_circuit.py: 25 advice, 18 fixed, 11 lookups, 16 equality columns, 24 gates, degree 5 => 71 commitments,
 64 iNTT(2^19), 64 NTT(2^21) + 1 iNTT(2^21), evaluate_h over 2^21 rows, 175 evaluations, SHPLONK).  The witness columns are
 resident in HBM when the timed region starts (witness synthesis is host work the north star leaves in Rust); everything from the
@@ -11,7 +12,8 @@ advice commitments to the last SHPLONK commitment — transcript hashing on the 
 region one proof per context is handed to the pure-Python verifier together with the CPU baseline (the reference's own
 acceptance check, sgx_dcap_verifier.rs:826-844); a proof that does not verify fails the run.
 `value` is quoted on the HBM-resident witness (bench contract).  The same K steps are then repeated with the witness starting in
-HOST memory and crossing PCIe inside every proof — `extra.host_witness` (page-locked staging memory / pageable arrays) — and the
+HOST memory and crossing PCIe inside every proof (zk_dev_upload_batch, the proofs in flight taking turns on the link) — `extra.host_witness` (page-locked
+staging memory / pageable arrays) — and the
 boundary as INTEGRATION.md 2 first wires it (one blocking host-buffer call per best_multiexp / best_fft / evaluate_h, a13-a16 on the
 CPU) is replayed as `extra.thin_shim`.  Extras also RESULT-check the BASELINE microbench sizes: MSM 2^20 / 2^24 closed form,
 batched NTT 2^22 x 25 round trip + 64 outputs against the direct sum.
@@ -29,6 +31,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -210,6 +213,8 @@ class ProverWorkload:
         self.n_intt = A + 3 * L + self.P
         self.n_ext = self.n_intt
 
+    upload_turn = threading.Lock()
+
     def step(self, timings=None, witness="resident", capture=None):
         """witness = "resident": the advice columns are in HBM when the step starts (a device-to-device copy, create_proof works in place);
         "pinned" / "pageable": they start in host memory and cross PCIe inside the step (page-locked staging memory / ordinary memory)."""
@@ -218,14 +223,16 @@ class ProverWorkload:
             for w, m in zip(self.work, self.master):
                 w.copy_from(m)
             adv = self.work
-        elif witness == "pinned":
-            if self.pinned is None:
+        else:
+            if witness == "pinned" and self.pinned is None:
                 self.pinned = [self.be.host_alloc((self.n, 4)) for _ in self.advice_host]
                 for p_, a_ in zip(self.pinned, self.advice_host):
                     p_[:] = a_
-            adv = self.pinned
-        else:
-            adv = self.advice_host
+            # the PCIe hop of the witness, inside the step: one zk_dev_upload_batch of the proof's columns.  The proofs in flight take turns on the link
+            # (one upload at a time), so in steady state one proof's upload runs under the kernels of the others instead of all uploads colliding.
+            with ProverWorkload.upload_turn:
+                self.be.upload_columns(self.work, self.pinned if witness == "pinned" else self.advice_host, self.n * 32)
+            adv = self.work
         self.seed += 1
         if self.native is not None and capture is None:
             # the native per-proof path (zk_plonk_create_proof, csrc/prover.hip): the C++ twin of plonk.create_proof — same bytes, no interpreter in the loop
@@ -537,7 +544,7 @@ def ntt_microbench(be, log_n, cols, seed, reps=3):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--k", type=int, default=19)
     ap.add_argument("--advice", type=int, default=25)
@@ -596,15 +603,28 @@ def main(argv=None):
         wls = [ProofWorkload(z, b, args.k, args.advice, args.fixed, args.lookups, args.perm_columns, args.degree) for b in bes]
     wl = wls[0]
 
-    def step_all(**kw):
+    def step_all(steps=1, **kw):
+        """`steps` steps = steps x inflight proofs: every host thread proves `steps` proofs back to back on its own context, with no join between steps —
+        a continuous pipeline, so the proofs drift out of phase and the GPU never waits for the slowest proof of a batch"""
         if inflight == 1:
-            wl.step(**kw)
+            for _ in range(steps):
+                wl.step(**kw)
             return
-        ths = [threading.Thread(target=w.step, kwargs=kw) for w in wls]
+        errors = []
+
+        def loop(w):
+            try:
+                for _ in range(steps):
+                    w.step(**kw)
+            except BaseException as e:
+                errors.append(e)
+        ths = [threading.Thread(target=loop, args=(w,)) for w in wls]
         for t in ths:
             t.start()
         for t in ths:
             t.join()
+        if errors:
+            raise errors[0]
 
     def barrier():
         for b in bes:
@@ -616,14 +636,12 @@ def main(argv=None):
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step_all()
+    step_all(args.warmup)
     for b in bes:
         b.timing(True)                         # HIP events on the library's own streams, inside the timed region
     barrier()
     t0 = time.time()
-    for _ in range(args.steps):
-        step_all()
+    step_all(args.steps)
     barrier()
     dt = time.time() - t0
     def tsum(label):
@@ -686,11 +704,10 @@ def main(argv=None):
         # are the PCIe-inclusive rates.
         host_rates = {}
         for kind in (("pinned",) if args.no_extras else ("pinned", "pageable")):
-            step_all(witness=kind)                                   # untimed: page-locks / first touch
+            step_all(1, witness=kind)                                # untimed: page-locks / first touch
             barrier()
             t1 = time.time()
-            for _ in range(args.steps):
-                step_all(witness=kind)
+            step_all(args.steps, witness=kind)
             barrier()
             dh = time.time() - t1
             if dist is not None:
@@ -699,8 +716,8 @@ def main(argv=None):
                 dh = float(th_.item())
             host_rates[kind] = {"proofs_per_hour": round(world * 3600.0 * proofs_total / dh, 2), "ms_per_proof": round(dh / proofs_total * 1e3, 3)}
         extra["host_witness"] = dict(host_rates, bytes_per_proof=wl.A * wl.n * 32,
-                                     what="same steps with the advice columns starting in host memory and uploaded inside create_proof (one zk_dev_upload_batch); "
-                                          "uploads of one proof overlap the kernels of the other proofs in flight")
+                                     what="same steps with the advice columns starting in host memory: every proof uploads its columns first (one zk_dev_upload_batch, the proofs in "
+                                          "flight take turns on the link), then create_proof runs on the device copies; the upload of one proof overlaps the kernels of the others")
     if args.mode == "prove" and not args.no_extras and world == 1:
         # The OTHER census of the synthetic circuit, same K steps, same contexts: "reference_exact" builds the base64 part exactly as
         # the reference configures and assigns it (15 advice columns that are zero outside 1696 rows, 7 lookups of 4/5 expressions on 65-/257-row
@@ -711,17 +728,19 @@ def main(argv=None):
             circuit2 = sgx.build(z, be, args.k, census=other)
             wls2 = [ProverWorkload(z, b, args.k, circuit2, srs=wl.params) for b in bes]
 
-            def step2():
-                ths_ = [threading.Thread(target=w_.step) for w_ in wls2]
+            def step2(steps):
+                def loop(w_):
+                    for _ in range(steps):
+                        w_.step()
+                ths_ = [threading.Thread(target=loop, args=(w_,)) for w_ in wls2]
                 for t_ in ths_:
                     t_.start()
                 for t_ in ths_:
                     t_.join()
-            step2()
+            step2(1)
             barrier()
             t1 = time.time()
-            for _ in range(args.steps):
-                step2()
+            step2(args.steps)
             barrier()
             d2 = time.time() - t1
             extra["census_" + other] = {"proofs_per_hour": round(3600.0 * proofs_total / d2, 2), "ms_per_proof": round(d2 / proofs_total * 1e3, 3),
@@ -945,7 +964,7 @@ def main(argv=None):
                         f"(tools/sgx_shaped_circuit.py): k={args.k}, extended_k={wl.ek}, A={wl.A} advice (14 full-width + 11 16-bit), F={wl.F} fixed, L={wl.L} lookups of 4-5 expressions, "
                         f"{wl.n_perm} equality columns (P={wl.P}), 24 gates, degree {wl.d}; per proof {wl.n_msm} MSM(2^{args.k}) + {wl.n_intt} iNTT + {wl.n_ext + 1} NTT(2^{wl.ek}) + evaluate_h "
                         f"+ {wl.info['evals'] + 1 if wl.info else '?'} evaluations + SHPLONK -> {len(wl.proof) if wl.proof else '?'}-byte proof; `value` = witness resident in HBM when a step starts (PCIe-inclusive rates: extra.host_witness; per-call host-buffer boundary: extra.thin_shim); "
-                        f"one step = a batch of {inflight} proofs in flight on the GPU (one context + HIP stream + host thread each)")
+                        f"one step = {inflight} proofs, {inflight} in flight on the GPU (one context + HIP stream + host thread each, proving back to back)")
         else:
             metric = "proofs/hour sgx_dcap_verifier k=19 (GPU hot path: MSM+NTT+quotient op-mix of create_proof; host witness/transcript excluded)"
             workload = (f"sgx_dcap_verifier QE3-report circuit shape, k={args.k}, extended_k={wl.ek}, A={args.advice} advice, F={args.fixed} fixed, "

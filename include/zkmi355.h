@@ -291,6 +291,9 @@ typedef struct zk_plonk_pk_desc {
     const void* const* sigma_values; const void* const* sigma_polys; const void* const* sigma_cosets;   /* DEVICE, n_perm_columns each */
     const void* l0; const void* l_last; const void* l_active_row;                                       /* DEVICE extended cosets */
     const void* transcript_repr;              /* HOST 32 B: vk.transcript_repr, canonical little endian */
+    uint32_t transcript;                      /* 0: Blake2bWrite + Challenge255, y-parity flag in bit 255 (stack A, sgx_dcap_verifier.rs:813);
+                                               * 1: snark-verifier PoseidonTranscript<NativeLoader> (T = 3, RATE = 2, R_F = 8, R_P = 57), flag in bit 254 (stack B gen_proof, base.rs:200-212);
+                                               * 2: snark-verifier EvmTranscript (Keccak-256, 32-byte big-endian words, uncompressed points; gen_evm_proof_shplonk, base.rs:193-199) */
 } zk_plonk_pk_desc;
 /* the caller's RNG (`&mut rng` of create_proof): fill out_fr with n uniform field elements as Montgomery limbs (n x 32 B).  Called from a helper thread of the
  * library, once per Fr::random block, in the order halo2 draws them: advice blinding per column, then per lookup the permuted-input and permuted-table

@@ -35,6 +35,7 @@ pub struct ZkPlonkPkDesc {
     pub sigma_values: *const *const c_void, pub sigma_polys: *const *const c_void, pub sigma_cosets: *const *const c_void,
     pub l0: *const c_void, pub l_last: *const c_void, pub l_active_row: *const c_void,
     pub transcript_repr: *const c_void,
+    pub transcript: u32, // 0 Blake2b/Challenge255 (stack A), 1 snark-verifier Poseidon, 2 snark-verifier EVM (Keccak)
 }
 
 type ZkRngFn = extern "C" fn(user: *mut c_void, n: usize, out_fr: *mut c_void);

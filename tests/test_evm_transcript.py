@@ -47,6 +47,8 @@ def _p256_evm(be, k):
     tr = EvmWrite()
     info = plonk.create_proof(params, pk, advice, instances, np.random.default_rng(18), tr)
     proof = tr.finalize()
+    # the library's C++ create_proof with its own Keccak transcript (zk_plonk_pk_desc.transcript = 2): same bytes as the Python twin through transcript.EvmWrite
+    assert plonk.NativeProver(params, pk, transcript="evm").create_proof([a.copy() for a in advice], instances, np.random.default_rng(18)) == proof
     assert len(proof) == 15 * 64 + 32 * 32 and info["commitments"] == 15 and info["evals"] == 32
     assert verifier.verify_proof(pk.vk, tcp.TAU, instances, proof, reader=evm_ref.Reader) is True
     wrong = [list(instances[0])]

@@ -60,6 +60,8 @@ def _p256_poseidon(be, k):
     tr = PoseidonWrite()
     info = plonk.create_proof(params, pk, advice, instances, np.random.default_rng(18), tr)
     proof = tr.finalize()
+    # the library's C++ create_proof with its own Poseidon (zk_plonk_pk_desc.transcript = 1): same bytes as the Python twin through transcript.PoseidonWrite
+    assert plonk.NativeProver(params, pk, transcript="poseidon").create_proof([a.copy() for a in advice], instances, np.random.default_rng(18)) == proof
     ref = bytes.fromhex(open(os.path.join(ROOT, "tests", "golden", "proof.bin")).read().strip()[2:])
     assert len(proof) == len(ref) == 1504 and info["commitments"] == 15 and info["evals"] == 32
     assert verifier.verify_proof(pk.vk, tcp.TAU, instances, proof, reader=poseidon_ref.Reader) is True

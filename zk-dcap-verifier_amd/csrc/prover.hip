@@ -86,11 +86,131 @@ inline bool canon_less(const u256& a, const u256& b) { for (int i = 7; i >= 0; i
 inline u256 load32(const void* p) { u256 o; memcpy(&o, p, 32); return o; }
 struct CanonLess { bool operator()(const u256& a, const u256& b) const { return canon_less(a, b); } };
 
-struct Transcript {                                                  // Blake2bWrite<_, G1Affine, Challenge255<_>>
+// ---- Keccak-256 (the original padding 0x01, as the EVM's KECCAK256), one shot --------------------------------------------------------------------------------
+inline void keccak256(const uint8_t* data, size_t n, uint8_t out[32]) {
+    static const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull, 0x0000000080000001ull,
+                                    0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+                                    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull,
+                                    0x000000000000800aull, 0x800000008000000aull, 0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    static const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};    // [x + 5 y]
+    uint64_t a[25] = {0};
+    auto permute = [&]() {
+        for (int rd = 0; rd < 24; rd++) {
+            uint64_t c[5], d[5], b[25];
+            for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+            for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ ((c[(x + 1) % 5] << 1) | (c[(x + 1) % 5] >> 63));
+            for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
+            for (int x = 0; x < 5; x++)
+                for (int y = 0; y < 5; y++) {
+                    const int r = ROT[x + 5 * y];
+                    const uint64_t v = a[x + 5 * y];
+                    b[y + 5 * ((2 * x + 3 * y) % 5)] = r ? (v << r) | (v >> (64 - r)) : v;
+                }
+            for (int y = 0; y < 5; y++)
+                for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+            a[0] ^= RC[rd];
+        }
+    };
+    const size_t rate = 136;
+    std::vector<uint8_t> m(data, data + n);
+    m.push_back(0x01);
+    while (m.size() % rate) m.push_back(0);
+    m.back() |= 0x80;
+    for (size_t off = 0; off < m.size(); off += rate) {
+        for (size_t i = 0; i < rate / 8; i++) { uint64_t w; memcpy(&w, &m[off + 8 * i], 8); a[i] ^= w; }
+        permute();
+    }
+    memcpy(out, a, 32);
+}
+
+// ---- Poseidon over Fr as snark-verifier's transcript uses it: T = 3, RATE = 2, R_F = 8, R_P = 57; constants from the Grain LFSR of the Poseidon paper ----------------
+struct PoseidonSpec {
+    static constexpr int T = 3, RATE = 2, RF = 8, RP = 57, BITS = 254;
+    Fe rc[RF + RP][T], mds[T][T];
+    PoseidonSpec() {
+        uint8_t st[80];
+        int pos = 0;
+        auto put = [&](uint32_t value, int len) { for (int i = 0; i < len; i++) st[pos++] = (value >> (len - 1 - i)) & 1; };      // MSB first
+        put(1, 2); put(0, 4); put(BITS, 12); put(T, 12); put(RF, 10); put(RP, 10);                                                  // prime field, x^alpha s-box
+        for (int i = 0; i < 30; i++) st[pos++] = 1;
+        auto raw = [&]() { const uint8_t nb = st[62] ^ st[51] ^ st[38] ^ st[23] ^ st[13] ^ st[0]; memmove(st, st + 1, 79); st[79] = nb; return nb; };
+        for (int i = 0; i < 160; i++) raw();
+        auto bit = [&]() { for (;;) { const uint8_t b1 = raw(), b2 = raw(); if (b1) return b2; } };                                // self-shrinking
+        auto integer = [&]() { u256 v = Fr::zero(); for (int i = 0; i < BITS; i++) { for (int l = 7; l > 0; l--) v.v[l] = (v.v[l] << 1) | (v.v[l - 1] >> 31); v.v[0] = (v.v[0] << 1) | bit(); } return v; };
+        for (int r = 0; r < RF + RP; r++)
+            for (int i = 0; i < T; i++) {
+                u256 v;
+                do v = integer(); while (!Fr::eq(Fr::reduce_once(v), v));                  // round constants: rejection sampling below r
+                rc[r][i] = Fr::to_mont(v);
+            }
+        for (;;) {                                                                          // MDS: Cauchy matrix 1 / (x_i + y_j) of 2 T distinct samples (taken mod r)
+            Fe v[2 * T];
+            bool distinct = true;
+            for (int i = 0; i < 2 * T; i++) {
+                v[i] = Fr::to_mont(Fr::reduce_once(integer()));
+                for (int j = 0; j < i; j++) distinct &= !Fr::eq(v[i], v[j]);
+            }
+            if (!distinct) continue;
+            for (int i = 0; i < T; i++)
+                for (int j = 0; j < T; j++) mds[i][j] = Fr::inv(Fr::add(v[i], v[T + j]));
+            break;
+        }
+    }
+    void permute(Fe s[T]) const {
+        for (int r = 0; r < RF + RP; r++) {
+            for (int i = 0; i < T; i++) s[i] = Fr::add(s[i], rc[r][i]);
+            const bool full = r < RF / 2 || r >= RF / 2 + RP;
+            for (int i = 0; i < (full ? T : 1); i++) { const Fe x2 = Fr::sqr(s[i]); s[i] = Fr::mul(Fr::sqr(x2), s[i]); }
+            Fe o[T];
+            for (int i = 0; i < T; i++) { o[i] = Fr::zero(); for (int j = 0; j < T; j++) o[i] = Fr::add(o[i], Fr::mul(mds[i][j], s[j])); }
+            for (int i = 0; i < T; i++) s[i] = o[i];
+        }
+    }
+};
+const PoseidonSpec& poseidon_spec() { static const PoseidonSpec spec; return spec; }
+
+// The transcript of create_proof, three flavours (zk_plonk_pk_desc.transcript):
+//   0  Blake2bWrite<_, G1Affine, Challenge255<_>>                      stack A (sgx_dcap_verifier.rs:813): points compressed with the y-parity flag in bit 255
+//   1  snark-verifier PoseidonTranscript<G1Affine, NativeLoader, _>    stack B gen_proof (base.rs:200-212): a point is absorbed as its coordinates taken mod r,
+//                                                                       a squeeze is one sponge squeeze; points compressed with the flag in bit 254 (halo2curves-axiom)
+//   2  snark-verifier EvmTranscript<G1Affine, NativeLoader, _, _>      stack B gen_evm_proof_shplonk (base.rs:193-199): 32-byte BIG-endian words, Keccak-256
+struct Transcript {
+    int kind = 0;
+    bool bad_point = false;                                           // flavours 1 / 2 cannot absorb the identity (it has no coordinates): create_proof returns ZK_ERR_ARG
     Blake2b st{"Halo2-Transcript"};
+    Fe sponge[3];
+    std::vector<Fe> pending;
+    std::vector<uint8_t> evm;
     std::vector<uint8_t> out;
-    Fe squeeze() {                                                    // Challenge255: the 64-byte digest as a little-endian integer mod r
-        const uint8_t pre = 0;
+    explicit Transcript(int kind_) : kind(kind_) {
+        sponge[0] = Fr::to_mont([] { u256 x = Fr::zero(); x.v[2] = 1; return x; }());     // 2^64
+        sponge[1] = sponge[2] = Fr::zero();
+    }
+    static void be32(const u256& c, uint8_t o[32]) { for (int i = 0; i < 32; i++) o[i] = (uint8_t)(c.v[(31 - i) >> 2] >> (8 * ((31 - i) & 3))); }
+    void absorb(const Fe* chunk, int n) {
+        for (int i = 0; i < n; i++) sponge[1 + i] = Fr::add(sponge[1 + i], chunk[i]);
+        if (n < PoseidonSpec::RATE) sponge[1 + n] = Fr::add(sponge[1 + n], Fr::one());
+        poseidon_spec().permute(sponge);
+    }
+    Fe squeeze() {
+        if (kind == 1) {
+            std::vector<Fe> buf;
+            buf.swap(pending);
+            for (size_t i = 0; i < buf.size(); i += PoseidonSpec::RATE) absorb(&buf[i], (int)std::min<size_t>(PoseidonSpec::RATE, buf.size() - i));
+            if (buf.size() % PoseidonSpec::RATE == 0) absorb(nullptr, 0);
+            return sponge[1];
+        }
+        if (kind == 2) {
+            std::vector<uint8_t> data = evm;
+            if (evm.size() == 32) data.push_back(0x01);
+            uint8_t h[32];
+            keccak256(data.data(), data.size(), h);
+            evm.assign(h, h + 32);
+            u256 v;
+            for (int i = 0; i < 32; i++) ((uint8_t*)v.v)[i] = h[31 - i];                   // big-endian integer -> little-endian limbs
+            return Fr::to_mont(v);                                                         // (v < 2^256: the Montgomery product reduces it mod r)
+        }
+        const uint8_t pre = 0;                                        // Challenge255: the 64-byte digest as a little-endian integer mod r
         st.update(&pre, 1);
         uint8_t d[64];
         st.digest(d);
@@ -98,13 +218,16 @@ struct Transcript {                                                  // Blake2bW
         return Fr::add(Fr::mul(lo, r2), Fr::mul(Fr::mul(hi, r2), r2));
     }
     void common_scalar(const Fe& s) {
-        const uint8_t pre = 2;
+        if (kind == 1) { pending.push_back(s); return; }
         const u256 c = Fr::from_mont(s);
+        if (kind == 2) { uint8_t b[32]; be32(c, b); evm.insert(evm.end(), b, b + 32); return; }
+        const uint8_t pre = 2;
         st.update(&pre, 1); st.update(c.v, 32);
     }
     void write_scalar(const Fe& s) {
         common_scalar(s);
         const u256 c = Fr::from_mont(s);
+        if (kind == 2) { uint8_t b[32]; be32(c, b); out.insert(out.end(), b, b + 32); return; }
         out.insert(out.end(), (const uint8_t*)c.v, (const uint8_t*)c.v + 32);
     }
     void write_point(const uint64_t jac[12]) {                        // normalised {x, y, z}: z = mont(1), or all zero for the identity
@@ -112,6 +235,23 @@ struct Transcript {                                                  // Blake2bW
         bool ident = true;
         for (int i = 8; i < 12; i++) ident &= jac[i] == 0;
         if (!ident) { x = Fq::from_mont(load32(jac)); y = Fq::from_mont(load32(jac + 4)); }
+        if (kind != 0 && ident) { bad_point = true; return; }
+        if (kind == 1) {
+            pending.push_back(Fr::to_mont(Fr::reduce_once(x)));       // fe_to_fe: the coordinate as an integer, mod r (q < 2 r)
+            pending.push_back(Fr::to_mont(Fr::reduce_once(y)));
+            uint8_t enc[32];
+            memcpy(enc, x.v, 32);
+            enc[31] |= (uint8_t)((y.v[0] & 1) << 6);
+            out.insert(out.end(), enc, enc + 32);
+            return;
+        }
+        if (kind == 2) {
+            uint8_t b[64];
+            be32(x, b); be32(y, b + 32);
+            evm.insert(evm.end(), b, b + 64);
+            out.insert(out.end(), b, b + 64);
+            return;
+        }
         const uint8_t pre = 1;
         st.update(&pre, 1); st.update(x.v, 32); st.update(y.v, 32);
         uint8_t enc[32];
@@ -237,7 +377,8 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     const uint32_t n_sets = pk->n_perm_columns ? (pk->n_perm_columns + chunk - 1) / chunk : 0;
     const uint32_t n_pieces = pk->cs_degree - 1;
     Arena mem(ctx);
-    Transcript tr;
+    if (pk->transcript > 2) return ZK_ERR_ARG;
+    Transcript tr((int)pk->transcript);
     Draws draws;
     for (double& v : g_phase_ms) v = 0;
     PhaseClock clk;
@@ -596,6 +737,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         PK(commit(pk->srs_g, {tmp1}));
     }
     clk.lap(8);
+    if (tr.bad_point) return ZK_ERR_ARG;                              // a commitment to the zero polynomial under a transcript that cannot encode the identity
     *proof_len = tr.out.size();
     if (!proof_out || proof_cap < tr.out.size()) return ZK_ERR_LIMIT;
     memcpy(proof_out, tr.out.data(), tr.out.size());

@@ -31,13 +31,15 @@ class PkDesc(C.Structure):
                 ("fixed_values", C.c_void_p), ("fixed_polys", C.c_void_p), ("fixed_cosets", C.c_void_p),
                 ("sigma_values", C.c_void_p), ("sigma_polys", C.c_void_p), ("sigma_cosets", C.c_void_p),
                 ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
-                ("transcript_repr", C.c_void_p)]
+                ("transcript_repr", C.c_void_p), ("transcript", C.c_uint32)]
 
 
 class NativeProver:
     """marshalled once per (params, pk); create_proof per proof"""
 
-    def __init__(self, params: ParamsKZG, pk: ProvingKey):
+    TRANSCRIPTS = {"blake2b": 0, "poseidon": 1, "evm": 2}
+
+    def __init__(self, params: ParamsKZG, pk: ProvingKey, transcript: str = "blake2b"):
         assert params.world == 1 and pk.coset_parts is None, "the native prover is the single-GPU path (sharded proofs: plonk.create_proof)"
         self.params, self.pk, self.be = params, pk, pk.backend
         cs = pk.vk.cs
@@ -78,8 +80,9 @@ class NativeProver:
         d.sigma_values, d.sigma_polys, d.sigma_cosets = ptrs(pk.sigma_values), ptrs(pk.sigma_polys), ptrs(pk.sigma_cosets)
         d.l0, d.l_last, d.l_active_row = _dptr(pk.l0), _dptr(pk.l_last), _dptr(pk.l_active_row)
         d.transcript_repr = repr_bytes.ctypes.data
+        d.transcript = self.TRANSCRIPTS[transcript]         # which Fiat-Shamir transcript / proof encoding (zk_plonk_pk_desc.transcript)
         self.desc = d
-        self.proof_cap = 32 * (cs.num_advice_columns + 3 * len(cs.lookups) + len(cs.permutation_columns) + 16 +
+        self.proof_cap = (64 if transcript == "evm" else 32) * (cs.num_advice_columns + 3 * len(cs.lookups) + len(cs.permutation_columns) + 16 +
                                len(aq) + len(fq) + 1 + len(cs.permutation_columns) + 3 * len(cs.permutation_columns) + 5 * len(cs.lookups) + 8)
 
     def create_proof(self, advice: Sequence, instances: Sequence[Sequence[int]], rng) -> bytes:

@@ -308,7 +308,7 @@ int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* c
 /* wall milliseconds of the nine phases (instances, advice, lookups, grand products, random poly, h numerator, h commit, evaluations, SHPLONK) of the
  * calling thread's last zk_plonk_create_proof */
 int zk_plonk_last_phase_ms(double out[9]);
-/* return the per-proof device buffers zk_plonk_create_proof keeps for reuse on this context (call before zk_ctx_destroy) */
+/* return the per-proof device buffers zk_plonk_create_proof keeps for reuse on this context (zk_ctx_destroy does it too) */
 int zk_plonk_trim(zk_ctx* ctx);
 
 /* library / build identification */

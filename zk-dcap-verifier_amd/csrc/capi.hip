@@ -83,6 +83,7 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
 
 void zk_ctx_destroy(zk_ctx* ctx) {
     if (!ctx) return;
+    (void)zk_plonk_trim(ctx);                   // device buffers zk_plonk_create_proof kept for reuse on this context (a later context at the same address must not inherit them)
     {
         LOCK;
         (void)hipSetDevice(ctx->device);

@@ -303,11 +303,12 @@ struct Draws {
     std::vector<size_t> counts;
     std::mutex mu; std::condition_variable cv; size_t done = 0;
     std::thread th;
+    std::atomic<bool> abandoned{false};                                // the proof ended early (an error): stop asking the caller for randomness nobody will use
     void start(zk_rng_fn rng, void* user) {
         items.resize(counts.size());
         for (size_t i = 0; i < counts.size(); i++) items[i].resize(counts[i] * 4 + 4);
         th = std::thread([this, rng, user]() {
-            for (size_t i = 0; i < counts.size(); i++) {
+            for (size_t i = 0; i < counts.size() && !abandoned.load(); i++) {
                 if (counts[i]) rng(user, counts[i], items[i].data());
                 { std::lock_guard<std::mutex> lk(mu); done = i + 1; }
                 cv.notify_all();
@@ -315,7 +316,7 @@ struct Draws {
         });
     }
     const uint64_t* take(size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done > i; }); return items[i].data(); }
-    ~Draws() { if (th.joinable()) th.join(); }
+    ~Draws() { abandoned.store(true); if (th.joinable()) th.join(); }
 };
 
 struct Query { const void* poly; Fe point; Fe eval; };                 // ProverQuery { point, poly } + its evaluation

@@ -83,6 +83,30 @@ def test_native_prover_reports_a_short_output_buffer_and_its_phase_clock(emu, or
     params.release()
 
 
+def test_native_prover_refuses_a_bad_descriptor_or_instance(emu, orc):
+    """indices that would read outside the descriptor's arrays, an unknown transcript, a non-canonical instance value: ZK_ERR_ARG, no proof, no crash"""
+    from zk_dcap_verifier_amd.fields import R_MOD
+    cs, fixed, asm, advice, instances = tcp.toy_circuit(5)
+    params = z.kzg.ParamsKZG.setup(5, tcp.TAU, backend=emu)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    native = plonk.NativeProver(params, pk)
+    good = native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(2))
+    native.desc.transcript = 7
+    with pytest.raises(z.ZkError):
+        native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(2))
+    native.desc.transcript = 0
+    n_adv = native.desc.n_advice
+    native.desc.n_advice = 1                                          # the permutation and the queries name advice columns 1 and 2
+    with pytest.raises(z.ZkError):
+        native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(2))
+    native.desc.n_advice = n_adv
+    with pytest.raises(z.ZkError):
+        native.create_proof([a.copy() for a in advice], [[instances[0][0], R_MOD + 5]], np.random.default_rng(2))
+    assert native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(2)) == good
+    pk.release()
+    params.release()
+
+
 def test_native_provers_on_two_contexts_in_threads(built, orc):
     """one context + host thread per proof in flight (the bench's throughput mode): the second context borrows the first one's SRS tables; same bytes"""
     import threading

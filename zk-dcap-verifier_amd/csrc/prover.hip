@@ -377,6 +377,18 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     const uint32_t chunk = pk->cs_degree - 2;
     const uint32_t n_sets = pk->n_perm_columns ? (pk->n_perm_columns + chunk - 1) / chunk : 0;
     const uint32_t n_pieces = pk->cs_degree - 1;
+    // the descriptor is the caller's: refuse indices that would read outside its arrays
+    if ((pk->n_fixed && (!pk->fixed_values || !pk->fixed_polys || !pk->fixed_cosets)) || (pk->n_perm_columns && (!pk->perm_columns || !pk->sigma_values || !pk->sigma_polys || !pk->sigma_cosets)) ||
+        (L && (!pk->lookup_input_programs || !pk->lookup_table_programs || !pk->lookup_table_key)) || (pk->n_advice_queries && !pk->advice_queries) ||
+        (pk->n_fixed_queries && !pk->fixed_queries) || !pk->l0 || !pk->l_last || !pk->l_active_row || !pk->transcript_repr)
+        return ZK_ERR_ARG;
+    for (uint32_t j = 0; j < pk->n_perm_columns; j++) {
+        const uint32_t ty = pk->perm_columns[2 * j], ix = pk->perm_columns[2 * j + 1];
+        if (ty > 2 || ix >= (ty == 0 ? pk->n_advice : ty == 1 ? pk->n_fixed : pk->n_instance)) return ZK_ERR_ARG;
+    }
+    for (uint32_t i = 0; i < pk->n_advice_queries; i++) if (pk->advice_queries[2 * i] >= pk->n_advice) return ZK_ERR_ARG;
+    for (uint32_t i = 0; i < pk->n_fixed_queries; i++) if (pk->fixed_queries[2 * i] >= pk->n_fixed) return ZK_ERR_ARG;
+    for (uint32_t i = 0; i < pk->n_advice; i++) if (!advice[i]) return ZK_ERR_ARG;
     Arena mem(ctx);
     if (pk->transcript > 2) return ZK_ERR_ARG;
     Transcript tr((int)pk->transcript);
@@ -397,10 +409,12 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     std::vector<void*> inst_values;
     for (uint32_t c = 0; c < pk->n_instance; c++) {
         const uint32_t len = instance_lens ? instance_lens[c] : 0;
-        if (len > usable) return ZK_ERR_ARG;
+        if (len > usable || (len && (!instances || !instances[c]))) return ZK_ERR_ARG;
         std::vector<uint64_t> col((size_t)len * 4);
         for (uint32_t i = 0; i < len; i++) {
-            const Fe v = Fr::to_mont(load32((const char*)instances[c] + 32 * i));
+            const u256 canon = load32((const char*)instances[c] + 32 * i);
+            if (!Fr::eq(Fr::reduce_once(canon), canon)) return ZK_ERR_ARG;          // not a canonical scalar (Fr::from_repr would refuse it)
+            const Fe v = Fr::to_mont(canon);
             tr.common_scalar(v);
             memcpy(&col[4 * (size_t)i], v.v, 32);
         }

@@ -583,14 +583,15 @@ def main(argv=None):
     if os.environ.get("ZK_SWITCH_INTERVAL"):                 # experiment knob: CPython's GIL hand-over interval for the per-proof host threads
         sys.setswitchinterval(float(os.environ["ZK_SWITCH_INTERVAL"]))
     import zk_dcap_verifier_amd as z
-    be = z.Backend(local)                      # raises if the HIP library / GPU is missing: no CPU path
+    lib_path = os.environ.get("ZK_LIB") or None             # A/B: another build of the product library on the same box (same ABI)
+    be = z.Backend(local, lib_path)            # raises if the HIP library / GPU is missing: no CPU path
     assert "gfx950" in be.version() or os.environ.get("ZK_BENCH_PLUMBING_TEST") == "1"
 
     # One step = one batch of `inflight` proofs, each on its own context/stream and host thread, so the
     # latency-bound phases of one proof (bucket reduction, scans) overlap the throughput-bound phases of another.
     import threading
     inflight = max(1, args.inflight)
-    bes = [be] + [z.Backend(local) for _ in range(inflight - 1)]
+    bes = [be] + [z.Backend(local, lib_path) for _ in range(inflight - 1)]
     if args.mode == "prove":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import sgx_shaped_circuit as sgx

@@ -801,19 +801,34 @@ ZK_KERNEL void g1_chunk_prefix_kernel(const void* aff, uint32_t n, uint32_t chun
     for (uint32_t k = (uint32_t)lo; k < hi; k++) { xyzz_madd_signed(acc, load_affine(aff, k), false); store_xyzz(out_xyzz, k, acc); }
 }
 // counts[col] = {non-zero scalars, non-zero adjacent differences (a[i] != a[i+1], a[n] := 0)}
+// Each thread tests PROBE_EPT elements a workgroup-stride apart (neighbouring lanes read neighbouring 32-byte elements; the successor a[i + 1] is the next lane's
+// element, so its load hits the same cache lines), keeps both counts packed in one register (<= 16 bits each per workgroup) and the workgroup folds them with
+// an LDS tree — no two lanes ever add to the same counter.
+constexpr uint32_t PROBE_EPT = 8;
 ZK_KERNEL void msm_runs_probe_kernel(const void* const* cols, uint32_t n, uint32_t* counts) {
-    __shared__ uint32_t sh[2];
-    const uint32_t col = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (threadIdx.x < 2) sh[threadIdx.x] = 0;
-    __syncthreads();
-    if (i < n) {
-        const u256 a = load_u256(cols[col], i);
-        const u256 b = i + 1 < n ? load_u256(cols[col], i + 1) : Fr::zero();
-        if (!Fr::is_zero(a)) atomicAdd(&sh[0], 1u);
-        if (!Fr::eq(a, b)) atomicAdd(&sh[1], 1u);
+    __shared__ uint32_t sh[256];
+    const uint32_t col = blockIdx.y;
+    const uint64_t base = (uint64_t)blockIdx.x * blockDim.x * PROBE_EPT + threadIdx.x;
+    uint32_t c = 0;                                                  // low half: non-zero scalars, high half: non-zero adjacent differences
+#pragma unroll
+    for (uint32_t e = 0; e < PROBE_EPT; e++) {
+        const uint64_t i = base + (uint64_t)e * blockDim.x;
+        if (i < n) {
+            const u256 a = load_u256(cols[col], i);
+            const u256 b = i + 1 < n ? load_u256(cols[col], i + 1) : Fr::zero();
+            c += (Fr::is_zero(a) ? 0u : 1u) + (Fr::eq(a, b) ? 0u : 1u << 16);
+        }
     }
+    sh[threadIdx.x] = c;
     __syncthreads();
-    if (threadIdx.x < 2 && sh[threadIdx.x]) atomicAdd(&counts[2 * col + threadIdx.x], sh[threadIdx.x]);
+    for (uint32_t d = blockDim.x >> 1; d; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && sh[0]) {
+        if (sh[0] & 0xffffu) atomicAdd(&counts[2 * col], sh[0] & 0xffffu);
+        if (sh[0] >> 16) atomicAdd(&counts[2 * col + 1], sh[0] >> 16);
+    }
 }
 ZK_KERNEL void fr_adjacent_diff_kernel(const void* const* cols, const uint32_t* which, uint32_t n, void* out) {
     const uint32_t f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1075,7 +1090,7 @@ int msm_run_batch(zk_ctx* ctx, uint64_t handle, const void* const* scalars, size
             uint32_t* d_counts = (uint32_t*)((char*)ctx->ws_runs.p + nb * sizeof(void*));
             ZK_HIP(hipMemcpyAsync((void*)d_cols, ptrs.data(), nb * sizeof(void*), hipMemcpyHostToDevice, st));
             ZK_HIP(hipMemsetAsync(d_counts, 0, nb * 8, st));
-            ZK_LAUNCH(msm_runs_probe_kernel, dim3((uint32_t)((n + 255) / 256), (uint32_t)nb), 256, 0, st, (const void* const*)d_cols, (uint32_t)n, d_counts);
+            ZK_LAUNCH(msm_runs_probe_kernel, dim3((uint32_t)((n + 256 * PROBE_EPT - 1) / (256 * PROBE_EPT)), (uint32_t)nb), 256, 0, st, (const void* const*)d_cols, (uint32_t)n, d_counts);
             ZK_CHECK_LAUNCH();
             std::vector<uint32_t> counts(2 * nb);
             ZK_HIP(hipMemcpyAsync(counts.data(), d_counts, nb * 8, hipMemcpyDeviceToHost, st));

@@ -43,7 +43,7 @@ def test_domain_batch(emu, orc, pyref):
     pc.check_domain_batch(emu, orc, pyref, 3, 2, 2)          # single-pass transforms, batched
 
 
-@pytest.mark.parametrize("n,c", [(1, 0), (2, 0), (5, 0), (33, 0), (200, 5), (300, 7), (700, 0)])
+@pytest.mark.parametrize("n,c", [(1, 0), (2, 0), (5, 0), (33, 0), (200, 5), (300, 7), (700, 0), (300, 16)])      # c = 16: the half-limb digit path of the production sizes
 def test_msm_uniform(emu, orc, pyref, n, c):
     emu.tune(msm_c=c)
     try:
@@ -54,7 +54,7 @@ def test_msm_uniform(emu, orc, pyref, n, c):
 
 @pytest.mark.parametrize("two_level", [0, 1])
 @pytest.mark.parametrize("n,c,kind", [(1, 0, "uniform"), (33, 0, "uniform"), (300, 7, "uniform"), (700, 0, "uniform"), (513, 9, "uniform"),
-                                      (257, 0, "ones"), (257, 0, "witness"), (257, 0, "minus_one"), (64, 0, "zeros")])
+                                      (257, 0, "ones"), (257, 0, "witness"), (257, 0, "minus_one"), (64, 0, "zeros"), (257, 16, "minus_one"), (130, 16, "uniform")])
 def test_msm_both_sorts(emu, orc, pyref, n, c, kind, two_level):
     """The pairs are grouped by bucket either by the one-level counting sort (small / batched inputs) or the two-level one (large inputs):
     force each and compare with the oracle; a batch too."""

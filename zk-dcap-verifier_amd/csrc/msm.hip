@@ -71,6 +71,37 @@ ZK_HD void for_each_digit_static(u256& s, int c, int W, F&& f, uint32_t carry = 
     }
 }
 
+// c = 16, W = 16 (every table of 2^17 points and more): the digits are the half-limbs, read in place — no 256-bit shift per window
+template <class F>
+ZK_HD void for_each_digit16(const u256& s, F&& f) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t d = ((s.v[j >> 1] >> (16 * (j & 1))) & 0xffffu) + carry;
+        if (d > 0x8000u) {
+            carry = 1;
+            const uint32_t m = 0x10000u - d;
+            if (m) f(j, m, true);
+        } else {
+            carry = 0;
+            if (d) f(j, d, false);
+        }
+    }
+}
+template <int J = 0, class F>
+ZK_HD void for_each_digit16_static(const u256& s, F&& f, uint32_t carry = 0) {
+    if constexpr (J < 16) {
+        const uint32_t d = ((s.v[J >> 1] >> (16 * (J & 1))) & 0xffffu) + carry;
+        uint32_t cy = 0;
+        if (d > 0x8000u) {
+            cy = 1;
+            const uint32_t m = 0x10000u - d;
+            if (m) f(WinIdx<J>{}, m, true);
+        } else if (d) f(WinIdx<J>{}, d, false);
+        for_each_digit16_static<J + 1>(s, f, cy);
+    }
+}
+
 // largest b in [0, B) with arr[b] <= j  (arr is a non-decreasing exclusive scan, arr[0] = 0)
 ZK_HD uint32_t find_segment(const uint32_t* arr, uint32_t B, uint32_t j) {
     uint32_t lo = 0, hi = B;
@@ -282,9 +313,11 @@ ZK_KERNEL void msm_hist_kernel(MsmPlan p) {
     const uint32_t chunk = ceil_div(p.n, gridDim.x);
     const uint32_t lo = blockIdx.x * chunk;
     const uint32_t hi = lo + chunk < p.n ? lo + chunk : p.n;
+    const bool wide16 = p.c == 16 && p.W == 16;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         u256 s = Fr::from_mont(load_u256(scalars, i));
-        for_each_digit(s, p.c, p.W, [&](int, uint32_t mag, bool) { atomicAdd(&lh[mag - 1], 1u); });
+        if (wide16) for_each_digit16(s, [&](int, uint32_t mag, bool) { atomicAdd(&lh[mag - 1], 1u); });
+        else for_each_digit(s, p.c, p.W, [&](int, uint32_t mag, bool) { atomicAdd(&lh[mag - 1], 1u); });
     }
     __syncthreads();
     uint32_t* ghist = plan_small(p, col);
@@ -301,6 +334,7 @@ ZK_KERNEL void msm_scatter_kernel(MsmPlan p) {
     const uint32_t B = p.B, col = blockIdx.y;
     const void* scalars = p.scalars[col];
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lh[b] = 0;
+    const bool wide16 = p.c == 16 && p.W == 16;
     const uint32_t chunk = ceil_div(p.n, gridDim.x);            // <= SC_SPT * blockDim and chunk * W <= 65536 (host): ranks fit 16 bits
     const uint32_t lo = blockIdx.x * chunk;
     const uint32_t hi = lo + chunk < p.n ? lo + chunk : p.n;
@@ -317,12 +351,13 @@ ZK_KERNEL void msm_scatter_kernel(MsmPlan p) {
         const uint32_t i = lo + threadIdx.x + u * blockDim.x;
         if (i < hi) {
             sc[u] = Fr::from_mont(sc[u]);
-            u256 t = sc[u];
-            for_each_digit_static<SC_WMAX>(t, p.c, p.W, [&](auto jc, uint32_t mag, bool) {
+            auto count = [&](auto jc, uint32_t mag, bool) {
                 constexpr int j = decltype(jc)::value;
                 const uint32_t r = atomicAdd(&lh[mag - 1], 1u);
                 if (j & 1) rk[u][j / 2] |= r << 16; else rk[u][j / 2] = r;
-            });
+            };
+            if (wide16) for_each_digit16_static(sc[u], count);
+            else { u256 t = sc[u]; for_each_digit_static<SC_WMAX>(t, p.c, p.W, count); }
         }
     }
     __syncthreads();
@@ -341,12 +376,15 @@ ZK_KERNEL void msm_scatter_kernel(MsmPlan p) {
 #pragma unroll
     for (uint32_t u = 0; u < SC_SPT; u++) {
         const uint32_t i = lo + threadIdx.x + u * blockDim.x;
-        if (i < hi)
-            for_each_digit_static<SC_WMAX>(sc[u], p.c, p.W, [&](auto jc, uint32_t mag, bool neg) {
+        if (i < hi) {
+            auto place = [&](auto jc, uint32_t mag, bool neg) {
                 constexpr int j = decltype(jc)::value;
                 const uint32_t r = (j & 1) ? rk[u][j / 2] >> 16 : rk[u][j / 2] & 0xffffu;
                 sorted[lh[mag - 1] + r] = (neg ? 0x80000000u : 0u) | ((uint32_t)j * p.n_table + i);
-            });
+            };
+            if (wide16) for_each_digit16_static(sc[u], place);
+            else for_each_digit_static<SC_WMAX>(sc[u], p.c, p.W, place);
+        }
     }
 }
 

@@ -836,127 +836,142 @@ def main(argv=None):
                 cpu = {"error": str(e)}
         if ntt_checks and isinstance(cpu, dict) and "ntt_direct_sum_check" in cpu:
             extra["ntt_2^22_x25"]["direct_sum_check_64_outputs"] = cpu["ntt_direct_sum_check"]["ok"]
-    if world > 1 and not args.no_extras:
-        # MSM with the base table sharded over the ranks (SURVEY 8d cfg 5 / 8e): rank g holds bases and scalars
-        # [g*N/G, (g+1)*N/G); the 128-byte XYZZ partials are all-gathered over RCCL/xGMI and summed on every rank.
-        sizes = [int(x) for x in os.environ.get("ZK_BENCH_SHARDED_LOG_N", "21,24").split(",")]
-        for logn in sizes:
-            try:
-                n_loc = (1 << logn) // world
-                kh = rand_fr(n_loc, 31 + rank)
-                ks = be.to_device(kh)
-                pts = be.alloc(n_loc * 64)
-                be.g1_fixed_base_mul(ks, n_loc, pts)
-                h = be.bases_register((pts, n_loc))
-                pts.free()
-                sh = rand_fr(n_loc, 77 + rank)
-                ks.upload(sh)
-                gather = [torch.zeros(16, dtype=torch.int64, device=tdev) for _ in range(world)]
+    def multi_gpu_extras():
+        if tdev == "cuda":
+            torch.cuda.set_device(local)                       # the current device is per host thread
+        if world > 1 and not args.no_extras:
+            # MSM with the base table sharded over the ranks (SURVEY 8d cfg 5 / 8e): rank g holds bases and scalars
+            # [g*N/G, (g+1)*N/G); the 128-byte XYZZ partials are all-gathered over RCCL/xGMI and summed on every rank.
+            sizes = [int(x) for x in os.environ.get("ZK_BENCH_SHARDED_LOG_N", "21,24").split(",")]
+            for logn in sizes:
+                try:
+                    n_loc = (1 << logn) // world
+                    kh = rand_fr(n_loc, 31 + rank)
+                    ks = be.to_device(kh)
+                    pts = be.alloc(n_loc * 64)
+                    be.g1_fixed_base_mul(ks, n_loc, pts)
+                    h = be.bases_register((pts, n_loc))
+                    pts.free()
+                    sh = rand_fr(n_loc, 77 + rank)
+                    ks.upload(sh)
+                    gather = [torch.zeros(16, dtype=torch.int64, device=tdev) for _ in range(world)]
 
-                def sharded():
-                    part = be.msm_partial(h, ks, n_loc)
-                    mine = torch.from_numpy(part.view(np.int64).copy()).to(tdev)
-                    dist.all_gather(gather, mine)
-                    parts = torch.stack(gather).cpu().numpy().view(np.uint64)
-                    return be.g1_sum_xyzz(parts)
-                res = sharded()
+                    def sharded():
+                        part = be.msm_partial(h, ks, n_loc)
+                        mine = torch.from_numpy(part.view(np.int64).copy()).to(tdev)
+                        dist.all_gather(gather, mine)
+                        parts = torch.stack(gather).cpu().numpy().view(np.uint64)
+                        return be.g1_sum_xyzz(parts)
+                    res = sharded()
+                    barrier()
+                    t = time.time()
+                    for _ in range(3):
+                        sharded()
+                    barrier()
+                    ds = (time.time() - t) / 3
+                    rec = {"ranks": world, "ms": round(ds * 1e3, 3), "Mscalar_per_s": round((1 << logn) / ds / 1e6, 2)}
+                    if logn <= 21:   # closed form across ranks: sum over all shards of s_i k_i, checked via the fixed-base path
+                        rinv = pow(1 << 256, -1, R_MOD)
+                        loc = sum(a_ * b_ for a_, b_ in zip(_ints(kh), _ints(sh))) % R_MOD
+                        lt = torch.tensor([(loc >> (62 * i)) & ((1 << 62) - 1) for i in range(5)], dtype=torch.int64, device=tdev)
+                        allp = [torch.zeros(5, dtype=torch.int64, device=tdev) for _ in range(world)]
+                        dist.all_gather(allp, lt)
+                        tot = sum(sum(int(v) << (62 * i) for i, v in enumerate(p_.cpu().tolist())) for p_ in allp) % R_MOD * rinv % R_MOD
+                        one = be.to_device(np.array([[(tot >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]], dtype=np.uint64))
+                        o = be.alloc(64)
+                        be.g1_fixed_base_mul(one, 1, o)
+                        rec["closed_form_check"] = bool((res[:8] == o.download((8,))).all())
+                        one.free()
+                        o.free()
+                    extra[f"msm_sharded_2^{logn}"] = rec
+                    be.bases_release(h)
+                    ks.free()
+                except Exception as e:
+                    extra[f"msm_sharded_2^{logn}_error"] = str(e)
+
+        if world > 1 and not args.no_extras and args.mode == "prove":
+            # ONE proof spread over the ranks (BASELINE configs[4] / SURVEY 8e): both SRS tables sharded by index range, every commitment of
+            # create_proof = per-rank partial MSMs + one all_gather of 128-byte points; everything else is computed redundantly on every rank.
+            try:
+                from zk_dcap_verifier_amd.transcript import Blake2bWrite
+
+                def all_gather_points(part):
+                    mine = torch.from_numpy(np.ascontiguousarray(part).view(np.int64).copy()).to(tdev)
+                    out = [torch.zeros_like(mine) for _ in range(world)]
+                    dist.all_gather(out, mine)
+                    return torch.stack(out).cpu().numpy().view(np.uint64)
+                held = {}
+                # torch tensors are handed to the library as raw device pointers: only where torch's memory IS the library's device memory
+                device_route = backend == "nccl" or os.environ.get("ZK_BENCH_PLUMBING_TEST") == "1"
+
+                def coset_exchange(nbytes):                        # the quotient's numerators: RCCL all_gather between HBM buffers, no host hop
+                    if held.get("n") != nbytes:
+                        held.update(n=nbytes, send=torch.zeros(nbytes // 8, dtype=torch.int64, device=tdev),
+                                    recv=torch.zeros(world * nbytes // 8, dtype=torch.int64, device=tdev))
+                        if tdev == "cuda":
+                            torch.cuda.synchronize()
+
+                    def run():
+                        be.sync()                                   # the library's stream wrote `send`
+                        dist.all_gather_into_tensor(held["recv"], held["send"])
+                        if tdev == "cuda":
+                            torch.cuda.synchronize()                # ... and will read `recv`
+                    return held["send"].data_ptr(), held["recv"].data_ptr(), run
+                sp = z.kzg.ParamsKZG.sharded(args.k, wl.params.g_host, wl.params.g_lagrange_host, rank, world, all_gather_points, backend=be,
+                                             coset_exchange=coset_exchange if device_route else None)
+                cs_, fixed_, asm_, _adv = circuit
+                spk = z.plonk.keygen(sp, cs_, fixed_, asm_)
+
+                phase_ms = {}
+
+                def sharded_proof(seed):
+                    for w_, m_ in zip(wl.work, wl.master):
+                        w_.copy_from(m_)
+                    tr_ = Blake2bWrite()
+                    phase_ms.clear()
+                    z.plonk.create_proof(sp, spk, wl.work, [], np.random.default_rng(seed), tr_, timings=phase_ms)
+                    return tr_.finalize()
+                route = "device" if device_route else "host"
+                try:
+                    sharded_proof(1000)
+                except Exception as e_:                            # keep the measurement: numerators through the host all_gather instead
+                    route = f"host ({e_})"
+                    sp.coset_exchange = None
+                    sharded_proof(1000)
                 barrier()
                 t = time.time()
-                for _ in range(3):
-                    sharded()
+                for i_ in range(2):
+                    pr_sharded = sharded_proof(1001 + i_)
                 barrier()
-                ds = (time.time() - t) / 3
-                rec = {"ranks": world, "ms": round(ds * 1e3, 3), "Mscalar_per_s": round((1 << logn) / ds / 1e6, 2)}
-                if logn <= 21:   # closed form across ranks: sum over all shards of s_i k_i, checked via the fixed-base path
-                    rinv = pow(1 << 256, -1, R_MOD)
-                    loc = sum(a_ * b_ for a_, b_ in zip(_ints(kh), _ints(sh))) % R_MOD
-                    lt = torch.tensor([(loc >> (62 * i)) & ((1 << 62) - 1) for i in range(5)], dtype=torch.int64, device=tdev)
-                    allp = [torch.zeros(5, dtype=torch.int64, device=tdev) for _ in range(world)]
-                    dist.all_gather(allp, lt)
-                    tot = sum(sum(int(v) << (62 * i) for i, v in enumerate(p_.cpu().tolist())) for p_ in allp) % R_MOD * rinv % R_MOD
-                    one = be.to_device(np.array([[(tot >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]], dtype=np.uint64))
-                    o = be.alloc(64)
-                    be.g1_fixed_base_mul(one, 1, o)
-                    rec["closed_form_check"] = bool((res[:8] == o.download((8,))).all())
-                    one.free()
-                    o.free()
-                extra[f"msm_sharded_2^{logn}"] = rec
-                be.bases_release(h)
-                ks.free()
+                ds = (time.time() - t) / 2
+                wl.seed = 1001                                     # the replica prover with the same RNG stream must emit the same bytes
+                wl.step()
+                tt = torch.tensor([ds, 1.0 if wl.proof == pr_sharded else 0.0], dtype=torch.float64, device=tdev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+                same = bool(tt[1].item() == 1.0)
+                tt2 = torch.tensor([ds], dtype=torch.float64, device=tdev)
+                dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+                extra["sharded_proof"] = {"ranks": world, "ms_per_proof": round(float(tt2.item()) * 1e3, 2), "identical_to_single_gpu_proof": same,
+                                          "quotient_exchange": route, "phase_ms_rank0": {k_: round(v, 2) for k_, v in phase_ms.items()},
+                                          "single_gpu_phase_ms": extra.get("single_proof", {}).get("phase_ms"),
+                                          "what": "create_proof with both SRS tables sharded by index range (71 commitments = partial MSMs + all_gather of 128-byte XYZZ points) "
+                                                  "and the quotient sharded by extended-domain coset (size-n coset NTTs + evaluate_h per rank, one all_gather of n*32 bytes per coset); RCCL"}
+                spk.release()
+                sp.release()
             except Exception as e:
-                extra[f"msm_sharded_2^{logn}_error"] = str(e)
+                extra["sharded_proof_error"] = str(e)
 
-    if world > 1 and not args.no_extras and args.mode == "prove":
-        # ONE proof spread over the ranks (BASELINE configs[4] / SURVEY 8e): both SRS tables sharded by index range, every commitment of
-        # create_proof = per-rank partial MSMs + one all_gather of 128-byte points; everything else is computed redundantly on every rank.
-        try:
-            from zk_dcap_verifier_amd.transcript import Blake2bWrite
 
-            def all_gather_points(part):
-                mine = torch.from_numpy(np.ascontiguousarray(part).view(np.int64).copy()).to(tdev)
-                out = [torch.zeros_like(mine) for _ in range(world)]
-                dist.all_gather(out, mine)
-                return torch.stack(out).cpu().numpy().view(np.uint64)
-            held = {}
-            # torch tensors are handed to the library as raw device pointers: only where torch's memory IS the library's device memory
-            device_route = backend == "nccl" or os.environ.get("ZK_BENCH_PLUMBING_TEST") == "1"
-
-            def coset_exchange(nbytes):                        # the quotient's numerators: RCCL all_gather between HBM buffers, no host hop
-                if held.get("n") != nbytes:
-                    held.update(n=nbytes, send=torch.zeros(nbytes // 8, dtype=torch.int64, device=tdev),
-                                recv=torch.zeros(world * nbytes // 8, dtype=torch.int64, device=tdev))
-                    if tdev == "cuda":
-                        torch.cuda.synchronize()
-
-                def run():
-                    be.sync()                                   # the library's stream wrote `send`
-                    dist.all_gather_into_tensor(held["recv"], held["send"])
-                    if tdev == "cuda":
-                        torch.cuda.synchronize()                # ... and will read `recv`
-                return held["send"].data_ptr(), held["recv"].data_ptr(), run
-            sp = z.kzg.ParamsKZG.sharded(args.k, wl.params.g_host, wl.params.g_lagrange_host, rank, world, all_gather_points, backend=be,
-                                         coset_exchange=coset_exchange if device_route else None)
-            cs_, fixed_, asm_, _adv = circuit
-            spk = z.plonk.keygen(sp, cs_, fixed_, asm_)
-
-            phase_ms = {}
-
-            def sharded_proof(seed):
-                for w_, m_ in zip(wl.work, wl.master):
-                    w_.copy_from(m_)
-                tr_ = Blake2bWrite()
-                phase_ms.clear()
-                z.plonk.create_proof(sp, spk, wl.work, [], np.random.default_rng(seed), tr_, timings=phase_ms)
-                return tr_.finalize()
-            route = "device" if device_route else "host"
-            try:
-                sharded_proof(1000)
-            except Exception as e_:                            # keep the measurement: numerators through the host all_gather instead
-                route = f"host ({e_})"
-                sp.coset_exchange = None
-                sharded_proof(1000)
-            barrier()
-            t = time.time()
-            for i_ in range(2):
-                pr_sharded = sharded_proof(1001 + i_)
-            barrier()
-            ds = (time.time() - t) / 2
-            wl.seed = 1001                                     # the replica prover with the same RNG stream must emit the same bytes
-            wl.step()
-            tt = torch.tensor([ds, 1.0 if wl.proof == pr_sharded else 0.0], dtype=torch.float64, device=tdev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
-            same = bool(tt[1].item() == 1.0)
-            tt2 = torch.tensor([ds], dtype=torch.float64, device=tdev)
-            dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
-            extra["sharded_proof"] = {"ranks": world, "ms_per_proof": round(float(tt2.item()) * 1e3, 2), "identical_to_single_gpu_proof": same,
-                                      "quotient_exchange": route, "phase_ms_rank0": {k_: round(v, 2) for k_, v in phase_ms.items()},
-                                      "single_gpu_phase_ms": extra.get("single_proof", {}).get("phase_ms"),
-                                      "what": "create_proof with both SRS tables sharded by index range (71 commitments = partial MSMs + all_gather of 128-byte XYZZ points) "
-                                              "and the quotient sharded by extended-domain coset (size-n coset NTTs + evaluate_h per rank, one all_gather of n*32 bytes per coset); RCCL"}
-            spk.release()
-            sp.release()
-        except Exception as e:
-            extra["sharded_proof_error"] = str(e)
+    # The N > 1 extras are the only collectives of a run that no earlier round could exercise on real RCCL: they run under a watchdog so that a rank that
+    # raises (or a collective that never completes) costs the extras, not the bench line — `value` above is already measured.
+    multi_hung = False
+    if world > 1 and not args.no_extras:
+        th_multi = threading.Thread(target=multi_gpu_extras, daemon=True)
+        th_multi.start()
+        th_multi.join(float(os.environ.get("ZK_BENCH_MULTI_TIMEOUT", "300")))
+        if th_multi.is_alive():
+            multi_hung = True
+            extra["multi_gpu_extras_error"] = "timed out (a collective did not complete); the N > 1 extras were abandoned"
 
     if rank == 0:
         if args.mode == "prove":
@@ -981,6 +996,9 @@ def main(argv=None):
                            "parallelism": f"{world} x independent proofs (one process per GPU)"},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line), flush=True)
+    if multi_hung:
+        sys.stdout.flush()
+        os._exit(0)                                            # a collective is stuck in a daemon thread: no orderly teardown is possible
     if dist is not None:
         dist.destroy_process_group()
     for b in bes:

@@ -116,6 +116,52 @@ struct Field {
     }
     static ZK_HD u256 dbl(const u256& a) { return add(a, a); }
 
+    // ---- redundant ranges (the NTT butterflies, Harvey's scheme).  p < 2^254, so values may live in [0, 4p) inside 256 bits: a butterfly then needs ONE
+    // conditional correction instead of three (product, sum, difference).  Every function states the ranges it takes and gives. ----
+    static ZK_HD constexpr uint32_t p2(int i) { return (p(i) << 1) | (i ? p(i - 1) >> 31 : 0u); }      // limbs of 2p
+    // a in [0, 4p) -> a mod 2p in [0, 2p)
+    static ZK_HD u256 red2p(const u256& a) {
+        u256 d;
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(a.v[i], p2(i), br, &br);
+        u256 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = br ? a.v[i] : d.v[i];
+        return o;
+    }
+    // a, b in [0, 2p) -> a + b in [0, 4p)   (no correction)
+    static ZK_HD u256 add_lazy(const u256& a, const u256& b) {
+        u256 s;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s.v[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
+        return s;
+    }
+    // a, b in [0, 2p) -> a - b + 2p in (0, 4p)   (no correction)
+    static ZK_HD u256 sub_lazy(const u256& a, const u256& b) {
+        u256 s;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s.v[i] = __builtin_addc(a.v[i], p2(i), c, &c);
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s.v[i] = __builtin_subc(s.v[i], b.v[i], br, &br);
+        return s;
+    }
+    // a in [0, 4p), b in [0, p] -> a*b*R^-1 in [0, 2p): the Montgomery product without its final subtraction ((4p*p + 2^256 p) / 2^256 < 1.76 p)
+    static ZK_HD u256 mul_lazy(const u256& a, const u256& b) {
+        uint64_t acc = 0;
+        uint32_t cnt = 0;
+        uint32_t m[8];
+        u256 r;
+#include "field_mul_body.inc"
+        r.v[7] = (uint32_t)acc;
+        return r;
+    }
+    // a in [0, 4p) -> the canonical representative in [0, p)
+    static ZK_HD u256 normalize(const u256& a) { return reduce_once(red2p(a)); }
+
     // Montgomery product a*b*R^-1 mod p: finely integrated product scanning (Comba columns).  Column k
     // gathers every a_i*b_j and m_i*p_j with i + j = k in a 96-bit accumulator (64-bit register pair +
     // overflow counter): each of the 128 partial products costs one v_mad_u64_u32 (carry-out to VCC)

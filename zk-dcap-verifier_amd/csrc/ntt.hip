@@ -78,13 +78,15 @@ ZK_HD u256 ntt_load_input(const NttPassArgs& a, size_t idx) {
     }
     return v;
 }
+// last store of a transform: v comes out of the tile in [0, 4p) and leaves canonical — through the full product of a fused scaling, or a plain normalisation
 ZK_HD u256 ntt_post(const NttPassArgs& a, u256 v, size_t out_idx) {
-    if (a.post_scale) v = Fr::mul(v, a.scale);
+    bool canonical = false;
+    if (a.post_scale) { v = Fr::mul(v, a.scale); canonical = true; }
     if (a.post_zeta_inv) {
         uint32_t m = (uint32_t)out_idx % 3u;
-        if (m) v = Fr::mul(v, zeta_pow(3 - m));  // ZETA^-m = ZETA^(3-m)
+        if (m) { v = Fr::mul(v, zeta_pow(3 - m)); canonical = true; }  // ZETA^-m = ZETA^(3-m)
     }
-    return v;
+    return canonical ? v : Fr::normalize(v);
 }
 ZK_HD void lds_put(uint4* lo, uint4* hi, uint32_t idx, const u256& v) {
     lo[idx] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
@@ -122,6 +124,9 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
         __syncthreads();
         s = 2;
     }
+    // Butterflies in Harvey's redundant form (field.cuh): tile values live in [0, 4p); a twiddle product comes back in [0, 2p) without its final
+    // subtraction, sums and differences are left uncorrected, and ONE conditional subtraction of 2p per input brings a value back under 2p — a third of the
+    // corrections of the canonical form.  Whoever reads the tile afterwards (the pass's output code) takes [0, 4p).
     for (; s + 1 < r; s += 2) {
         const uint32_t h = 1u << s;
         const uint32_t nq = (1u << (r - 2)) << c_log;  // quads per step in the tile
@@ -132,17 +137,22 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
             u256 x0 = lds_get(lo, hi, i0), x1 = lds_get(lo, hi, i0 + step), x2 = lds_get(lo, hi, i0 + 2 * step), x3 = lds_get(lo, hi, i0 + 3 * step);
             if (pos) {
                 const u256 w1 = tw_at((size_t)pos << (r - 1 - s));
-                x1 = Fr::mul(x1, w1);
-                x3 = Fr::mul(x3, w1);
+                x1 = Fr::mul_lazy(x1, w1);
+                x3 = Fr::mul_lazy(x3, w1);
+            } else {
+                x1 = Fr::red2p(x1);
+                x3 = Fr::red2p(x3);
             }
-            const u256 t0 = Fr::add(x0, x1), t1 = Fr::sub(x0, x1);
-            u256 t2 = Fr::add(x2, x3), t3 = Fr::sub(x2, x3);
-            if (pos) t2 = Fr::mul(t2, tw_at((size_t)pos << (r - 2 - s)));
-            t3 = Fr::mul(t3, tw_at((size_t)(pos + h) << (r - 2 - s)));
-            lds_put(lo, hi, i0, Fr::add(t0, t2));
-            lds_put(lo, hi, i0 + step, Fr::add(t1, t3));
-            lds_put(lo, hi, i0 + 2 * step, Fr::sub(t0, t2));
-            lds_put(lo, hi, i0 + 3 * step, Fr::sub(t1, t3));
+            x0 = Fr::red2p(x0);
+            x2 = Fr::red2p(x2);
+            const u256 t0 = Fr::red2p(Fr::add_lazy(x0, x1)), t1 = Fr::red2p(Fr::sub_lazy(x0, x1));
+            u256 t2 = Fr::add_lazy(x2, x3), t3 = Fr::sub_lazy(x2, x3);
+            t2 = pos ? Fr::mul_lazy(t2, tw_at((size_t)pos << (r - 2 - s))) : Fr::red2p(t2);
+            t3 = Fr::mul_lazy(t3, tw_at((size_t)(pos + h) << (r - 2 - s)));
+            lds_put(lo, hi, i0, Fr::add_lazy(t0, t2));
+            lds_put(lo, hi, i0 + step, Fr::add_lazy(t1, t3));
+            lds_put(lo, hi, i0 + 2 * step, Fr::sub_lazy(t0, t2));
+            lds_put(lo, hi, i0 + 3 * step, Fr::sub_lazy(t1, t3));
         }
         __syncthreads();
     }
@@ -153,10 +163,11 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
             const uint32_t col = q & (C - 1), bq = q >> c_log;
             const uint32_t grp = bq >> s, pos = bq & (half - 1);
             const uint32_t i0 = ((grp << (s + 1)) + pos) * C + col, i1 = i0 + half * C;
-            u256 x = lds_get(lo, hi, i0), y = lds_get(lo, hi, i1);
-            if (pos) y = Fr::mul(y, tw_at((size_t)pos << (r - 1 - s)));
-            lds_put(lo, hi, i0, Fr::add(x, y));
-            lds_put(lo, hi, i1, Fr::sub(x, y));
+            const u256 x = Fr::red2p(lds_get(lo, hi, i0));
+            u256 y = lds_get(lo, hi, i1);
+            y = pos ? Fr::mul_lazy(y, tw_at((size_t)pos << (r - 1 - s))) : Fr::red2p(y);
+            lds_put(lo, hi, i0, Fr::add_lazy(x, y));
+            lds_put(lo, hi, i1, Fr::sub_lazy(x, y));
         }
         __syncthreads();
     }
@@ -192,13 +203,14 @@ ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
         u256 v = lds_get(lo, hi, e);
         const uint32_t ex = ((m0 + col) * row) << sh;  // < 2^log_n
         if (ex) {
+            // (the tile holds values in [0, 4p); the product with a canonical twiddle is stored in [0, 2p), an untouched value as it is: the next pass takes [0, 4p))
             if (a.tw_full) {   // one coalesced 32-byte read in exactly the order this pass stores
-                v = Fr::mul(v, load_u256(a.tw_full, ((size_t)row << cols_log) + m0 + col));
+                v = Fr::mul_lazy(v, load_u256(a.tw_full, ((size_t)row << cols_log) + m0 + col));
             } else {
                 u256 tw = load_u256(a.tw_lo, ex & lomask);
                 const uint32_t h = ex >> a.lo_bits;
                 if (h) tw = Fr::mul(tw, load_u256(a.tw_hi, h));
-                v = Fr::mul(v, tw);
+                v = Fr::mul_lazy(v, tw);
             }
         }
         if (a.debug_mode != 2 || v.v[3] == 0x12345u) store_u256(a.dst, base + ((size_t)row << cols_log) + col, v);

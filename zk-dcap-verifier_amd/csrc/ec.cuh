@@ -88,6 +88,41 @@ ZK_HD void xyzz_madd(XYZZ& acc, const u256& x2, const u256& y2) {
     acc.zz = Fq::mul(acc.zz, PP);
     acc.zzz = Fq::mul(acc.zzz, PPP);
 }
+// The same addition for long chains (the bucket accumulation): the accumulator's coordinates live in [0, 2q) — products skip their final subtraction
+// (field.cuh, "one notch tighter") — and (x2, y2) is canonical.  acc.zz is exactly 0 for the identity (it is only ever SET to zero); the caller
+// brings the coordinates back to [0, q) once, after the last addition (xyzz_normalize).
+ZK_HD void xyzz_madd_lazy(XYZZ& acc, const u256& x2, const u256& y2) {
+    if (xyzz_is_identity(acc)) {
+        acc.x = x2; acc.y = y2; acc.zz = Fq::one(); acc.zzz = Fq::one();
+        return;
+    }
+    const u256 U2 = Fq::mul_lazy(x2, acc.zz);
+    const u256 S2 = Fq::mul_lazy(y2, acc.zzz);
+    const u256 P = Fq::sub2(U2, acc.x);
+    const u256 R = Fq::sub2(S2, acc.y);
+    if (Fq::is_zero_mod(P)) {  // same x: doubling or cancellation (rare; bases repeat or P + (-P))
+        if (Fq::is_zero_mod(R)) acc = xyzz_mdbl(x2, y2);
+        else acc = xyzz_identity();
+        return;
+    }
+    const u256 PP = Fq::sqr_lazy(P);
+    const u256 PPP = Fq::mul_lazy(P, PP);
+    const u256 Q = Fq::mul_lazy(acc.x, PP);
+    const u256 X3 = Fq::sub2(Fq::sub2(Fq::sqr_lazy(R), PPP), Fq::dbl2(Q));
+    const u256 Y3 = Fq::mul2_add_2p(R, Fq::sub2(Q, X3), acc.y, Fq::neg2(PPP));   // R*(Q - X3) - Y1*PPP, one reduction
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = Fq::mul_lazy(acc.zz, PP);
+    acc.zzz = Fq::mul_lazy(acc.zzz, PPP);
+}
+ZK_HD void xyzz_madd_signed_lazy(XYZZ& acc, const Affine& p, bool negate) {
+    if (affine_is_identity(p)) return;
+    const u256 y = negate ? Fq::neg(p.y) : p.y;
+    xyzz_madd_lazy(acc, p.x, y);
+}
+ZK_HD void xyzz_normalize(XYZZ& acc) {                                // coordinates in [0, 2q) -> [0, q)
+    acc.x = Fq::reduce_once(acc.x); acc.y = Fq::reduce_once(acc.y); acc.zz = Fq::reduce_once(acc.zz); acc.zzz = Fq::reduce_once(acc.zzz);
+}
 ZK_HD void xyzz_madd_signed(XYZZ& acc, const Affine& p, bool negate) {
     if (affine_is_identity(p)) return;
     u256 y = negate ? Fq::neg(p.y) : p.y;

@@ -563,9 +563,10 @@ ZK_KERNEL void msm_accumulate_kernel(MsmPlan p) {
             ref = sorted[q];
             pt = load_affine(table, ref & 0x7fffffffu);
         }
-        xyzz_madd_signed(acc, cur, (cur_ref >> 31) != 0);
+        xyzz_madd_signed_lazy(acc, cur, (cur_ref >> 31) != 0);   // coordinates in [0, 2q) along the chain: eight of the ten products skip their final subtraction
         if (q >= end) break;
     }
+    xyzz_normalize(acc);
     store_xyzz(p.sub[0], (size_t)col * p.sub_stride[0] + out, acc);
 }
 

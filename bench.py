@@ -688,7 +688,7 @@ def main(argv=None):
             traffic, traffic_source = tjd.get("msm_accumulate_bytes_per_launch"), tjd.get("source", "").split(" (")[0]
         except Exception:
             traffic = None
-    XYZZ_MADD_PEAK = 13.17e9   # mixed additions/s of the same code in a register-only loop (profiles/r01/run43_microbench_dedicated_sqr.txt)
+    XYZZ_MADD_PEAK = 13.82e9   # mixed additions/s of the same code (xyzz_madd_lazy) in a register-only loop (profiles/r02/run79_microbench_lazy_madd.txt; the canonical form: 13.10e9)
     roofline = {"kernel": "msm_accumulate_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(acc_ms / max(acc_n, 1), 4), "launches": acc_n,

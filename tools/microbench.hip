@@ -89,6 +89,16 @@ __global__ void k_madd(uint32_t* out, uint32_t seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x.v[0] ^ acc.zzz.v[2];
 }
 
+__global__ void k_madd_lazy(uint32_t* out, uint32_t seed) {            // the form msm_accumulate runs: coordinates in [0, 2q), eight of ten products without the final subtraction
+    Affine g; g.x = Fq::one(); g.y = Fq::dbl(Fq::one());
+    XYZZ acc = xyzz_mdbl(g.x, g.y);
+    u256 t = Fq::one(); t.v[0] ^= (threadIdx.x + seed) & 0xff;
+    acc.x = Fq::mul(acc.x, t);
+    for (int i = 0; i < ITER / 8; i++) xyzz_madd_lazy(acc, g.x, g.y);
+    xyzz_normalize(acc);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x.v[0] ^ acc.zzz.v[2];
+}
+
 // ---- round 2: what a 52-bit-limb v_fma_f64 Montgomery product would be built from -------------------------------------
 // Per 52x52 partial product (Emmart/Zheng/Weems): hi = fma_rz(a, b, 2^104); lo = fma_rz(a, b, (2^104 + 2^52) - hi); then the two bit patterns are
 // added into 64-bit integer column sums.  The kernels below measure each ingredient's issue rate and the whole 5 multiplicand-limb group.
@@ -216,5 +226,6 @@ int main() {
         run("fq_addsub", k_fqadd, 2.0 * ITER, 256, bpc);
     }
     for (int bpc : {1, 2, 4}) run("xyzz_madd", k_madd, 1.0 * (ITER / 8), 256, bpc);
+    for (int bpc : {1, 2, 4}) run("xyzz_madd_lazy", k_madd_lazy, 1.0 * (ITER / 8), 256, bpc);
     return 0;
 }

@@ -592,6 +592,10 @@ def main(argv=None):
     import threading
     inflight = max(1, args.inflight)
     bes = [be] + [z.Backend(local, lib_path) for _ in range(inflight - 1)]
+    bench_tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("ZK_TUNE", "").split(",") if kv}   # experiment knob: zk_tune_set on every context
+    for b in bes:
+        if bench_tune:
+            b.tune(**bench_tune)
     if args.mode == "prove":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import sgx_shaped_circuit as sgx

@@ -20,6 +20,31 @@ void hh_xyzz_sum(const Affine* pts, const uint8_t* neg, size_t n, XYZZ* out) {
     for (size_t i = 0; i < n; i++) xyzz_madd_signed(acc, pts[i], neg[i] != 0);
     *out = acc;
 }
+// the redundant-range forms (field.cuh): inputs may be anywhere in the range each function documents
+void hh_fq_lazy(int op, const u256* a, const u256* b, const u256* c, const u256* d, u256* o, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        switch (op) {
+            case 0: o[i] = Fq::mul_lazy(a[i], b[i]); break;
+            case 1: o[i] = Fq::sqr_lazy(a[i]); break;
+            case 2: o[i] = Fq::sub2(a[i], b[i]); break;
+            case 3: o[i] = Fq::dbl2(a[i]); break;
+            case 4: o[i] = Fq::neg2(a[i]); break;
+            case 5: o[i] = Fq::mul2_add_2p(a[i], b[i], c[i], d[i]); break;
+            case 6: o[i] = Fq::red2p(a[i]); break;
+            case 7: o[i] = Fq::add_lazy(a[i], b[i]); break;
+            case 8: o[i] = Fq::sub_lazy(a[i], b[i]); break;
+            case 9: o[i] = Fq::normalize(a[i]); break;
+            case 10: o[i] = Fq::zero(); o[i].v[0] = Fq::is_zero_mod(a[i]) ? 1 : 0; break;
+            default: o[i] = Fq::mul(a[i], b[i]); break;              // 11: the full product on inputs up to 4p
+        }
+    }
+}
+void hh_xyzz_sum_lazy(const Affine* pts, const uint8_t* neg, size_t n, XYZZ* out) {
+    XYZZ acc = xyzz_identity();
+    for (size_t i = 0; i < n; i++) xyzz_madd_signed_lazy(acc, pts[i], neg[i] != 0);
+    xyzz_normalize(acc);
+    *out = acc;
+}
 void hh_xyzz_add(const XYZZ* a, const XYZZ* b, XYZZ* out) { XYZZ t = *a; xyzz_add(t, *b); *out = t; }
 void hh_xyzz_dbl(const XYZZ* a, XYZZ* out) { *out = xyzz_dbl(*a); }
 }

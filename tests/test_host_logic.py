@@ -89,6 +89,78 @@ def test_xyzz_group_law_including_special_cases(hh, orc, pyref):
     assert xyzz_to_affine(orc, p, o5) == p.g1_add(want, want)
 
 
+def test_redundant_range_arithmetic_on_the_range_boundaries(hh, orc, pyref):
+    """field.cuh's lazy forms (the NTT butterflies in [0, 4p), the bucket accumulation in [0, 2p)): for inputs ON the boundaries of the documented ranges —
+    0, 1, p - 1, p, p + 1, 2p - 1, 2p, 4p - 1 — and random ones, every result lies in the documented output range and is congruent to the exact answer."""
+    q, rnd = pyref.P, random.Random(11)
+    Rinv = pow(1 << 256, -1, q)
+    lim = lambda xs: orc.ints_to_limbs(xs)
+    ints = lambda arr: orc.limbs_to_ints(arr)
+
+    def run(op, a, b=None, c=None, d=None):
+        A = lim(a)
+        B, C_, D = (lim(x) if x is not None else A for x in (b, c, d))
+        out = np.empty_like(A)
+        hh.hh_fq_lazy(C.c_int(op), P(A), P(B), P(C_), P(D), P(out), C.c_size_t(len(a)))
+        return ints(out)
+    e2 = [0, 1, q - 1, q, q + 1, 2 * q - 1]                           # [0, 2q)
+    e4 = e2 + [2 * q, 2 * q + 1, 3 * q, 4 * q - 1]                    # [0, 4q)
+    r2 = e2 + [rnd.randrange(2 * q) for _ in range(400)]
+    r4 = e4 + [rnd.randrange(4 * q) for _ in range(400)]
+    canon = [0, 1, q - 1] + [rnd.randrange(q) for _ in range(len(r4) - 3)]
+    pairs2 = [(a, b) for a in e2 for b in e2] + [(rnd.randrange(2 * q), rnd.randrange(2 * q)) for _ in range(300)]
+    a2, b2 = [p_[0] for p_ in pairs2], [p_[1] for p_ in pairs2]
+    for got, a, b in zip(run(0, r4, canon), r4, canon):               # mul_lazy: [0, 4q) x [0, q) -> [0, 2q)
+        assert got < 2 * q and got % q == a * b * Rinv % q
+    for got, a, b in zip(run(0, a2, b2), a2, b2):                     # ... and [0, 2q) x [0, 2q) -> [0, 2q) (the accumulate chain)
+        assert got < 2 * q and got % q == a * b * Rinv % q
+    for got, a in zip(run(1, r2), r2):
+        assert got < 2 * q and got % q == a * a * Rinv % q
+    for got, a, b in zip(run(2, a2, b2), a2, b2):
+        assert got < 2 * q and got % q == (a - b) % q
+    for got, a in zip(run(3, r2), r2):
+        assert got < 2 * q and got % q == 2 * a % q
+    for got, a in zip(run(4, r2), r2):
+        assert got <= 2 * q and got % q == -a % q
+    top = [2 * q] * 8 + [rnd.randrange(2 * q + 1) for _ in range(300)]   # mul2_add_2p takes the closed range [0, 2q]
+    aa, bb, cc, dd = ([rnd.choice(top) for _ in range(400)] for _ in range(4))
+    aa[0] = bb[0] = cc[0] = dd[0] = 2 * q
+    for got, a, b, c, d in zip(run(5, aa, bb, cc, dd), aa, bb, cc, dd):
+        assert got < 2 * q and got % q == (a * b + c * d) * Rinv % q
+    for got, a in zip(run(6, r4), r4):
+        assert got < 2 * q and got % q == a % q
+    for got, a, b in zip(run(7, a2, b2), a2, b2):
+        assert got < 4 * q and got == a + b
+    for got, a, b in zip(run(8, a2, b2), a2, b2):
+        assert 0 < got < 4 * q and got == a + 2 * q - b
+    for got, a in zip(run(9, r4), r4):
+        assert got == a % q
+    for got, a in zip(run(10, r2), r2):
+        assert got == (1 if a % q == 0 else 0)
+    for got, a, b in zip(run(11, r4, canon), r4, canon):              # the full product accepts a redundant left operand (ntt_post)
+        assert got == a * b * Rinv % q
+
+
+def test_lazy_mixed_addition_chain_equals_the_canonical_one(hh, orc, pyref):
+    p, rnd = pyref, random.Random(8)
+    pts = [p.g1_mul(p.G1_GEN, rnd.randrange(1, p.R)) for _ in range(40)]
+    seq = [pts[0], pts[0]] + pts[1:] + [None, pts[3], pts[2], pts[7], pts[7]]       # doubling first, identity base, repeats, P then P again late in the chain
+    neg = [0, 0] + [rnd.randrange(2) for _ in pts[1:]] + [0, 1, 0, 0, 1]
+    arr, ng = orc.g1_affine_from_ints(seq), np.array(neg, dtype=np.uint8)
+    lazy, canon = np.zeros(16, dtype=np.uint64), np.zeros(16, dtype=np.uint64)
+    hh.hh_xyzz_sum_lazy(P(arr), P(ng), C.c_size_t(len(seq)), P(lazy))
+    hh.hh_xyzz_sum(P(arr), P(ng), C.c_size_t(len(seq)), P(canon))
+    want = None
+    for q_, s_ in zip(seq, neg):
+        want = p.g1_add(want, p.g1_neg(q_) if s_ else q_)
+    assert xyzz_to_affine(orc, p, lazy) == xyzz_to_affine(orc, p, canon) == want
+    assert all(v < p.P for v in orc.limbs_to_ints(lazy.reshape(4, 4)))             # normalised coordinates
+    two = orc.g1_affine_from_ints([pts[5], pts[9], pts[5], pts[9]])                 # ... + P + Q - P - Q = identity through the lazy path
+    o2 = np.zeros(16, dtype=np.uint64)
+    hh.hh_xyzz_sum_lazy(P(two), P(np.array([0, 0, 1, 1], dtype=np.uint8)), C.c_size_t(4), P(o2))
+    assert xyzz_to_affine(orc, p, o2) is None
+
+
 def test_chained_copy_rows_equals_scalar_copy_and_is_a_bijection():
     """Assembly.copy_rows must only take its vectorised path for cells that are their own (singleton) cycle: `sizes` is kept for cycle
     representatives only, so after copy_rows(A, B) the B cells still read size 1 — a chained copy_rows(B, C) has to fall back to copy()."""

@@ -38,6 +38,15 @@ def test_domain(emu, orc, pyref, j, k):
     pc.check_domain(emu, orc, pyref, j, k)
 
 
+def test_batched_transform_in_slices_of_columns(emu, orc, pyref):
+    """above the workspace budget (ntt_ws_limit_mb; k >= 22 in production) a batch is transformed in slices of columns: same results"""
+    emu.tune(ntt_ws_limit_mb=1)
+    try:
+        pc.check_domain_batch(emu, orc, pyref, 4, 10, 11)           # 2^12-point extended columns of 128 KiB: eight fit, eleven go in two slices
+    finally:
+        emu.tune(ntt_ws_limit_mb=24576)
+
+
 def test_domain_batch(emu, orc, pyref):
     pc.check_domain_batch(emu, orc, pyref, 4, 5, 3)
     pc.check_domain_batch(emu, orc, pyref, 3, 2, 2)          # single-pass transforms, batched

@@ -385,6 +385,17 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
     if (count > 65535) return ctx->fail(ZK_ERR_LIMIT, "zk_ntt batch: more than 65535 columns");
     for (size_t i = 0; i < count; i++) if (!h_cols[i] || (h_srcs && !h_srcs[i])) return ctx->fail(ZK_ERR_ARG, "zk_ntt: null column pointer");
     const size_t N = (size_t)1 << log_n;
+    {   // the passes of a batch run out of place through one workspace of count columns: above a budget, transform the batch in slices of columns
+        const size_t budget = (size_t)std::max(ctx->tune.ntt_ws_limit_mb, 1) << 20, per_col = N * 32;
+        const size_t fit = std::max<size_t>(1, budget / per_col);
+        if (count > fit) {
+            for (size_t i = 0; i < count; i += fit) {
+                int rc = ntt_dev_batch(ctx, h_cols + i, h_srcs ? h_srcs + i : nullptr, std::min(fit, count - i), log_n, omega, fuse);
+                if (rc) return rc;
+            }
+            return ZK_OK;
+        }
+    }
     NttFuse nf;
     if (fuse) nf = *fuse;
     if (log_n == 0) {

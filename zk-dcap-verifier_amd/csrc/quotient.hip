@@ -155,14 +155,16 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_k
         for (int r = 0; r < NR; r++) {
             const u256 a = resolve(sa, pa, r);
             switch (op) {
-                case M_ADD: res[r] = Fr::add(a, resolve(sb, pb, r)); break;
-                case M_SUB: res[r] = Fr::sub(a, resolve(sb, pb, r)); break;
-                case M_MUL: res[r] = Fr::mul(a, resolve(sb, pb, r)); break;
-                case M_SQR: res[r] = Fr::sqr(a); break;
-                case M_DBL: res[r] = Fr::dbl(a); break;
-                case M_NEG: res[r] = Fr::neg(a); break;
-                case M_MULADD: res[r] = Fr::add(Fr::mul(a, resolve(sb, pb, r)), resolve(sc, pc_, r)); break;
-                case M_FOLD2: res[r] = Fr::mul2_add(acc[r], resolve(sc, pc_, r), a, resolve(sb, pb, r)); break;
+                // every value of a row (slots, accumulator) lives in [0, 2p] (field.cuh, redundant ranges): products skip their final subtraction, sums and
+                // differences are corrected by 2p (same cost as by p), memory operands arrive canonical, and the row's result is normalised once at the end
+                case M_ADD: res[r] = Fr::red2p(Fr::add_lazy(a, resolve(sb, pb, r))); break;
+                case M_SUB: res[r] = Fr::sub2(a, resolve(sb, pb, r)); break;
+                case M_MUL: res[r] = Fr::mul_lazy(a, resolve(sb, pb, r)); break;
+                case M_SQR: res[r] = Fr::sqr_lazy(a); break;
+                case M_DBL: res[r] = Fr::dbl2(a); break;
+                case M_NEG: res[r] = Fr::neg2(a); break;
+                case M_MULADD: res[r] = Fr::red2p(Fr::add_lazy(Fr::mul_lazy(a, resolve(sb, pb, r)), resolve(sc, pc_, r))); break;
+                case M_FOLD2: res[r] = Fr::mul2_add_2p(acc[r], resolve(sc, pc_, r), a, resolve(sb, pb, r)); break;
                 default: res[r] = a; break;
             }
         }
@@ -185,7 +187,7 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_k
         ins = nxt; pa = na; pb = nb; pc_ = nc;
     }
 #pragma unroll
-    for (int r = 0; r < NR; r++) store_u256(q.out, idx0 - q.row_base + r * T, acc[r]);
+    for (int r = 0; r < NR; r++) store_u256(q.out, idx0 - q.row_base + r * T, Fr::normalize(acc[r]));
 }
 
 // ------------------------------------------------------------------------------------------------

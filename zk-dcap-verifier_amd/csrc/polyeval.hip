@@ -51,12 +51,16 @@ ZK_KERNEL void pe_eval_partial_kernel(const void* const* polys, const void* poin
     const uint32_t span = T * PE_E, start = blockIdx.x * span;
     u256 xT = x;                                   // x^T, T a power of two
     for (uint32_t t = T; t > 1; t >>= 1) xT = Fr::sqr(xT);
+    // Horner in x^T over c[start + tid + e*T], two coefficients per step: acc*x^2T + c_hi*x^T with ONE Montgomery reduction for both products, sums in the
+    // redundant range [0, 2p) (field.cuh); the product with x^tid below is a full one and returns the canonical value
+    static_assert(PE_E % 2 == 0, "two coefficients per Horner step");
+    const u256 xT2 = Fr::sqr(xT);
     u256 acc = Fr::zero();
-#pragma unroll 8
-    for (int e = (int)PE_E - 1; e >= 0; e--) {     // Horner in x^T over c[start + tid + e*T]
-        const uint32_t idx = start + tid + (uint32_t)e * T;
-        acc = Fr::mul(acc, xT);
-        if (idx < n) acc = Fr::add(acc, load_u256(poly, idx));
+#pragma unroll 4
+    for (int e = (int)PE_E - 1; e >= 1; e -= 2) {
+        const uint32_t ih = start + tid + (uint32_t)e * T, il = ih - T;
+        const u256 ch = ih < n ? load_u256(poly, ih) : Fr::zero(), cl = il < n ? load_u256(poly, il) : Fr::zero();
+        acc = Fr::red2p(Fr::add_lazy(Fr::mul2_add_2p(acc, xT2, ch, xT), cl));
     }
     acc = Fr::mul(acc, fr_pow_u32(x, tid));
     acc = pe_block_sum(acc);
@@ -169,20 +173,21 @@ ZK_KERNEL void kd_carry_kernel(void* carries, uint32_t nblk, void* out) {
 // ---- linear combinations (SHPLONK / multiopen polynomial combos) -----------------------------------
 // out[i] = sum_j s_j * p_j[i]: the `poly * power_of_y` ... `reduce(|acc, poly| acc + &poly)` chains of
 // halo2_proofs src/poly/kzg/multiopen/shplonk/prover.rs, one pass over all inputs instead of one pass per term.
-// args: [count pointers | pad to 32 B | count scalars]; a scalar equal to mont(1) skips its multiplication.
+// args: [count pointers | pad to 32 B | count scalars]
 ZK_KERNEL void pe_lincomb_kernel(const void* const* polys, const void* scalars, uint32_t count, size_t n, void* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const u256 one = Fr::one();
+    // terms are taken two at a time with ONE Montgomery reduction for both products (192 instead of 256 multiply-adds) and summed in the redundant range
+    // [0, 2p) (field.cuh); the element is normalised when it is stored.  (A scalar mont(1) is just another scalar: v * R * R^-1 = v.)
     for (; i < n; i += stride) {
         u256 acc = Fr::zero();
-        for (uint32_t j = 0; j < count; j++) {
-            const u256 s = load_u256(scalars, j);
-            u256 v = load_u256(polys[j], i);
-            if (!Fr::eq(s, one)) v = Fr::mul(v, s);
-            acc = Fr::add(acc, v);
+        uint32_t j = 0;
+        for (; j + 1 < count; j += 2) {
+            const u256 t = Fr::mul2_add_2p(load_u256(polys[j], i), load_u256(scalars, j), load_u256(polys[j + 1], i), load_u256(scalars, j + 1));
+            acc = Fr::red2p(Fr::add_lazy(acc, t));
         }
-        store_u256(out, i, acc);
+        if (j < count) acc = Fr::red2p(Fr::add_lazy(acc, Fr::mul_lazy(load_u256(polys[j], i), load_u256(scalars, j))));
+        store_u256(out, i, Fr::normalize(acc));
     }
 }
 

@@ -281,10 +281,15 @@ struct Field {
         return reduce_once(r);
     }
 
+    // a * R^-1: the Montgomery reduction alone (64 m_i*p_j products; a product with the constant 1 would spend 128) — field_redc_body.inc
     static ZK_HD u256 from_mont(const u256& a) {
-        u256 o1 = zero();
-        o1.v[0] = 1;
-        return mul(a, o1);
+        uint64_t acc = 0;
+        uint32_t cnt = 0;
+        uint32_t m[8];
+        u256 r;
+#include "field_redc_body.inc"
+        r.v[7] = (uint32_t)acc;
+        return reduce_once(r);
     }
     static ZK_HD u256 to_mont(const u256& a) { return mul(a, R2()); }
 

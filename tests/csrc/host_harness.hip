@@ -45,6 +45,7 @@ void hh_xyzz_sum_lazy(const Affine* pts, const uint8_t* neg, size_t n, XYZZ* out
     xyzz_normalize(acc);
     *out = acc;
 }
+void hh_xyzz_add_lazy(const XYZZ* a, const XYZZ* b, XYZZ* out) { XYZZ t = *a; xyzz_add_lazy(t, *b); xyzz_add_lazy(t, *b); xyzz_normalize(t); *out = t; }   // a + b + b: the second addition meets lazy coordinates
 void hh_xyzz_add(const XYZZ* a, const XYZZ* b, XYZZ* out) { XYZZ t = *a; xyzz_add(t, *b); *out = t; }
 void hh_xyzz_dbl(const XYZZ* a, XYZZ* out) { *out = xyzz_dbl(*a); }
 }

@@ -155,6 +155,20 @@ def test_lazy_mixed_addition_chain_equals_the_canonical_one(hh, orc, pyref):
         want = p.g1_add(want, p.g1_neg(q_) if s_ else q_)
     assert xyzz_to_affine(orc, p, lazy) == xyzz_to_affine(orc, p, canon) == want
     assert all(v < p.P for v in orc.limbs_to_ints(lazy.reshape(4, 4)))             # normalised coordinates
+    # the full addition in the lazy range: a + b + b, a + a + a (doubling branch first), identity operands
+    o3, o4 = np.zeros(16, dtype=np.uint64), np.zeros(16, dtype=np.uint64)
+    other = np.zeros(16, dtype=np.uint64)
+    hh.hh_xyzz_sum(P(orc.g1_affine_from_ints(pts[20:30])), P(np.zeros(10, dtype=np.uint8)), C.c_size_t(10), P(other))
+    w2 = None
+    for q_ in pts[20:30]:
+        w2 = p.g1_add(w2, q_)
+    hh.hh_xyzz_add_lazy(P(canon), P(other), P(o3))
+    assert xyzz_to_affine(orc, p, o3) == p.g1_add(p.g1_add(want, w2), w2)
+    hh.hh_xyzz_add_lazy(P(canon), P(canon), P(o4))
+    assert xyzz_to_affine(orc, p, o4) == p.g1_add(p.g1_add(want, want), want)
+    ident = np.zeros(16, dtype=np.uint64)
+    hh.hh_xyzz_add_lazy(P(ident), P(other), P(o4))
+    assert xyzz_to_affine(orc, p, o4) == p.g1_add(w2, w2)
     two = orc.g1_affine_from_ints([pts[5], pts[9], pts[5], pts[9]])                 # ... + P + Q - P - Q = identity through the lazy path
     o2 = np.zeros(16, dtype=np.uint64)
     hh.hh_xyzz_sum_lazy(P(two), P(np.array([0, 0, 1, 1], dtype=np.uint8)), C.c_size_t(4), P(o2))

@@ -154,6 +154,32 @@ ZK_HD void xyzz_add(XYZZ& acc, const XYZZ& q) {
     acc.zzz = Fq::mul(Fq::mul(acc.zzz, q.zzz), PPP);
 }
 
+// acc += q with both points' coordinates in [0, 2q) (the bucket-reduction chains: merge levels, row / column sums, weight-bit classes); xyzz_normalize at the end
+ZK_HD void xyzz_add_lazy(XYZZ& acc, const XYZZ& q) {
+    if (xyzz_is_identity(q)) return;
+    if (xyzz_is_identity(acc)) { acc = q; return; }
+    const u256 U1 = Fq::mul_lazy(acc.x, q.zz);
+    const u256 U2 = Fq::mul_lazy(q.x, acc.zz);
+    const u256 S1 = Fq::mul_lazy(acc.y, q.zzz);
+    const u256 S2 = Fq::mul_lazy(q.y, acc.zzz);
+    const u256 P = Fq::sub2(U2, U1);
+    const u256 R = Fq::sub2(S2, S1);
+    if (Fq::is_zero_mod(P)) {
+        if (Fq::is_zero_mod(R)) { xyzz_normalize(acc); acc = xyzz_dbl(acc); }
+        else acc = xyzz_identity();
+        return;
+    }
+    const u256 PP = Fq::sqr_lazy(P);
+    const u256 PPP = Fq::mul_lazy(P, PP);
+    const u256 Q = Fq::mul_lazy(U1, PP);
+    const u256 X3 = Fq::sub2(Fq::sub2(Fq::sqr_lazy(R), PPP), Fq::dbl2(Q));
+    const u256 Y3 = Fq::mul2_add_2p(R, Fq::sub2(Q, X3), S1, Fq::neg2(PPP));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = Fq::mul_lazy(Fq::mul_lazy(acc.zz, q.zz), PP);
+    acc.zzz = Fq::mul_lazy(Fq::mul_lazy(acc.zzz, q.zzz), PPP);
+}
+
 ZK_HD Affine load_affine(const void* base, size_t idx) {
     Affine p;
     p.x = load_u256(base, 2 * idx);

@@ -585,7 +585,8 @@ ZK_KERNEL void msm_merge_kernel(MsmPlan p, uint32_t r, uint32_t Mpow_prev) {
     const void* in = p.sub[(r - 1) & 1];
     const size_t ibase = (size_t)col * p.sub_stride[(r - 1) & 1] + so_in[b] + (size_t)k * p.M;
     XYZZ acc = load_xyzz(in, ibase);
-    for (uint32_t m = 1; m < p.M && k * p.M + m < cnt_in; m++) xyzz_add(acc, load_xyzz(in, ibase + m));
+    for (uint32_t m = 1; m < p.M && k * p.M + m < cnt_in; m++) xyzz_add_lazy(acc, load_xyzz(in, ibase + m));   // coordinates in [0, 2q) along the chain (ec.cuh)
+    xyzz_normalize(acc);
     store_xyzz(p.sub[r & 1], (size_t)col * p.sub_stride[r & 1] + t, acc);
 }
 
@@ -625,7 +626,7 @@ __device__ __forceinline__ XYZZ rc_wave_sum(XYZZ acc) {
     __syncthreads();
     for (uint32_t d = SEG >> 1; d > 0; d >>= 1) {
         const bool on = (tid & (SEG - 1)) < d;
-        if (on) { xyzz_add(acc, get(tid + d)); }
+        if (on) { xyzz_add_lazy(acc, get(tid + d)); }              // callers normalise what they store
         __syncthreads();
         if (on) put(acc);
         __syncthreads();
@@ -652,10 +653,11 @@ ZK_KERNEL void msm_rowcol_kernel(MsmPlan p) {
         const uint32_t w = row ? ((fixed << lo_bits) | m) : ((m << lo_bits) | fixed);
         if (w >= 1 && w <= B) {
             const uint32_t b = w - 1;
-            if (so[b + 1] > so[b]) xyzz_add(acc, load_xyzz(buf, cbase + so[b]));
+            if (so[b + 1] > so[b]) xyzz_add_lazy(acc, load_xyzz(buf, cbase + so[b]));
         }
     }
     acc = rc_wave_sum<RC_G>(acc);
+    xyzz_normalize(acc);
     if (live && lane == 0) store_xyzz(p.cls[0], (size_t)col * (n_hi + n_lo) + g, acc);
 }
 // grid (c, nb): class t < hi_bits sums the rows whose index has bit t, class hi_bits + t' the columns whose index has bit t'
@@ -667,8 +669,9 @@ ZK_KERNEL void msm_rc_class_kernel(MsmPlan p) {
     const size_t base = (size_t)col * (n_hi + n_lo) + (rows ? 0 : n_hi);
     XYZZ acc = xyzz_identity();
     for (uint32_t m = tid; m < count; m += RC_T)
-        if ((m >> bit) & 1u) xyzz_add(acc, load_xyzz(p.cls[0], base + m));
+        if ((m >> bit) & 1u) xyzz_add_lazy(acc, load_xyzz(p.cls[0], base + m));
     acc = rc_wave_sum<RC_T>(acc);
+    xyzz_normalize(acc);
     if (tid == 0) store_xyzz(p.cls[1], (size_t)col * p.c + t, acc);
 }
 

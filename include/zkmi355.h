@@ -300,7 +300,7 @@ typedef struct zk_plonk_pk_desc {
  * blinding, per permutation set and per lookup the grand-product blinding, then the n coefficients of the vanishing argument's random polynomial. */
 typedef void (*zk_rng_fn)(void* user, size_t n, void* out_fr);
 /* advice: n_advice columns of 2^k x 32 B (HOST, or DEVICE when advice_on_device — then consumed: they hold coefficients afterwards); instances: HOST,
- * instance_lens[c] canonical 32-byte values per instance column.  The proof (32 bytes per commitment and evaluation) is written to proof_out;
+ * instance_lens[c] canonical 32-byte values per instance column.  The proof (32 bytes per commitment and per evaluation; 64 per commitment under transcript 2) is written to proof_out;
  * *proof_len receives its length (ZK_ERR_LIMIT when proof_cap is too small).  Errors of the entry points it drives are returned as they are
  * (e.g. ZK_ERR_ARG from zk_lookup_permute_batch_dev for a lookup input outside its table: halo2's Error::ConstraintSystemFailure). */
 int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,

@@ -34,9 +34,56 @@ static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 
 inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 inline thread_local unsigned char* emu_smem = nullptr;
+// Work-item contexts.  glibc's swapcontext saves and restores the signal mask — two system calls per switch, and a barrier-heavy kernel switches millions of
+// times: the test suite spent most of its time in the kernel.  On x86-64 the switch is done here instead (callee-saved registers + stack pointer, System V
+// ABI); elsewhere ucontext remains.
+#if defined(__x86_64__)
+struct EmuCtx { void* sp; };
+extern "C" void emu_ctx_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.weak emu_ctx_switch
+.type emu_ctx_switch,@function
+emu_ctx_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_ctx_switch,.-emu_ctx_switch
+)");
+static inline void emu_swap(EmuCtx* from, EmuCtx* to) { emu_ctx_switch(&from->sp, to->sp); }
+static inline void emu_make(EmuCtx* c, void* stack, size_t size, void (*entry)()) {
+    void** sp = reinterpret_cast<void**>((reinterpret_cast<uintptr_t>(stack) + size) & ~(uintptr_t)15);
+    *--sp = nullptr;                               // the entry function's (never used) return address: rsp = 8 mod 16 at its first instruction
+    *--sp = reinterpret_cast<void*>(entry);        // where the first switch into this context returns to
+    for (int i = 0; i < 6; i++) *--sp = nullptr;   // rbp rbx r12 r13 r14 r15
+    c->sp = sp;
+}
+#else
+struct EmuCtx { ucontext_t uc; };
+static inline void emu_swap(EmuCtx* from, EmuCtx* to) { swapcontext(&from->uc, &to->uc); }
+static inline void emu_make(EmuCtx* c, void* stack, size_t size, void (*entry)()) {
+    getcontext(&c->uc);
+    c->uc.uc_stack.ss_sp = stack;
+    c->uc.uc_stack.ss_size = size;
+    c->uc.uc_link = nullptr;
+    makecontext(&c->uc, entry, 0);
+}
+#endif
 struct EmuSched {
-    ucontext_t main;
-    std::vector<ucontext_t> ctx;
+    EmuCtx main;
+    std::vector<EmuCtx> ctx;
     std::vector<char> done;
     std::vector<char> stack_mem;     // nt stacks, grow-only
     unsigned cur = 0;
@@ -46,7 +93,7 @@ struct EmuSched {
 };
 inline thread_local EmuSched* emu_sched = nullptr;
 // barrier = hand the OS thread back to the scheduler; it resumes this work-item after every other one has run up to its own barrier
-static inline void __syncthreads() { EmuSched* s = emu_sched; swapcontext(&s->ctx[s->cur], &s->main); }
+static inline void __syncthreads() { EmuSched* s = emu_sched; emu_swap(&s->ctx[s->cur], &s->main); }
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 template <class T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
@@ -100,7 +147,7 @@ static void emu_fiber_main() {
             __syncthreads();                      // workgroups run one after another (static __shared__ reuse)
         }
     s->done[me] = 1;
-    swapcontext(&s->ctx[me], &s->main);           // never resumed
+    emu_swap(&s->ctx[me], &s->main);              // never resumed
 }
 inline std::mutex& emu_launch_mutex() { static std::mutex m; return m; }
 template <class F>
@@ -123,20 +170,14 @@ static inline void emu_launch(dim3 grid, dim3 block, size_t smem_bytes, F f) {
     emu_sched = s;
     emu_smem = static_cast<unsigned char*>(smem);
     blockDim = block; gridDim = grid;
-    for (unsigned t = 0; t < nt; t++) {
-        getcontext(&s->ctx[t]);
-        s->ctx[t].uc_stack.ss_sp = s->stack_mem.data() + (size_t)t * STACK;
-        s->ctx[t].uc_stack.ss_size = STACK;
-        s->ctx[t].uc_link = nullptr;
-        makecontext(&s->ctx[t], emu_fiber_main, 0);
-    }
+    for (unsigned t = 0; t < nt; t++) emu_make(&s->ctx[t], s->stack_mem.data() + (size_t)t * STACK, STACK, emu_fiber_main);
     unsigned remaining = nt;
     while (remaining) {
         for (unsigned t = 0; t < nt; t++) {
             if (s->done[t]) continue;
             s->cur = t;
             threadIdx = dim3(t % block.x, t / block.x, 0);
-            swapcontext(&s->main, &s->ctx[t]);
+            emu_swap(&s->main, &s->ctx[t]);
             if (s->done[t]) remaining--;
         }
     }

@@ -165,8 +165,13 @@ static inline void emu_launch(dim3 grid, dim3 block, size_t smem_bytes, F f) {
     s->run = [](void* c) { (*static_cast<F*>(c))(); };
     s->arg = &f;
     s->grid = grid;
-    void* smem = nullptr;
-    if (posix_memalign(&smem, 256, smem_bytes ? smem_bytes : 256)) abort();
+    static thread_local void* smem = nullptr;      // dynamic LDS: one grow-only buffer per launching thread (an allocation per launch was an mmap / munmap pair)
+    static thread_local size_t smem_cap = 0;
+    if (smem_bytes > smem_cap || !smem) {
+        free(smem);
+        smem_cap = smem_bytes > 4096 ? smem_bytes : 4096;
+        if (posix_memalign(&smem, 256, smem_cap)) abort();
+    }
     emu_sched = s;
     emu_smem = static_cast<unsigned char*>(smem);
     blockDim = block; gridDim = grid;
@@ -182,7 +187,6 @@ static inline void emu_launch(dim3 grid, dim3 block, size_t smem_bytes, F f) {
         }
     }
     emu_sched = nullptr;
-    free(smem);
 }
 #define ZK_LAUNCH(kern, grid, block, smem, stream, ...) \
     emu_launch(dim3(grid), dim3(block), (smem), [&]() { kern(__VA_ARGS__); })

@@ -31,7 +31,7 @@ def _check(be, k, seed, twin=True):
     return shape
 
 
-@pytest.mark.parametrize("seed", list(range(1, 13)))
+@pytest.mark.parametrize("seed", list(range(1, 25)))
 def test_random_circuits_emulated(emu, orc, seed):
     _check(emu, 5 + seed % 2, seed)
 

@@ -294,10 +294,18 @@ typedef struct zk_plonk_pk_desc {
     uint32_t transcript;                      /* 0: Blake2bWrite + Challenge255, y-parity flag in bit 255 (stack A, sgx_dcap_verifier.rs:813);
                                                * 1: snark-verifier PoseidonTranscript<NativeLoader> (T = 3, RATE = 2, R_F = 8, R_P = 57), flag in bit 254 (stack B gen_proof, base.rs:200-212);
                                                * 2: snark-verifier EvmTranscript (Keccak-256, 32-byte big-endian words, uncompressed points; gen_evm_proof_shplonk, base.rs:193-199) */
+    uint32_t draw_schedule;                   /* order in which the caller's rng is consumed (see zk_rng_fn): 1 = halo2's (bindings set this), 0 = this library's rounds 1-2 */
 } zk_plonk_pk_desc;
 /* the caller's RNG (`&mut rng` of create_proof): fill out_fr with n uniform field elements as Montgomery limbs (n x 32 B).  Called from a helper thread of the
- * library, once per Fr::random block, in the order halo2 draws them: advice blinding per column, then per lookup the permuted-input and permuted-table
- * blinding, per permutation set and per lookup the grand-product blinding, then the n coefficients of the vanishing argument's random polynomial. */
+ * library, once per Fr::random block.  draw_schedule 1 follows halo2_proofs v2023_01_20 draw by draw ([3P-MEM]) — including the Blind(Fr::random) every
+ * commitment draws, which KZG discards but which advances the stream:
+ *   plonk/prover.rs            per advice column its n - usable_rows blinding rows; then one Blind per advice column
+ *   lookup/prover.rs           per lookup: blinding_factors + 1 permuted-input rows, as many permuted-table rows (permute_expression_pair), two Blinds (commit_values)
+ *   permutation/prover.rs      per column set: blinding_factors rows, one Blind
+ *   lookup/prover.rs           per lookup product: blinding_factors rows, one Blind
+ *   vanishing/prover.rs        commit: the n coefficients of the random polynomial, one Blind;  construct: one Blind per h(X) piece
+ * so a proof consumes exactly the draws the CPU create_proof would and leaves the caller's rng in the same state (all draws are complete when the call returns ZK_OK).
+ * draw_schedule 0 is the order of this library's first two rounds (no Blind draws; every lookup's input rows before any table rows), kept for its golden proofs. */
 typedef void (*zk_rng_fn)(void* user, size_t n, void* out_fr);
 /* advice: n_advice columns of 2^k x 32 B (HOST, or DEVICE when advice_on_device — then consumed: they hold coefficients afterwards); instances: HOST,
  * instance_lens[c] canonical 32-byte values per instance column.  The proof (32 bytes per commitment and per evaluation; 64 per commitment under transcript 2) is written to proof_out;

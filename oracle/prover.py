@@ -70,11 +70,12 @@ class _Writer:
         self.out += (s % R).to_bytes(32, "little")
 
     def write_point(self, pt):
-        x, y = (0, 0) if pt is None else pt
+        if pt is None:                                               # halo2's common_point refuses the identity (it has no coordinates)
+            raise ValueError("cannot write points at infinity to the transcript")
+        x, y = pt
         self.h.update(b"\x01" + x.to_bytes(32, "little") + y.to_bytes(32, "little"))
         b = bytearray(x.to_bytes(32, "little"))
-        if pt is not None:
-            b[31] |= (y & 1) << 7
+        b[31] |= (y & 1) << 7
         self.out += b
 
 
@@ -261,10 +262,18 @@ def _permute_expression_pair(inp, tab, usable, blind_in, blind_tab):
     return a + list(blind_in), s + list(blind_tab)
 
 
-def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.Generator, require_satisfied: bool = True) -> bytes:
+def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.Generator, require_satisfied: bool = True, draw_schedule: int = 1) -> bytes:
     """advice: cs.num_advice_columns lists of n canonical ints (rows past the usable ones are overwritten with blinding); instances: lists of
     canonical ints.  Returns the proof bytes (Blake2b transcript).  require_satisfied = False: behave as halo2 does on a witness that violates a gate —
-    no check, extended_to_coeff silently truncates h(X) to (d-1) n coefficients (poly/domain.rs) — instead of stopping (differential tests on random circuits)."""
+    no check, extended_to_coeff silently truncates h(X) to (d-1) n coefficients (poly/domain.rs) — instead of stopping (differential tests on random circuits).
+    draw_schedule: 1 = every Fr::random of halo2's provers in place, including the Blind each commitment draws (`blind()` below: drawn and dropped, as KZG does);
+    0 = the order of this repo's rounds 1-2 (no Blind draws, the lookups' input rows all before their table rows) — kept for the first set of golden proofs."""
+    assert draw_schedule in (0, 1)
+
+    def blind(times=1):                                              # `Blind(Scheme::Scalar::random(&mut rng))`: the stream advances, the value is unused under KZG
+        if draw_schedule == 1:
+            for _ in range(times):
+                rand_fr(rng, 1)
     cs, k, n = keys.cs, params.k, params.n
     w = p.omega(k)
     ek = _extended_k(cs, k)
@@ -287,6 +296,7 @@ def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.G
         assert len(col) == n
         col[usable:] = rand_fr(rng, n - usable)
         adv_values.append(col)
+    blind(len(adv_values))                                           # plonk/prover.rs: `let blinds: Vec<_> = advice_values.iter().map(|_| Blind(random)).collect()`
     for col in adv_values:
         tr.write_point(params.commit_lagrange(col))
     # 3 ---------------------------------------------------------------------------------------------------------------------------------------
@@ -305,9 +315,17 @@ def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.G
             out.append(acc)
         return out
     compressed = [(compress(lk.input_expressions), compress(lk.table_expressions)) for lk in cs.lookups]
-    bi = [rand_fr(rng, bf + 1) for _ in range(L)]
-    bt = [rand_fr(rng, bf + 1) for _ in range(L)]
-    permuted = [_permute_expression_pair(c[0], c[1], usable, bi[j], bt[j]) for j, c in enumerate(compressed)]
+    if draw_schedule == 1:                                           # lookup/prover.rs commit_permuted, lookup by lookup: permute_expression_pair extends the input
+        permuted = []                                                # then the table with random rows, commit_values draws one Blind per commitment
+        for cin_, ctab_ in compressed:
+            bi_ = rand_fr(rng, bf + 1)
+            bt_ = rand_fr(rng, bf + 1)
+            permuted.append(_permute_expression_pair(cin_, ctab_, usable, bi_, bt_))
+            blind(2)
+    else:
+        bi = [rand_fr(rng, bf + 1) for _ in range(L)]
+        bt = [rand_fr(rng, bf + 1) for _ in range(L)]
+        permuted = [_permute_expression_pair(c[0], c[1], usable, bi[j], bt[j]) for j, c in enumerate(compressed)]
     for a_, s_ in permuted:
         tr.write_point(params.commit_lagrange(a_))
         tr.write_point(params.commit_lagrange(s_))
@@ -316,9 +334,15 @@ def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.G
     perm_cols = [lag[t][i] for t, i in cs.permutation_columns]
     chunk = cs.permutation_chunk_len()
     n_sets = (len(perm_cols) + chunk - 1) // chunk if perm_cols else 0
-    perm_blind = [rand_fr(rng, bf) for _ in range(n_sets)]
-    lookup_blind = [rand_fr(rng, bf) for _ in range(L)]
-    random_poly = rand_fr(rng, n)
+    perm_blind, lookup_blind = [], []
+    for _ in range(n_sets):                                          # permutation/prover.rs: the set's blinding rows, then its Blind
+        perm_blind.append(rand_fr(rng, bf))
+        blind()
+    for _ in range(L):                                               # lookup/prover.rs commit_product: the same per lookup
+        lookup_blind.append(rand_fr(rng, bf))
+        blind()
+    random_poly = rand_fr(rng, n)                                    # vanishing/prover.rs commit: n coefficients, one Blind; construct: one Blind per piece of h(X)
+    blind(1 + (cs.degree() - 1))
     wp = [pow(w, i, R) for i in range(n)]
     zs, last_z = [], 1
     for s in range(n_sets):

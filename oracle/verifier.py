@@ -37,7 +37,9 @@ class _Reader:
         self.h.update(b"\x02" + (s % R).to_bytes(32, "little"))
 
     def common_point(self, pt):
-        x, y = (0, 0) if pt is None else pt
+        if pt is None:                                               # Blake2bRead::common_point fails on the identity, so verify_proof returns an error
+            raise ValueError("cannot write points at infinity to the transcript")
+        x, y = pt
         self.h.update(b"\x01" + x.to_bytes(32, "little") + y.to_bytes(32, "little"))
 
     def _take(self) -> bytes:

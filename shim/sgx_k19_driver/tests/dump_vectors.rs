@@ -2,6 +2,8 @@
 //! Same call sequence as the reference's test (circuits/src/sgx_dcap_verifier.rs:790-844) — MockProver, gen_srs, keygen_vk, keygen_pk, create_proof,
 //! verify_proof — with k from the environment (default 19; needs ECDSA_CONFIG=src/configs/ecdsa_circuit.tmp.config, :163-168) and ChaCha20 instead of
 //! OsRng so that proof bytes are reproducible.  Run with HALO2_MI355X=0 to dump REFERENCE vectors, with the backend on to compare.
+//! Kind 5 records how many rng calls precede each transcript squeeze (a counting wrapper around the ChaCha20 + a recording wrapper around Blake2bWrite): the
+//! one datum that settles zk_plonk_pk_desc.draw_schedule — tests/test_rust_vectors.py compares it with plonk/prover.py draw_plan.
 //! Uncompiled in the build image (no rustc there).
 use std::io::Write;
 
@@ -23,7 +25,10 @@ use halo2_base::halo2_proofs::{
 };
 use halo2_base::utils::fs::gen_srs;
 use halo2_base64::sgx_dcap_verifier::SgxDcapVerifierCircuit; // `pub mod sgx_dcap_verifier` in circuits/src/lib.rs; SgxDcapVerifierCircuit::new at :252-257
+use halo2_base::halo2_proofs::transcript::{Transcript, TranscriptWrite};
 use rand::{RngCore, SeedableRng};
+use std::cell::Cell;
+use std::rc::Rc;
 use rand_chacha::ChaCha20Rng;
 
 fn raw<T>(v: &[T]) -> &[u8] {
@@ -37,6 +42,63 @@ fn dump(dir: &str, name: &str, kind: u32, parts: &[&[u8]]) {
     f.write_all(&kind.to_le_bytes()).unwrap();
     for p in parts {
         f.write_all(p).unwrap();
+    }
+}
+
+/// The seeded rng behind a counter: every `Fr::random(&mut rng)` of create_proof — blinding rows, the Blind of each commitment, the random polynomial —
+/// advances `calls` (in units of next_u64; `per_fr` calibrates one Fr::random).  zk_plonk_pk_desc.draw_schedule = 1 claims this exact sequence
+/// (include/zkmi355.h zk_rng_fn); kind 5 below is what settles it.
+struct CountingRng {
+    inner: ChaCha20Rng,
+    calls: Rc<Cell<u64>>,
+}
+impl RngCore for CountingRng {
+    fn next_u32(&mut self) -> u32 {
+        self.calls.set(self.calls.get() + 1);
+        self.inner.next_u32()
+    }
+    fn next_u64(&mut self) -> u64 {
+        self.calls.set(self.calls.get() + 1);
+        self.inner.next_u64()
+    }
+    fn fill_bytes(&mut self, dest: &mut [u8]) {
+        self.calls.set(self.calls.get() + ((dest.len() + 7) / 8) as u64);
+        self.inner.fill_bytes(dest)
+    }
+    fn try_fill_bytes(&mut self, dest: &mut [u8]) -> Result<(), rand::Error> {
+        self.fill_bytes(dest);
+        Ok(())
+    }
+}
+
+/// Blake2bWrite behind a recorder: at every squeeze_challenge it notes how far the rng has advanced, and which transcript byte offset the proof has reached.
+struct RecordingTranscript {
+    inner: Blake2bWrite<Vec<u8>, G1Affine, Challenge255<G1Affine>>,
+    calls: Rc<Cell<u64>>,
+    points: u64,
+    scalars: u64,
+    at_squeeze: Vec<[u64; 3]>, // (rng calls so far, points written so far, scalars written so far)
+}
+impl Transcript<G1Affine, Challenge255<G1Affine>> for RecordingTranscript {
+    fn squeeze_challenge(&mut self) -> Challenge255<G1Affine> {
+        self.at_squeeze.push([self.calls.get(), self.points, self.scalars]);
+        self.inner.squeeze_challenge()
+    }
+    fn common_point(&mut self, point: G1Affine) -> std::io::Result<()> {
+        self.inner.common_point(point)
+    }
+    fn common_scalar(&mut self, scalar: Fr) -> std::io::Result<()> {
+        self.inner.common_scalar(scalar)
+    }
+}
+impl TranscriptWrite<G1Affine, Challenge255<G1Affine>> for RecordingTranscript {
+    fn write_point(&mut self, point: G1Affine) -> std::io::Result<()> {
+        self.points += 1;
+        self.inner.write_point(point)
+    }
+    fn write_scalar(&mut self, scalar: Fr) -> std::io::Result<()> {
+        self.scalars += 1;
+        self.inner.write_scalar(scalar)
     }
 }
 
@@ -98,6 +160,24 @@ fn prove_k19_and_dump_vectors() {
     let mut probe = ChaCha20Rng::seed_from_u64(7);
     let first_draws: Vec<u64> = (0..8).map(|_| probe.next_u64()).collect();
     dump(&dir, &format!("proof_sgx_k{k}_seed7"), 4, &[&(proof.len() as u64).to_le_bytes(), &proof, raw(&first_draws)]);
+
+    // ---- kind 5: the draw schedule — how far the rng stands at every transcript squeeze of the SAME proof (must reproduce the kind-4 bytes) -----------------
+    //   per_fr u32 (next_u64 calls of one Fr::random) | n_squeezes u32 | n_squeezes x (calls u64, points written u64, scalars written u64) | total calls u64
+    let calls = Rc::new(Cell::new(0u64));
+    let mut crng = CountingRng { inner: ChaCha20Rng::seed_from_u64(7), calls: calls.clone() };
+    let per_fr = {
+        use halo2_base::halo2_proofs::halo2curves::group::ff::Field;
+        let c = Rc::new(Cell::new(0u64));
+        let _ = Fr::random(CountingRng { inner: ChaCha20Rng::seed_from_u64(1), calls: c.clone() });
+        c.get() as u32
+    };
+    let mut rec = RecordingTranscript { inner: Blake2bWrite::<_, _, Challenge255<_>>::init(vec![]), calls: calls.clone(), points: 0, scalars: 0, at_squeeze: vec![] };
+    let circuit2 = SgxDcapVerifierCircuit::<Fr>::new(cert.trim().bytes().collect());
+    create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<'_, Bn256>, Challenge255<G1Affine>, _, RecordingTranscript, _>(
+        &params, &pk, &[circuit2], &[&[]], &mut crng, &mut rec).unwrap();
+    assert_eq!(rec.inner.finalize(), proof, "the recording transcript changed the proof");
+    let flat: Vec<u64> = rec.at_squeeze.iter().flat_map(|t| t.iter().copied()).collect();
+    dump(&dir, &format!("draws_sgx_k{k}_seed7"), 5, &[&per_fr.to_le_bytes(), &(rec.at_squeeze.len() as u32).to_le_bytes(), raw(&flat), &calls.get().to_le_bytes()]);
 
     let strategy = SingleStrategy::new(&params);
     let mut rt = Blake2bRead::<_, _, Challenge255<_>>::init(&proof[..]);

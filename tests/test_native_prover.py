@@ -11,15 +11,15 @@ from zk_dcap_verifier_amd.transcript import Blake2bWrite
 import test_create_proof as tcp
 
 
-def _toy(be, k, seed):
+def _toy(be, k, seed, draw_schedule=1):
     import verifier
     cs, fixed, asm, advice, instances = tcp.toy_circuit(k)
     params = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
     pk = plonk.keygen(params, cs, fixed, asm)
-    native = plonk.NativeProver(params, pk)
+    native = plonk.NativeProver(params, pk, draw_schedule=draw_schedule)
     proof = native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(seed))
     tr = Blake2bWrite()
-    plonk.create_proof(params, pk, [a.copy() for a in advice], instances, np.random.default_rng(seed), tr)
+    plonk.create_proof(params, pk, [a.copy() for a in advice], instances, np.random.default_rng(seed), tr, draw_schedule=draw_schedule)
     assert proof == tr.finalize()
     assert verifier.verify_proof(pk.vk, tcp.TAU, instances, proof) is True
     # device-resident witness: same bytes
@@ -30,7 +30,7 @@ def _toy(be, k, seed):
     return proof
 
 
-def _sgx(be, k, census, golden=None):
+def _sgx(be, k, census, golden=None, draw_schedule=1):
     import os, sys
     import verifier
     from conftest import ROOT
@@ -39,7 +39,7 @@ def _sgx(be, k, census, golden=None):
     cs, fixed, asm, advice = sc.build(z, be, k, census=census)
     params = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
     pk = plonk.keygen(params, cs, fixed, asm)
-    proof = plonk.NativeProver(params, pk).create_proof(advice, [], np.random.default_rng(3))
+    proof = plonk.NativeProver(params, pk, draw_schedule=draw_schedule).create_proof(advice, [], np.random.default_rng(3))
     if golden:
         assert proof == tcp._golden(golden)
     assert verifier.verify_proof(pk.vk, tcp.TAU, [], proof) is True
@@ -54,6 +54,44 @@ def test_native_prover_emits_the_golden_toy_proof_emulated(emu, orc):
 def test_native_prover_emits_the_sgx_shaped_goldens_emulated(emu, orc):
     _sgx(emu, 8, "chip_estimate", tcp.GOLDEN_SGX)
     _sgx(emu, 9, "reference_exact", tcp.GOLDEN_REF_EXACT)
+
+
+def test_native_prover_draw_schedule_0_goldens_emulated(emu, orc):
+    """the order of Fr::random draws of this repo's rounds 1-2 (no Blind draws, lookup input rows before table rows) still gives the first set of goldens"""
+    assert _toy(emu, 6, 7, draw_schedule=0) == tcp._golden(tcp.sched0(tcp.GOLDEN_PROOF))
+    _sgx(emu, 8, "chip_estimate", tcp.sched0(tcp.GOLDEN_SGX), draw_schedule=0)
+
+
+def test_draw_schedule_leaves_the_callers_rng_where_halo2_would(emu, orc):
+    """Under schedule 1 a proof consumes exactly draw_plan's draws — blinding rows, random polynomial AND the Blind(Fr::random) of every commitment (advice,
+    permuted pairs, grand products, random polynomial, h pieces) — and all of them are made before zk_plonk_create_proof returns, so a caller that proves twice
+    with one seeded rng (the shape of a Rust caller's `&mut rng`) gets the same two proofs from the native prover and from the Python twin; the running
+    totals per challenge are what shim/sgx_k19_driver's counting RNG dumps (tests/test_rust_vectors.py kind 5)."""
+    from zk_dcap_verifier_amd.plonk.prover import draw_plan
+    cs, fixed, asm, advice, instances = tcp.toy_circuit(6)
+    params = z.kzg.ParamsKZG.setup(6, tcp.TAU, backend=emu)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    native = plonk.NativeProver(params, pk)
+    rng_n, rng_t = np.random.default_rng(11), np.random.default_rng(11)
+    first_n = native.create_proof([a.copy() for a in advice], instances, rng_n)
+    second_n = native.create_proof([a.copy() for a in advice], instances, rng_n)
+    out = []
+    for _ in range(2):
+        tr = Blake2bWrite()
+        plonk.create_proof(params, pk, [a.copy() for a in advice], instances, rng_t, tr)
+        out.append(tr.finalize())
+    assert [first_n, second_n] == out and first_n != second_n
+    assert rng_n.integers(0, 1 << 62) == rng_t.integers(0, 1 << 62)          # both streams stand at the same place afterwards
+    bf, n = cs.blinding_factors(), 1 << 6
+    chunk = cs.permutation_chunk_len()
+    n_sets = -(-len(cs.permutation_columns) // chunk)
+    plan = draw_plan(cs.num_advice_columns, len(cs.lookups), n_sets, cs.degree() - 1, n, bf, 1)
+    total = sum(c for _, _, c, _ in plan)
+    A, L = cs.num_advice_columns, len(cs.lookups)
+    assert total == A * (bf + 1) + A + L * (2 * (bf + 1) + 2) + n_sets * (bf + 1) + L * (bf + 1) + n + 1 + (cs.degree() - 1)
+    assert sum(c for _, _, c, _ in draw_plan(A, L, n_sets, cs.degree() - 1, n, bf, 0)) == A * (bf + 1) + L * 2 * (bf + 1) + (n_sets + L) * bf + n
+    pk.release()
+    params.release()
 
 
 def test_native_prover_refuses_a_lookup_input_outside_the_table(emu, orc):
@@ -140,6 +178,10 @@ def test_native_prover_goldens_gpu(gpu, orc):
     assert _toy(gpu, 6, 7) == tcp._golden(tcp.GOLDEN_PROOF)
     _sgx(gpu, 8, "chip_estimate", tcp.GOLDEN_SGX)
     _sgx(gpu, 9, "reference_exact", tcp.GOLDEN_REF_EXACT)
+    # ... and the first set (draw schedule 0)
+    assert _toy(gpu, 6, 7, draw_schedule=0) == tcp._golden(tcp.sched0(tcp.GOLDEN_PROOF))
+    _sgx(gpu, 8, "chip_estimate", tcp.sched0(tcp.GOLDEN_SGX), draw_schedule=0)
+    _sgx(gpu, 9, "reference_exact", tcp.sched0(tcp.GOLDEN_REF_EXACT), draw_schedule=0)
 
 
 @pytest.mark.gpu

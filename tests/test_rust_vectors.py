@@ -7,6 +7,8 @@ ZKV1 format (little endian): b"ZKV1" | kind u32 | payload
   kind 1  MSM    n u64 | n x 32 B scalars (Fr, Montgomery limbs as Rust holds them) | n x 64 B bases (G1Affine) | 96 B result (G1 {x, y, z} Jacobian)
   kind 2  NTT    log_n u32 | omega 32 B | 2^log_n x 32 B input | 2^log_n x 32 B output of best_fft
   kind 4  proof  len u64 | proof bytes | 8 x u64 first draws of the seeded ChaCha20 stream
+  kind 5  draws  per_fr u32 (rng calls of one Fr::random) | n_squeezes u32 | n_squeezes x (rng calls so far u64, points written u64, scalars written u64) | total calls u64
+                 — the order in which create_proof consumes `&mut rng`, read off a counting RNG at every transcript squeeze: pins zk_plonk_pk_desc.draw_schedule
 plus vk_cs.json — the real circuit's census (A, F, L, equality columns, degree), to replace the estimates of tools/sgx_shaped_circuit.py.
 """
 import glob
@@ -46,6 +48,11 @@ def read_zkv(path):
         ln = struct.unpack_from("<Q", b, off)[0]
         off += 8
         return {"kind": "proof", "proof": b[off:off + ln], "first_draws": list(struct.unpack_from("<8Q", b, off + ln))}
+    if kind == 5:
+        per_fr, nsq = struct.unpack_from("<II", b, off)
+        off += 8
+        rows = [list(struct.unpack_from("<3Q", b, off + 24 * i)) for i in range(nsq)]
+        return {"kind": "draws", "per_fr": per_fr, "at_squeeze": rows, "total": struct.unpack_from("<Q", b, off + 24 * nsq)[0]}
     raise ValueError(f"{path}: unknown ZKV1 kind {kind}")
 
 
@@ -80,6 +87,51 @@ def test_format_round_trip_with_oracle_written_vectors(orc, pyref, tmp_path):
     assert v["kind"] == "ntt" and v["log_n"] == 5 and (v["output"] == orc.best_fft(v["input"], v["omega"], 5)).all()
     write_zkv(tmp_path / "p.zkv", 4, [struct.pack("<Q", 5), b"hello", struct.pack("<8Q", *range(8))])
     assert read_zkv(tmp_path / "p.zkv") == {"kind": "proof", "proof": b"hello", "first_draws": list(range(8))}
+
+
+def expected_squeeze_record(census: dict, schedule: int):
+    """What the Rust driver's kind-5 record must read for a circuit with this census (vk_cs.json keys) if halo2 draws in `schedule`'s order: per squeeze
+    (Fr::random draws so far, points written, scalars written) — theta, beta, gamma, y, x, then SHPLONK's y, v, u — and the total number of draws."""
+    from zk_dcap_verifier_amd.plonk.prover import draw_plan
+    A, L, P, d, bf, k = (census[key] for key in ("num_advice_columns", "lookups", "permutation_columns", "degree", "blinding_factors", "k"))
+    chunk = d - 2
+    n_sets = -(-P // chunk) if P else 0
+    plan = draw_plan(A, L, n_sets, d - 1, 1 << k, bf, schedule)
+    upto = lambda names: sum(c for _, _, c, sq in plan if sq in names)
+    n_evals = census["advice_queries"] + census["fixed_queries"] + 1 + P + (3 * n_sets - 1 if n_sets else 0) + 5 * L
+    pts = [A, A + 2 * L, A + 2 * L, A + 2 * L + n_sets + L + 1, A + 2 * L + n_sets + L + 1 + (d - 1)]
+    rows = [[upto({"theta"}), pts[0], 0], [upto({"theta", "beta"}), pts[1], 0], [upto({"theta", "beta"}), pts[2], 0],
+            [upto({"theta", "beta", "y"}), pts[3], 0], [upto({"theta", "beta", "y", "x"}), pts[4], 0]]
+    total = sum(c for _, _, c, _ in plan)
+    rows += [[total, pts[4], n_evals], [total, pts[4], n_evals], [total, pts[4] + 1, n_evals]]
+    return rows, total
+
+
+def test_draw_record_round_trip_and_expected_counts(tmp_path):
+    """the kind-5 loader on a record written here from draw_plan — and the two schedules must be told apart by it (else the Rust dump could not settle anything)"""
+    census = {"k": 8, "num_advice_columns": 25, "lookups": 11, "permutation_columns": 16, "degree": 5, "blinding_factors": 5, "advice_queries": 60, "fixed_queries": 30}
+    rows1, total1 = expected_squeeze_record(census, 1)
+    rows0, total0 = expected_squeeze_record(census, 0)
+    assert total1 - total0 == 25 + 2 * 11 + 6 + 11 + 1 + 4 and rows1[0][0] == 25 * 6 + 25 and rows0[0][0] == 25 * 6        # one Blind per commitment of phases 2-7
+    assert [r[0] for r in rows1] != [r[0] for r in rows0]
+    flat = [v * 8 if i % 3 == 0 else v for r in rows1 for i, v in enumerate(r)]
+    write_zkv(tmp_path / "d.zkv", 5, [struct.pack("<II", 8, len(rows1)), struct.pack("<%dQ" % len(flat), *flat), struct.pack("<Q", total1 * 8)])
+    v = read_zkv(tmp_path / "d.zkv")
+    assert v["kind"] == "draws" and v["per_fr"] == 8 and v["total"] == total1 * 8
+    assert [[r[0] // v["per_fr"], r[1], r[2]] for r in v["at_squeeze"]] == rows1
+
+
+@pytest.mark.skipif(not (_vectors(5) and os.path.exists(os.path.join(DIR, "vk_cs.json"))), reason="no Rust draw-count record under tests/golden/rust")
+def test_draw_schedule_equals_rust_create_proof():
+    """THE check of DESIGN.md 1's top open parity risk: halo2's create_proof, run under a counting rng, must have consumed exactly draw_plan(schedule 1)'s
+    draws before each squeeze; the message says which schedule (if any) the record matches."""
+    census = json.load(open(os.path.join(DIR, "vk_cs.json")))
+    for p in _vectors(5):
+        v = read_zkv(p)
+        got = [[r[0] / v["per_fr"], r[1], r[2]] for r in v["at_squeeze"]]
+        want1, total1 = expected_squeeze_record(census, 1)
+        want0, _ = expected_squeeze_record(census, 0)
+        assert got == want1 and v["total"] == total1 * v["per_fr"], (p, "matches schedule 0" if got == want0 else "matches neither schedule", got, want1)
 
 
 @pytest.mark.skipif(not _vectors(1), reason="no Rust MSM vectors under tests/golden/rust (shim/README.md: needs a Rust toolchain)")

@@ -176,7 +176,7 @@ const PoseidonSpec& poseidon_spec() { static const PoseidonSpec spec; return spe
 //   2  snark-verifier EvmTranscript<G1Affine, NativeLoader, _, _>      stack B gen_evm_proof_shplonk (base.rs:193-199): 32-byte BIG-endian words, Keccak-256
 struct Transcript {
     int kind = 0;
-    bool bad_point = false;                                           // flavours 1 / 2 cannot absorb the identity (it has no coordinates): create_proof returns ZK_ERR_ARG
+    bool bad_point = false;                                           // no flavour can absorb the identity (halo2's common_point: "cannot write points at infinity to the transcript"): create_proof returns ZK_ERR_ARG
     Blake2b st{"Halo2-Transcript"};
     Fe sponge[3];
     std::vector<Fe> pending;
@@ -235,7 +235,7 @@ struct Transcript {
         bool ident = true;
         for (int i = 8; i < 12; i++) ident &= jac[i] == 0;
         if (!ident) { x = Fq::from_mont(load32(jac)); y = Fq::from_mont(load32(jac + 4)); }
-        if (kind != 0 && ident) { bad_point = true; return; }
+        if (ident) { bad_point = true; return; }
         if (kind == 1) {
             pending.push_back(Fr::to_mont(Fr::reduce_once(x)));       // fe_to_fe: the coordinate as an integer, mod r (q < 2 r)
             pending.push_back(Fr::to_mont(Fr::reduce_once(y)));
@@ -256,7 +256,7 @@ struct Transcript {
         st.update(&pre, 1); st.update(x.v, 32); st.update(y.v, 32);
         uint8_t enc[32];
         memcpy(enc, x.v, 32);
-        if (!ident) enc[31] |= (uint8_t)((y.v[0] & 1) << 7);
+        enc[31] |= (uint8_t)((y.v[0] & 1) << 7);
         out.insert(out.end(), enc, enc + 32);
     }
 };
@@ -316,6 +316,7 @@ struct Draws {
         });
     }
     const uint64_t* take(size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done > i; }); return items[i].data(); }
+    void finish() { if (!counts.empty()) (void)take(counts.size() - 1); }     // a successful proof leaves the caller's stream where halo2 would: every planned draw made
     ~Draws() { abandoned.store(true); if (th.joinable()) th.join(); }
 };
 
@@ -395,13 +396,22 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     Draws draws;
     for (double& v : g_phase_ms) v = 0;
     PhaseClock clk;
-    // draw sizes in the mirror's order: advice blinding (one draw per column), then bi / bt per lookup, permutation sets, lookup products, the random polynomial
-    for (uint32_t i = 0; i < pk->n_advice; i++) draws.counts.push_back(n - usable);
-    const size_t d_bi = draws.counts.size(); for (uint32_t l = 0; l < L; l++) draws.counts.push_back(bf + 1);
-    const size_t d_bt = draws.counts.size(); for (uint32_t l = 0; l < L; l++) draws.counts.push_back(bf + 1);
-    const size_t d_pb = draws.counts.size(); for (uint32_t s = 0; s < n_sets; s++) draws.counts.push_back(bf);
-    const size_t d_lb = draws.counts.size(); for (uint32_t l = 0; l < L; l++) draws.counts.push_back(bf);
-    const size_t d_rp = draws.counts.size(); draws.counts.push_back(n);
+    // The caller's `&mut rng` is consumed in halo2's order (plonk/prover.rs and the argument provers it calls; [3P-MEM]).  draw_schedule 1 (upstream, the default of
+    // every binding): the blinding rows of every advice column, then one Blind(Fr::random) per advice column (KZG ignores the value, the stream advances); per lookup, in order:
+    // permute_expression_pair's input rows then table rows, then commit_values' two Blinds; per permutation set its rows + one Blind; per lookup product its rows + one Blind; the
+    // vanishing argument's n coefficients + one Blind; one Blind per h(X) piece.  draw_schedule 0 (rounds 1-2 of this repo): no Blind draws, all lookups' input rows before all table rows.
+    if (pk->draw_schedule > 1) return ZK_ERR_ARG;
+    const bool upstream = pk->draw_schedule == 1;
+    auto plan = [&](size_t count) { draws.counts.push_back(count); return draws.counts.size() - 1; };
+    std::vector<size_t> d_bi(L), d_bt(L), d_pb(n_sets), d_lb(L);
+    for (uint32_t i = 0; i < pk->n_advice; i++) plan(n - usable);                                  // items [0, n_advice)
+    if (upstream) for (uint32_t i = 0; i < pk->n_advice; i++) plan(1);
+    if (upstream) for (uint32_t l = 0; l < L; l++) { d_bi[l] = plan(bf + 1); d_bt[l] = plan(bf + 1); plan(1); plan(1); }
+    else { for (uint32_t l = 0; l < L; l++) d_bi[l] = plan(bf + 1); for (uint32_t l = 0; l < L; l++) d_bt[l] = plan(bf + 1); }
+    for (uint32_t s = 0; s < n_sets; s++) { d_pb[s] = plan(bf); if (upstream) plan(1); }
+    for (uint32_t l = 0; l < L; l++) { d_lb[l] = plan(bf); if (upstream) plan(1); }
+    const size_t d_rp = plan(n);
+    if (upstream) for (uint32_t i = 0; i < 1 + n_pieces; i++) plan(1);
     draws.start(rng, rng_user);
 
     // ---- 1. vk, instances ----------------------------------------------------------------------------------------------------------------------------
@@ -478,8 +488,8 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     if (L) {
         std::vector<uint64_t> bi((size_t)L * (bf + 1) * 4), bt((size_t)L * (bf + 1) * 4);
         for (uint32_t l = 0; l < L; l++) {
-            memcpy(&bi[(size_t)l * (bf + 1) * 4], draws.take(d_bi + l), (bf + 1) * 32);
-            memcpy(&bt[(size_t)l * (bf + 1) * 4], draws.take(d_bt + l), (bf + 1) * 32);
+            memcpy(&bi[(size_t)l * (bf + 1) * 4], draws.take(d_bi[l]), (bf + 1) * 32);
+            memcpy(&bt[(size_t)l * (bf + 1) * 4], draws.take(d_bt[l]), (bf + 1) * 32);
         }
         for (uint32_t l = 0; l < L; l++) { pin[l] = mem.get(col_bytes); ptab[l] = mem.get(col_bytes); if (!pin[l] || !ptab[l]) return ZK_ERR_HIP; }
         PK(zk_lookup_permute_batch_dev(ctx, (const void* const*)cin.data(), (const void* const*)ctab.data(), L, k, bf, bi.data(), bt.data(), pin.data(), ptab.data()));
@@ -498,7 +508,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
             vals[j] = ty == 0 ? adv[ix] : ty == 1 ? pk->fixed_values[ix] : inst_values[ix];
         }
         std::vector<uint64_t> blind((size_t)n_sets * bf * 4);
-        for (uint32_t s = 0; s < n_sets; s++) memcpy(&blind[(size_t)s * bf * 4], draws.take(d_pb + s), bf * 32);
+        for (uint32_t s = 0; s < n_sets; s++) memcpy(&blind[(size_t)s * bf * 4], draws.take(d_pb[s]), bf * 32);
         for (uint32_t s = 0; s < n_sets; s++) { zs[s] = mem.get(col_bytes); if (!zs[s]) return ZK_ERR_HIP; }
         PK(zk_permutation_product_all_dev(ctx, vals.data(), pk->sigma_values, pk->n_perm_columns, chunk, k, beta.v, gamma.v, blind.data(), bf, zs.data()));
     }
@@ -506,7 +516,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         std::vector<const void*> quads;
         for (uint32_t l = 0; l < L; l++) { quads.push_back(cin[l]); quads.push_back(ctab[l]); quads.push_back(pin[l]); quads.push_back(ptab[l]); }
         std::vector<uint64_t> blind((size_t)L * bf * 4);
-        for (uint32_t l = 0; l < L; l++) memcpy(&blind[(size_t)l * bf * 4], draws.take(d_lb + l), bf * 32);
+        for (uint32_t l = 0; l < L; l++) memcpy(&blind[(size_t)l * bf * 4], draws.take(d_lb[l]), bf * 32);
         for (uint32_t l = 0; l < L; l++) { lzs[l] = mem.get(col_bytes); if (!lzs[l]) return ZK_ERR_HIP; }
         PK(zk_lookup_product_batch_dev(ctx, quads.data(), L, k, beta.v, gamma.v, blind.data(), bf, lzs.data()));
     }
@@ -753,6 +763,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     }
     clk.lap(8);
     if (tr.bad_point) return ZK_ERR_ARG;                              // a commitment to the zero polynomial under a transcript that cannot encode the identity
+    draws.finish();
     *proof_len = tr.out.size();
     if (!proof_out || proof_cap < tr.out.size()) return ZK_ERR_LIMIT;
     memcpy(proof_out, tr.out.data(), tr.out.size());

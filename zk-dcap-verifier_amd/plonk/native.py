@@ -31,7 +31,7 @@ class PkDesc(C.Structure):
                 ("fixed_values", C.c_void_p), ("fixed_polys", C.c_void_p), ("fixed_cosets", C.c_void_p),
                 ("sigma_values", C.c_void_p), ("sigma_polys", C.c_void_p), ("sigma_cosets", C.c_void_p),
                 ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
-                ("transcript_repr", C.c_void_p), ("transcript", C.c_uint32)]
+                ("transcript_repr", C.c_void_p), ("transcript", C.c_uint32), ("draw_schedule", C.c_uint32)]
 
 
 class NativeProver:
@@ -39,7 +39,7 @@ class NativeProver:
 
     TRANSCRIPTS = {"blake2b": 0, "poseidon": 1, "evm": 2}
 
-    def __init__(self, params: ParamsKZG, pk: ProvingKey, transcript: str = "blake2b"):
+    def __init__(self, params: ParamsKZG, pk: ProvingKey, transcript: str = "blake2b", draw_schedule: int = 1):
         assert params.world == 1 and pk.coset_parts is None, "the native prover is the single-GPU path (sharded proofs: plonk.create_proof)"
         self.params, self.pk, self.be = params, pk, pk.backend
         cs = pk.vk.cs
@@ -81,6 +81,7 @@ class NativeProver:
         d.l0, d.l_last, d.l_active_row = _dptr(pk.l0), _dptr(pk.l_last), _dptr(pk.l_active_row)
         d.transcript_repr = repr_bytes.ctypes.data
         d.transcript = self.TRANSCRIPTS[transcript]         # which Fiat-Shamir transcript / proof encoding (zk_plonk_pk_desc.transcript)
+        d.draw_schedule = draw_schedule                     # 1: halo2's order of Fr::random draws; 0: rounds 1-2 of this repo (prover.py draw_plan)
         self.desc = d
         self.proof_cap = (64 if transcript == "evm" else 32) * (cs.num_advice_columns + 3 * len(cs.lookups) + len(cs.permutation_columns) + 16 +
                                len(aq) + len(fq) + 1 + len(cs.permutation_columns) + 3 * len(cs.permutation_columns) + 5 * len(cs.lookups) + 8)

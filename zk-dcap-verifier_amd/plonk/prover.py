@@ -39,6 +39,31 @@ def rotate_omega(x: int, rot: int, k: int) -> int:
     return x * pow(w, rot % (1 << k), R_MOD) % R_MOD
 
 
+def draw_plan(n_advice: int, n_lookups: int, n_sets: int, n_pieces: int, n: int, bf: int, schedule: int = 1):
+    """The order in which create_proof consumes the caller's `&mut rng`, as a list of (purpose, index, count of Fr::random draws, squeeze) items; `squeeze` names the
+    challenge squeezed AFTER the item's phase (the item is drawn before that squeeze happens in halo2) — tests/test_rust_vectors.py compares the running totals
+    with the Rust prover's counting RNG.  schedule 1 = halo2_proofs v2023_01_20 draw by draw ([3P-MEM]; include/zkmi355.h zk_rng_fn lists the source files):
+    every commitment also draws one Blind(Fr::random) that KZG discards ("blind" items).  schedule 0 = rounds 1-2 of this repo (no Blind draws, all lookups' input
+    rows before all table rows).  csrc/prover.hip builds the same plan."""
+    assert schedule in (0, 1)
+    up = schedule == 1
+    plan = [("advice", i, bf + 1, "theta") for i in range(n_advice)]      # rows [usable_rows, n): the bf blinding rows and the one after
+    if up:
+        plan += [("blind", None, 1, "theta")] * n_advice
+        for l in range(n_lookups):
+            plan += [("bi", l, bf + 1, "beta"), ("bt", l, bf + 1, "beta"), ("blind", None, 1, "beta"), ("blind", None, 1, "beta")]
+    else:
+        plan += [("bi", l, bf + 1, "beta") for l in range(n_lookups)] + [("bt", l, bf + 1, "beta") for l in range(n_lookups)]
+    for s in range(n_sets):
+        plan += [("perm_blind", s, bf, "y")] + ([("blind", None, 1, "y")] if up else [])
+    for l in range(n_lookups):
+        plan += [("lookup_blind", l, bf, "y")] + ([("blind", None, 1, "y")] if up else [])
+    plan.append(("random_poly", 0, n, "y"))
+    if up:
+        plan += [("blind", None, 1, "y")] + [("blind", None, 1, "x")] * n_pieces
+    return plan
+
+
 class _Joiner:
     """lets the helper thread sit in the `owned` list: create_proof's cleanup calls .free() on every entry"""
 
@@ -50,7 +75,7 @@ class _Joiner:
 
 
 def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances: Sequence[Sequence[int]], rng: np.random.Generator, transcript,
-                 timings: Optional[dict] = None, capture: Optional[dict] = None) -> dict:
+                 timings: Optional[dict] = None, capture: Optional[dict] = None, draw_schedule: int = 1) -> dict:
     """advice: cs.num_advice_columns columns of n rows — (n, 4) uint64 Montgomery host arrays or device buffers; rows past
     `usable_rows` are overwritten with blinding and device buffers are consumed (they hold coefficients afterwards).  instances:
     canonical ints per instance column.  Writes the proof into `transcript` and returns bookkeeping for tests / benches
@@ -59,13 +84,13 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     copies of the proof's committed Lagrange columns and challenges, so that a driver of the per-call host-buffer entry points can replay them."""
     owned: List = []
     try:
-        return _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture)
+        return _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture, draw_schedule)
     finally:
         for d in owned:
             d.free()
 
 
-def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture=None) -> dict:
+def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture=None, draw_schedule=1) -> dict:
     be, cs, k, n = pk.backend, pk.vk.cs, params.k, params.n
     dom = pk.domain
     ek, en = dom.extended_k, dom.extended_n
@@ -111,28 +136,35 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     from_host = [i for i, col in enumerate(advice) if isinstance(col, np.ndarray)]
     if from_host:
         be.upload_columns([adv_values[i] for i in from_host], [np.ascontiguousarray(advice[i], dtype=np.uint64).reshape(n, 4) for i in from_host], n * 32)
-    blinds = [rand_fr_array(rng, n - usable) for _ in advice]
-    if advice:
-        be.upload_columns([d.ptr + usable * 32 for d in adv_values], blinds, (n - usable) * 32)
-    # Every later `Fr::random` draw of the proof (lookup / permutation blinding rows, the n coefficients of the vanishing argument's random
-    # polynomial) depends on no challenge: a helper thread draws them now, in the order the phases consume them (the stream — hence the proof —
-    # is the same), while the GPU commits the advice columns; a phase waits only for its own item.
+    # Every `Fr::random` draw of the proof (blinding rows, the n coefficients of the vanishing argument's random polynomial, the Blind every commitment
+    # draws and KZG discards) depends on no challenge: the advice rows are drawn here, a helper thread draws the rest, in draw_plan's order (the stream —
+    # hence the proof — is the same), while the GPU commits the advice columns; a phase waits only for its own items.
     chunk = cs.permutation_chunk_len()
     n_sets = (len(cs.permutation_columns) + chunk - 1) // chunk if cs.permutation_columns else 0
-    drawn, ready = {}, {name: threading.Event() for name in ("bi", "bt", "perm_blind", "lookup_blind", "random_poly")}
+    plan = draw_plan(len(advice), L, n_sets, dom.quotient_poly_degree, n, bf, draw_schedule)
+    blinds = [rand_fr_array(rng, cnt) for _, _, cnt, _ in plan[:len(advice)]]
+    if advice:
+        be.upload_columns([d.ptr + usable * 32 for d in adv_values], blinds, (n - usable) * 32)
+    drawn = {name: {} for name in ("bi", "bt", "perm_blind", "lookup_blind", "random_poly")}
+    ready = {name: threading.Event() for name in drawn}
+    want = {name: sum(1 for it_ in plan if it_[0] == name) for name in drawn}
+    for name, cnt in want.items():
+        if cnt == 0:
+            ready[name].set()
     draw_error = []
 
     def draw_all():
         try:
-            for name, fn in (("bi", lambda: np.stack([rand_fr_array(rng, bf + 1) for _ in range(L)]) if L else np.zeros((0, bf + 1, 4), np.uint64)),
-                             ("bt", lambda: np.stack([rand_fr_array(rng, bf + 1) for _ in range(L)]) if L else np.zeros((0, bf + 1, 4), np.uint64)),
-                             ("perm_blind", lambda: [rand_fr_array(rng, bf) for _ in range(n_sets)]),
-                             ("lookup_blind", lambda: np.stack([rand_fr_array(rng, bf) for _ in range(L)]) if L else np.zeros((0, bf, 4), np.uint64)),
-                             ("random_poly", lambda: rand_fr_array(rng, n))):
-                drawn[name] = fn()
-                ready[name].set()
+            for name, idx, cnt, _ in plan[len(advice):]:
+                a = rand_fr_array(rng, cnt)
+                if name == "blind":
+                    continue
+                drawn[name][idx] = a
+                if len(drawn[name]) == want[name]:
+                    ready[name].set()
         except BaseException as e:                                   # never leave the main thread waiting
             draw_error.append(e)
+        finally:
             for ev_ in ready.values():
                 ev_.set()
 
@@ -140,7 +172,12 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
         ready[name].wait()
         if draw_error:
             raise draw_error[0]
-        return drawn[name]
+        items = [drawn[name][i] for i in range(want[name])]
+        if name == "random_poly":
+            return items[0]
+        if name == "perm_blind":
+            return items
+        return np.stack(items) if items else np.zeros((0, bf + 1 if name in ("bi", "bt") else bf, 4), np.uint64)
     drawer = threading.Thread(target=draw_all)
     drawer.start()
     owned.append(_Joiner(drawer))                                    # joined on every exit path (the generator belongs to the caller again afterwards)
@@ -205,7 +242,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     if capture is not None:
         capture.update(advice=[d.download((n, 4)) for d in adv_values], perm_products=[d.download((n, 4)) for d in zs],
                        lookup_products=[d.download((n, 4)) for d in lzs], permuted=[(a_.download((n, 4)), s_.download((n, 4))) for a_, s_ in permuted],
-                       compressed=[(c[0].download((n, 4)), c[1].download((n, 4))) for c in compressed], random_poly=drawn["random_poly"],
+                       compressed=[(c[0].download((n, 4)), c[1].download((n, 4))) for c in compressed], random_poly=drawn["random_poly"][0],
                        theta=theta, beta=beta, gamma=gamma, y=y)
     be.lagrange_to_coeff_batch_dev(lag, k)                           # in place: from here on these buffers hold coefficients
     adv_polys, inst_polys = adv_values, inst_values

@@ -72,7 +72,9 @@ class _Blake2bState:
 
     def common_point(self, pt) -> None:
         self.state.update(PREFIX_POINT)
-        x, y = (0, 0) if pt is None else pt
+        if pt is None:                                               # Blake2bWrite / Blake2bRead::common_point: `point.coordinates()` is None for the identity
+            raise ValueError("cannot write points at infinity to the transcript")
+        x, y = pt
         self.state.update(x.to_bytes(32, "little"))
         self.state.update(y.to_bytes(32, "little"))
 

@@ -190,12 +190,13 @@ PROVER = "native"      # --prover: "native" = zk_plonk_create_proof (C++ over th
 class ProverWorkload:
     """keygen once, then one create_proof per step on a copy of the resident witness."""
 
-    def __init__(self, z, be, k, circuit, srs=None):
+    def __init__(self, z, be, k, circuit, srs=None, pk=None):
         self.z, self.be, self.k, self.n = z, be, k, 1 << k
         cs, fixed, asm, advice = circuit
-        # one SRS for the process: the first context runs ParamsKZG::setup (fixed-base powers + EC-NTT); the others share its expanded tables in HBM
+        # one SRS and one proving key for the process: the first context runs ParamsKZG::setup (fixed-base powers + EC-NTT) and keygen; the others share its
+        # expanded tables, its columns and its compiled programs in HBM (zk_bases_share, zk_quotient_program_share)
         self.params = z.kzg.ParamsKZG.setup(k, TAU, backend=be) if srs is None else z.kzg.ParamsKZG.shared_with(srs, be)
-        self.pk = z.plonk.keygen(self.params, cs, fixed, asm)
+        self.pk = z.plonk.keygen(self.params, cs, fixed, asm) if pk is None else z.plonk.ProvingKey.shared_with(pk, be)
         self.native = z.plonk.NativeProver(self.params, self.pk) if PROVER == "native" else None
         self.master = [be.to_device(a) for a in advice]
         self.work = [be.alloc(self.n * 32) for _ in advice]
@@ -602,7 +603,7 @@ def main(argv=None):
         circuit = sgx.build(z, be, args.k, census=args.census)  # one satisfying witness, shared by the contexts
         wls = []
         for b in bes:
-            wls.append(ProverWorkload(z, b, args.k, circuit, srs=wls[0].params if wls else None))
+            wls.append(ProverWorkload(z, b, args.k, circuit, srs=wls[0].params if wls else None, pk=wls[0].pk if wls else None))
     else:
         circuit = None
         wls = [ProofWorkload(z, b, args.k, args.advice, args.fixed, args.lookups, args.perm_columns, args.degree) for b in bes]
@@ -731,7 +732,9 @@ def main(argv=None):
         census2 = None
         try:
             circuit2 = sgx.build(z, be, args.k, census=other)
-            wls2 = [ProverWorkload(z, b, args.k, circuit2, srs=wl.params) for b in bes]
+            wls2 = []
+            for b in bes:
+                wls2.append(ProverWorkload(z, b, args.k, circuit2, srs=wl.params, pk=wls2[0].pk if wls2 else None))
 
             def step2(steps):
                 def loop(w_):

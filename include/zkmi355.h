@@ -231,6 +231,9 @@ typedef struct zk_quotient_args {
 } zk_quotient_args;
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog);
+/* a compiled program is immutable: `ctx` receives a handle of its own onto the program `owner_prog` of `owner` (same device), so that several contexts
+ * (one per host thread that proves concurrently) run ONE compiled Evaluator; it is freed with its last handle */
+int zk_quotient_program_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_prog, uint64_t* prog);
 /* size of the compiled micro-program: instructions, live-value slots (the first is a register, the rest LDS), columns */
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
 /* opcode census of the compiled micro-program (the arithmetic a row costs — what the kernel's roofline is priced from):
@@ -313,6 +316,37 @@ typedef void (*zk_rng_fn)(void* user, size_t n, void* out_fr);
  * (e.g. ZK_ERR_ARG from zk_lookup_permute_batch_dev for a lookup input outside its table: halo2's Error::ConstraintSystemFailure). */
 int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
                           const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len);
+/* ---- the proving key as the library's own object: what a Rust / C caller uses instead of filling zk_plonk_pk_desc by hand ------------------------------ *
+ * zk_plonk_pk_build is the device half of halo2's keygen_pk (src/plonk/keygen.rs; reference call sites sgx_dcap_verifier.rs:807, p256-ecdsa base.rs:145): from the
+ * HOST data a halo2 ProvingKey holds — pk.fixed_values, pk.permutation.permutations (Lagrange columns of n = 2^k x 32 B), the constraint system's shape and the
+ * Evaluator / lookup expressions serialised as ZKQ1 blobs — it uploads the columns and derives on the GPU what keygen_pk derives on the CPU: coefficient forms
+ * (lagrange_to_coeff), extended cosets (coeff_to_extended) and l0 / l_last / l_active_row; extended_k follows EvaluationDomain::new(cs_degree, k).  Nothing of
+ * `host` is referenced after the call.  The key lives in HBM once per process: zk_plonk_pk_share gives another context of the same device (one context per
+ * concurrently proving host thread) a handle onto the same columns and compiled programs — pass that context's own SRS handles (zk_bases_share).
+ * zk_plonk_prove = zk_plonk_create_proof on the descriptor the library built.  With values_on_device the columns are DEVICE pointers (borrowed, must outlive the key). */
+typedef struct zk_plonk_pk_host {
+    uint32_t k, cs_degree, blinding_factors;
+    uint32_t n_fixed, n_advice, n_instance, n_lookups, n_perm_columns;
+    const uint32_t* perm_columns;             /* as zk_plonk_pk_desc */
+    const uint32_t* advice_queries; uint32_t n_advice_queries;
+    const uint32_t* fixed_queries;  uint32_t n_fixed_queries;
+    const void* evaluator_zkq1; size_t evaluator_zkq1_len;                      /* Evaluator::to_zkq1 (shim/halo2_proofs_mi355x/src/evaluation_zkq1.rs), extended_k as derived */
+    const void* const* lookup_input_zkq1; const size_t* lookup_input_zkq1_len;   /* n_lookups expression programs (extended_k = k): Horner in theta over input_expressions */
+    const void* const* lookup_table_zkq1; const size_t* lookup_table_zkq1_len;   /* ... over table_expressions */
+    const uint32_t* lookup_table_key;         /* n_lookups: equal key = structurally equal table expressions (their compressed column is computed once) */
+    const void* const* fixed_values;          /* n_fixed columns, n x 32 B Montgomery, HOST (DEVICE when values_on_device) */
+    const void* const* sigma_values;          /* n_perm_columns columns: pk.permutation.permutations */
+    uint32_t values_on_device;
+    const void* transcript_repr;              /* HOST 32 B */
+    uint32_t transcript, draw_schedule;       /* as zk_plonk_pk_desc */
+} zk_plonk_pk_host;
+int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk);
+int zk_plonk_pk_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_pk, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk);
+int zk_plonk_pk_release(zk_ctx* ctx, uint64_t pk);
+/* the descriptor behind a key handle (valid until the handle is released): for callers that drive single phases themselves */
+int zk_plonk_pk_descriptor(zk_ctx* ctx, uint64_t pk, const zk_plonk_pk_desc** desc);
+int zk_plonk_prove(zk_ctx* ctx, uint64_t pk, const void* const* advice, int advice_on_device, const void* const* instances, const uint32_t* instance_lens,
+                   zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len);
 /* wall milliseconds of the nine phases (instances, advice, lookups, grand products, random poly, h numerator, h commit, evaluations, SHPLONK) of the
  * calling thread's last zk_plonk_create_proof */
 int zk_plonk_last_phase_ms(double out[9]);

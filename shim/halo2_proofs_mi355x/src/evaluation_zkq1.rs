@@ -100,6 +100,31 @@ impl<C: CurveAffine> Evaluator<C> {
     }
 }
 
+/// `compress_expressions` of lookup::Argument::commit_permuted (theta-compression of a lookup's input or table expressions over the n = 2^k rows) as a ZKQ1
+/// program: header with extended_k = k, no permutation columns, no lookups; the "custom gates" graph is `Horner(Constant(0), [e_0 .. e_m-1], Theta)`, the same
+/// calculation Evaluator::new builds for the lookup's coset form.  Python twin: zk-dcap-verifier_amd/plonk/keygen.py `_compressor` + evaluation.py
+/// `expression_program`.  One program per lookup side goes into ZkPlonkPkHost.lookup_{input,table}_zkq1 (pk_desc.rs).
+pub(crate) fn lookup_expression_zkq1<C: CurveAffine>(cs: &ConstraintSystem<C::ScalarExt>, k: u32, exprs: &[Expression<C::ScalarExt>]) -> Vec<u8> {
+    let mut graph = GraphEvaluator::<C>::default(); // constants [0, 1, 2]
+    let parts: Vec<ValueSource> = exprs.iter().map(|e| graph.add_expression(e)).collect();
+    graph.add_calculation(Calculation::Horner(ValueSource::Constant(0), parts, ValueSource::Theta()));
+    let mut w: Vec<u32> = vec![
+        ZKQ1_MAGIC,
+        k,
+        k, // extended_k = k: rotations wrap modulo n, as Expression::evaluate over Lagrange columns does
+        cs.num_fixed_columns as u32,
+        cs.num_advice_columns as u32,
+        cs.num_instance_columns as u32,
+        cs.num_challenges as u32,
+        0, // blinding factors: unused by an expression program
+        3, // cs_degree: the smallest the loader accepts
+        0, // no permutation columns
+        0, // no lookups
+    ];
+    zkq1_graph(&mut w, &graph);
+    w.iter().flat_map(|x| x.to_le_bytes()).collect()
+}
+
 /// evaluate_h redirect: call at the top of Evaluator::evaluate_h; `None` = run the original body.  The program / proving-key handles are created
 /// on first use and cached per ProvingKey address (keygen_pk's output lives as long as the prover uses it).
 ///   zk_pk_load(prog, pk.fixed_cosets, pk.permutation.cosets, pk.l0, pk.l_last, pk.l_active_row, form = 1)     — the cosets pk already stores

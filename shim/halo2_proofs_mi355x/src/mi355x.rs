@@ -108,7 +108,7 @@ impl Gpu {
     }
 
     /// handle of the table that serves `bases` (registering, or re-registering when a LONGER slice of the same array shows up)
-    fn table_for(&self, bases: &[G1Affine]) -> Option<u64> {
+    pub(crate) fn table_for(&self, bases: &[G1Affine]) -> Option<u64> {
         let key = bases.as_ptr() as usize;
         let mut map = self.tables.lock().unwrap();
         if let Some(t) = map.get(&key) {

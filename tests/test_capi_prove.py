@@ -1,0 +1,52 @@
+"""The one-call boundary WITHOUT the Python mirror in the proving loop: tools/dump_pk_blob.py writes the host data of a proving key, SRS,
+witness and rng stream into one flat file; tests/csrc/capi_prove.c (gcc -std=c99) rebuilds the key with zk_plonk_pk_build, proves with zk_plonk_prove — first on
+one context, then on a second context that borrows tables and key — and must reproduce the golden proof of the independent CPU prover (oracle/prover.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+EMU_TUNE = "msm_sort_threads=64,msm_sort_wgs=3,msm_block=32,ntt_threads=32,ntt_tile_log=6,ntt_max_radix_log=4,msm_target_threads=64,msm_min_chunk=2,vec_block=32,quot_threads=32"
+
+
+def _run(exe, path, tune=None):
+    env = dict(os.environ)
+    if tune:
+        env["ZK_TUNE"] = tune
+    return subprocess.run([os.path.join(ROOT, "tests", "csrc", exe), str(path)], capture_output=True, text=True, timeout=900, env=env)
+
+
+@pytest.mark.parametrize("which,sched", [("toy", 1), ("toy", 0), ("sgx", 1)])
+def test_plain_c_prover_reproduces_the_goldens_emulated(emu, orc, tmp_path, which, sched):
+    import dump_pk_blob as dp
+    blob = dp.toy_blob(emu, 6, 7, sched) if which == "toy" else dp.sgx_blob(emu, 8, 3, "chip_estimate", sched)
+    path = tmp_path / "pk.zkpk"
+    path.write_bytes(blob)
+    r = _run("capi_prove_emu", path, EMU_TUNE)
+    assert r.returncode == 0 and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_plain_c_prover_has_no_cpu_fallback(emu, orc, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import dump_pk_blob as dp
+    path = tmp_path / "pk.zkpk"
+    path.write_bytes(dp.toy_blob(emu, 5, 1))
+    r = _run("capi_prove", path)
+    assert r.returncode == 3 and "no CPU fallback" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,k", [("toy", 6), ("sgx", 8), ("sgx", 12)])
+def test_plain_c_prover_on_gpu(gpu, orc, tmp_path, which, k):
+    import dump_pk_blob as dp
+    blob = dp.toy_blob(gpu, 6, 7) if which == "toy" else dp.sgx_blob(gpu, k, 3)
+    path = tmp_path / "pk.zkpk"
+    path.write_bytes(blob)
+    r = _run("capi_prove", path)
+    assert r.returncode == 0 and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

@@ -167,6 +167,23 @@ def test_native_provers_on_two_contexts_in_threads(built, orc):
     for t in ts:
         t.join()
     assert out["a"] == out["b"] == tcp._golden(tcp.GOLDEN_PROOF)
+    # ONE proving key for both contexts (ProvingKey.shared_with: columns and compiled programs shared, zk_quotient_program_share) proving at the same time
+    pka = plonk.keygen(pa, cs, fixed, asm)
+    pkb = plonk.ProvingKey.shared_with(pka, b)
+    out.clear()
+
+    def run_shared(name, params, pk):
+        native = plonk.NativeProver(params, pk)
+        out[name] = [native.create_proof([c.copy() for c in advice], instances, np.random.default_rng(7)) for _ in range(2)]
+    ts = [threading.Thread(target=run_shared, args=(n, p, k_)) for n, p, k_ in (("a", pa, pka), ("b", pb, pkb))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert out["a"] == out["b"] == [tcp._golden(tcp.GOLDEN_PROOF)] * 2
+    pkb.release()
+    assert plonk.NativeProver(pa, pka).create_proof([c.copy() for c in advice], instances, np.random.default_rng(7)) == tcp._golden(tcp.GOLDEN_PROOF)    # the owner is intact
+    pka.release()
     pb.release()
     pa.release()
     b.close()
@@ -189,3 +206,59 @@ def test_native_prover_goldens_gpu(gpu, orc):
 def test_native_prover_verifies_gpu(gpu, orc, k):
     _toy(gpu, 10, 5)
     _sgx(gpu, k, "chip_estimate")
+
+
+def test_proof_bytes_replayed_through_a_fresh_transcript_reach_the_same_state(emu, orc):
+    """shim/halo2_proofs_mi355x/src/create_proof_native.rs `replay`: the Rust hook gets the proof back as BYTES and feeds them through the caller's transcript —
+    the phase's points, a squeeze wherever create_proof squeezes, the evaluations, SHPLONK's two points — so that the writer ends with the same bytes and the same
+    hash state as after the CPU body.  Done here with the mirror's Blake2bWrite and the `Layout` arithmetic of that file; the reference state is the twin's
+    transcript after plonk.create_proof."""
+    from zk_dcap_verifier_amd.transcript import point_from_bytes
+    cs, fixed, asm, advice, instances = tcp.toy_circuit(6)
+    params = z.kzg.ParamsKZG.setup(6, tcp.TAU, backend=emu)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    proof = plonk.NativeProver(params, pk).create_proof([a.copy() for a in advice], instances, np.random.default_rng(5))
+    twin = Blake2bWrite()
+    plonk.create_proof(params, pk, [a.copy() for a in advice], instances, np.random.default_rng(5), twin)
+    assert twin.finalize() == proof
+    # what create_proof absorbed before the hook
+    t = Blake2bWrite()
+    pk.vk.hash_into(t)
+    for col in instances:
+        for v in col:
+            t.common_scalar(v)
+    chunk = cs.degree() - 2
+    p_ = len(cs.permutation_columns)
+    sets = -(-p_ // chunk) if p_ else 0
+    L = len(cs.lookups)
+    lay = dict(advice=cs.num_advice_columns, lookups=L, sets=sets, pieces=cs.degree() - 1,
+               evals=len(cs.advice_queries()) + len(cs.fixed_queries()) + 1 + p_ + (3 * sets - 1 if p_ else 0) + 5 * L)
+    assert len(proof) == 32 * (lay["advice"] + 2 * L + sets + L + 1 + lay["pieces"] + lay["evals"] + 2)      # `cap` of try_create_proof
+    at = [0]
+
+    def point():
+        t.write_point(point_from_bytes(proof[at[0]:at[0] + 32]))
+        at[0] += 32
+    for _ in range(lay["advice"]):
+        point()
+    t.squeeze_challenge()
+    for _ in range(2 * L):
+        point()
+    t.squeeze_challenge(), t.squeeze_challenge()
+    for _ in range(sets + L + 1):
+        point()
+    t.squeeze_challenge()
+    for _ in range(lay["pieces"]):
+        point()
+    t.squeeze_challenge()
+    for _ in range(lay["evals"]):
+        t.write_scalar(int.from_bytes(proof[at[0]:at[0] + 32], "little"))
+        at[0] += 32
+    t.squeeze_challenge(), t.squeeze_challenge()
+    point()
+    t.squeeze_challenge()
+    point()
+    assert at[0] == len(proof) and t.finalize() == proof
+    assert t.state.digest() == twin.state.digest()
+    pk.release()
+    params.release()

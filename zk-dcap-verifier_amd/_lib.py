@@ -458,6 +458,12 @@ class Backend:
         self._ck(self.lib.zk_quotient_program_load(self.ctx, buf, C.c_size_t(len(blob)), C.byref(h)))
         return h.value
 
+    def quotient_program_share(self, owner: "Backend", owner_prog: int) -> int:
+        """a handle of this context onto a program `owner` (same GPU) loaded: one compiled program per process (zk_quotient_program_share)"""
+        h = C.c_uint64()
+        self._ck(self.lib.zk_quotient_program_share(self.ctx, owner.ctx, C.c_uint64(owner_prog), C.byref(h)))
+        return h.value
+
     def quotient_program_info(self, prog: int) -> dict:
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._ck(self.lib.zk_quotient_program_info(self.ctx, C.c_uint64(prog), C.byref(a), C.byref(b), C.byref(c)))

@@ -50,6 +50,7 @@ int fr_interleave(zk_ctx* ctx, const void* const* h_cosets, size_t count, size_t
 }  // namespace zk
 using namespace zk;
 
+void zk_internal_plonk_ctx_destroyed(zk_ctx* ctx);   // prover.hip
 #define LOCK std::lock_guard<std::mutex> lk__(ctx->mu)
 #define NEED_CTX if (!ctx) return ZK_ERR_ARG
 
@@ -83,6 +84,7 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
 
 void zk_ctx_destroy(zk_ctx* ctx) {
     if (!ctx) return;
+    zk_internal_plonk_ctx_destroyed(ctx);       // proving keys built on / shared to this context (prover.hip)
     (void)zk_plonk_trim(ctx);                   // device buffers zk_plonk_create_proof kept for reuse on this context (a later context at the same address must not inherit them)
     {
         LOCK;
@@ -94,7 +96,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
         release_programs(ctx);
         release_gtab(ctx);
         zk::DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_sorted, &ctx->ws_mid, &ctx->ws_small, &ctx->ws_sub0, &ctx->ws_sub1, &ctx->ws_cls0,
-                              &ctx->ws_cls1, &ctx->ws_tmp, &ctx->ws_ntt, &ctx->ws_ntt_in, &ctx->ws_pts, &ctx->ws_runs};
+                              &ctx->ws_cls1, &ctx->ws_tmp, &ctx->ws_ntt, &ctx->ws_ntt_in, &ctx->ws_pts, &ctx->ws_runs, &ctx->ws_quot};
         for (auto* b : bufs) b->release();
         (void)hipStreamDestroy(ctx->stream);
     }
@@ -342,6 +344,10 @@ int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* ni, uint32_t* ns, uint32_t* nc) { ENTER; return quotient_program_info(ctx, prog, ni, ns, nc); }
 int zk_quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]) { ENTER; return quotient_program_opmix(ctx, prog, counts); }
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog) { ENTER; return quotient_program_release(ctx, prog); }
+int zk_quotient_program_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_prog, uint64_t* prog) {
+    if (!ctx || !owner || !prog) return ZK_ERR_ARG;
+    return quotient_program_share(ctx, owner, owner_prog, prog);
+}
 int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args, -1, 0, 0); }
 int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset) {
     ENTER;

@@ -100,10 +100,10 @@ struct zk_ctx {
     uint64_t next_handle = 1;
     std::map<uint64_t, zk::BaseTable> bases;
     std::vector<zk::TwiddleSet> twiddles;
-    std::map<uint64_t, zk::QuotProgram*> programs;
+    std::map<uint64_t, std::shared_ptr<zk::QuotProgram>> programs;   // compiled micro-programs are immutable once loaded: contexts of one device may share them (zk_quotient_program_share)
     std::map<uint64_t, std::vector<uint32_t>> lookup_tie_hint;   // lookupperm.hip: columns whose rows tied on the sort window in the previous call of the same shape
     // workspaces (grow-only)
-    zk::DevBuf ws_scalars, ws_sorted, ws_mid, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts, ws_runs;
+    zk::DevBuf ws_scalars, ws_sorted, ws_mid, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts, ws_runs, ws_quot;
     // last-call kernel timing (ms), filled when timing is enabled
     bool timing = false;
     std::map<std::string, double> last_ms;
@@ -166,4 +166,5 @@ struct NttFuse {              // optional fused pre/post operations (EvaluationD
 int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const NttFuse* fuse);
 void release_twiddles(zk_ctx* ctx);
 void release_programs(zk_ctx* ctx);
+int quotient_program_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_prog, uint64_t* prog);
 }  // namespace zk

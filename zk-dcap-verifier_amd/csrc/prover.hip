@@ -11,6 +11,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -265,17 +266,18 @@ struct Transcript {
 struct Pool {
     std::mutex mu;
     std::map<size_t, std::vector<void*>> free_;
+    bool retired = false;                                             // zk_plonk_trim ran while a proof of this context still held buffers: they are freed as they come back
 };
 std::mutex g_pools_mu;
-std::map<zk_ctx*, Pool*> g_pools;
-Pool* pool_of(zk_ctx* ctx) {
+std::map<zk_ctx*, std::shared_ptr<Pool>> g_pools;
+std::shared_ptr<Pool> pool_of(zk_ctx* ctx) {
     std::lock_guard<std::mutex> lk(g_pools_mu);
-    Pool*& p = g_pools[ctx];
-    if (!p) p = new Pool();
+    std::shared_ptr<Pool>& p = g_pools[ctx];
+    if (!p) p = std::make_shared<Pool>();
     return p;
 }
 struct Arena {                                                        // everything a proof allocates goes back to the pool when it ends
-    zk_ctx* ctx; Pool* pool; std::vector<std::pair<void*, size_t>> held;
+    zk_ctx* ctx; std::shared_ptr<Pool> pool; std::vector<std::pair<void*, size_t>> held;
     explicit Arena(zk_ctx* c) : ctx(c), pool(pool_of(c)) {}
     void* get(size_t bytes) {
         void* p = nullptr;
@@ -288,13 +290,15 @@ struct Arena {                                                        // everyth
         held.push_back({p, bytes});
         return p;
     }
+    void put(void* p, size_t bytes) {
+        bool retired;
+        { std::lock_guard<std::mutex> lk(pool->mu); retired = pool->retired; if (!retired) pool->free_[bytes].push_back(p); }
+        if (retired) (void)zk_dev_free(ctx, p);
+    }
     void give_back(void* p) {
-        for (auto& h : held) if (h.first == p) { std::lock_guard<std::mutex> lk(pool->mu); pool->free_[h.second].push_back(p); h.first = nullptr; return; }
+        for (auto& h : held) if (h.first == p) { put(p, h.second); h.first = nullptr; return; }
     }
-    ~Arena() {
-        std::lock_guard<std::mutex> lk(pool->mu);
-        for (auto& h : held) if (h.first) pool->free_[h.second].push_back(h.first);
-    }
+    ~Arena() { for (auto& h : held) if (h.first) put(h.first, h.second); }
 };
 
 // ---- the caller's Fr::random draws, made on a helper thread in the order the phases consume them ---------------------------------------------------------
@@ -770,6 +774,208 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     return ZK_OK;
 }
 
+
+// ---- the proving key as a library object (zk_plonk_pk_build / share / release / prove) -------------------------------------------------------------------------
+// The device half of keygen_pk, written — like create_proof above — as a CLIENT of the public entry points: upload the Lagrange columns, lagrange_to_coeff,
+// coeff_to_extended, l0 / l_last / l_active_row, load the ZKQ1 programs.  One PkMem per key per process (columns + the host arrays the descriptor points into);
+// every holding context has a PkHandle with its own program handles (zk_quotient_program_share) and SRS handles.
+namespace {
+struct PkMem {
+    std::vector<void*> owned;                                         // device allocations, freed by whoever drops the last handle
+    std::vector<const void*> fixed_values, fixed_polys, fixed_cosets, sigma_values, sigma_polys, sigma_cosets;
+    void* l[3] = {nullptr, nullptr, nullptr};
+    std::vector<uint32_t> perm_columns, advice_queries, fixed_queries, table_key;
+    uint8_t transcript_repr[32];
+    int holders = 0;
+};
+struct PkHandle {
+    PkMem* mem = nullptr;
+    zk_plonk_pk_desc desc;
+    uint64_t program = 0;
+    std::vector<uint64_t> in_prog, tab_prog;
+};
+std::mutex g_pk_mu;
+std::map<std::pair<zk_ctx*, uint64_t>, PkHandle*> g_pk_handles;
+uint64_t g_pk_next = 1;
+
+void pk_fill_desc(PkHandle* h, const zk_plonk_pk_desc& shape, uint64_t srs_g, uint64_t srs_g_lagrange) {
+    PkMem* m = h->mem;
+    zk_plonk_pk_desc& d = h->desc;
+    d = shape;
+    d.perm_columns = m->perm_columns.data(); d.advice_queries = m->advice_queries.data(); d.fixed_queries = m->fixed_queries.data();
+    d.srs_g = srs_g; d.srs_g_lagrange = srs_g_lagrange; d.program = h->program;
+    d.lookup_input_programs = h->in_prog.data(); d.lookup_table_programs = h->tab_prog.data(); d.lookup_table_key = m->table_key.data();
+    d.fixed_values = m->fixed_values.data(); d.fixed_polys = m->fixed_polys.data(); d.fixed_cosets = m->fixed_cosets.data();
+    d.sigma_values = m->sigma_values.data(); d.sigma_polys = m->sigma_polys.data(); d.sigma_cosets = m->sigma_cosets.data();
+    d.l0 = m->l[0]; d.l_last = m->l[1]; d.l_active_row = m->l[2];
+    d.transcript_repr = m->transcript_repr;
+}
+void pk_drop(zk_ctx* ctx, PkHandle* h) {                              // g_pk_mu held
+    if (h->program) (void)zk_quotient_program_release(ctx, h->program);
+    for (uint64_t p : h->in_prog) if (p) (void)zk_quotient_program_release(ctx, p);
+    for (uint64_t p : h->tab_prog) if (p) (void)zk_quotient_program_release(ctx, p);
+    if (h->mem && --h->mem->holders == 0) {
+        for (void* p : h->mem->owned) (void)zk_dev_free(ctx, p);
+        delete h->mem;
+    }
+    delete h;
+}
+}  // namespace
+
+extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk) {
+    if (!ctx || !host || !pk) return ZK_ERR_ARG;
+    const uint32_t k = host->k, L = host->n_lookups;
+    if (k < 1 || k > 27 || host->cs_degree < 3 || host->transcript > 2 || host->draw_schedule > 1 || !host->transcript_repr || !host->evaluator_zkq1) return ZK_ERR_ARG;
+    if ((host->n_fixed && !host->fixed_values) || (host->n_perm_columns && (!host->sigma_values || !host->perm_columns)) || (host->n_advice_queries && !host->advice_queries) ||
+        (host->n_fixed_queries && !host->fixed_queries) ||
+        (L && (!host->lookup_input_zkq1 || !host->lookup_input_zkq1_len || !host->lookup_table_zkq1 || !host->lookup_table_zkq1_len || !host->lookup_table_key)))
+        return ZK_ERR_ARG;
+    const size_t n = (size_t)1 << k, col_bytes = n * 32;
+    if ((size_t)host->blinding_factors + 2 >= n) return ZK_ERR_ARG;
+    uint32_t ek = k;                                                  // EvaluationDomain::new(j, k): the smallest extended domain that holds a quotient of degree (j - 1) n
+    while (((size_t)1 << ek) < n * (host->cs_degree - 1)) ek++;
+    if (ek > 27) return ZK_ERR_LIMIT;
+    const size_t ext_bytes = (size_t)32 << ek;
+    PkHandle* h = new PkHandle();
+    h->mem = new PkMem();
+    h->mem->holders = 1;
+    PkMem* m = h->mem;
+    auto fail = [&](int rc) { std::lock_guard<std::mutex> lk(g_pk_mu); pk_drop(ctx, h); return rc; };
+    auto alloc = [&](size_t bytes) -> void* { void* p = nullptr; if (zk_dev_alloc(ctx, bytes, &p) != ZK_OK) return nullptr; m->owned.push_back(p); return p; };
+    // values -> (values, polys, cosets); `src` are host columns, or device columns that are borrowed as they are
+    auto three_forms = [&](const void* const* src, size_t count, bool on_device, std::vector<const void*>& values, std::vector<const void*>& polys, std::vector<const void*>& cosets) -> int {
+        std::vector<void*> dst, pl, cs;
+        std::vector<const void*> hs;
+        for (size_t i = 0; i < count; i++) {
+            if (!src[i]) return ZK_ERR_ARG;
+            if (on_device) values.push_back(src[i]);
+            else { void* v = alloc(col_bytes); if (!v) return ZK_ERR_HIP; values.push_back(v); dst.push_back(v); hs.push_back(src[i]); }
+            void* p = alloc(col_bytes); void* c = alloc(ext_bytes);
+            if (!p || !c) return ZK_ERR_HIP;
+            pl.push_back(p); cs.push_back(c);
+        }
+        if (!dst.empty()) PK(zk_dev_upload_batch(ctx, dst.data(), hs.data(), dst.size(), col_bytes));
+        for (size_t i = 0; i < count; i++) PK(zk_dev_copy(ctx, pl[i], values[i], col_bytes));
+        if (count) {
+            PK(zk_lagrange_to_coeff_batch_dev(ctx, pl.data(), count, k));
+            PK(zk_coeff_to_extended_batch_dev(ctx, (const void* const*)pl.data(), cs.data(), count, k, ek));
+        }
+        polys.assign(pl.begin(), pl.end()); cosets.assign(cs.begin(), cs.end());
+        return ZK_OK;
+    };
+    int rc = three_forms(host->fixed_values, host->n_fixed, host->values_on_device != 0, m->fixed_values, m->fixed_polys, m->fixed_cosets);
+    if (!rc) rc = three_forms(host->sigma_values, host->n_perm_columns, host->values_on_device != 0, m->sigma_values, m->sigma_polys, m->sigma_cosets);
+    if (rc) return fail(rc);
+    {   // l0 = [row 0], l_last = [row n - bf - 1], l_active_row = [rows below it]: Lagrange columns -> extended cosets (keygen.rs)
+        const size_t last = n - host->blinding_factors - 1;
+        std::vector<uint64_t> col(3 * n * 4, 0);
+        const Fe one = Fr::one();
+        memcpy(&col[0], one.v, 32);
+        memcpy(&col[(n + last) * 4], one.v, 32);
+        for (size_t i = 0; i < last; i++) memcpy(&col[(2 * n + i) * 4], one.v, 32);
+        void* tmp[3];
+        const void* hs[3];
+        void* out[3];
+        for (int i = 0; i < 3; i++) {
+            void* t = nullptr;
+            if (zk_dev_alloc(ctx, col_bytes, &t) != ZK_OK) { for (int j = 0; j < i; j++) (void)zk_dev_free(ctx, tmp[j]); return fail(ZK_ERR_HIP); }
+            tmp[i] = t; hs[i] = &col[(size_t)i * n * 4];
+        }
+        rc = zk_dev_upload_batch(ctx, tmp, hs, 3, col_bytes);
+        for (int i = 0; i < 3 && !rc; i++) { out[i] = alloc(ext_bytes); if (!out[i]) rc = ZK_ERR_HIP; }
+        if (!rc) rc = zk_lagrange_to_coeff_batch_dev(ctx, tmp, 3, k);
+        if (!rc) rc = zk_coeff_to_extended_batch_dev(ctx, (const void* const*)tmp, out, 3, k, ek);
+        for (int i = 0; i < 3; i++) (void)zk_dev_free(ctx, tmp[i]);
+        if (rc) return fail(rc);
+        for (int i = 0; i < 3; i++) m->l[i] = out[i];
+    }
+    rc = zk_quotient_program_load(ctx, host->evaluator_zkq1, host->evaluator_zkq1_len, &h->program);
+    h->in_prog.assign(L, 0); h->tab_prog.assign(L, 0);
+    for (uint32_t l = 0; l < L && !rc; l++) {
+        rc = zk_quotient_program_load(ctx, host->lookup_input_zkq1[l], host->lookup_input_zkq1_len[l], &h->in_prog[l]);
+        if (!rc) rc = zk_quotient_program_load(ctx, host->lookup_table_zkq1[l], host->lookup_table_zkq1_len[l], &h->tab_prog[l]);
+    }
+    if (rc) return fail(rc);
+    m->perm_columns.assign(host->perm_columns, host->perm_columns + 2 * (size_t)host->n_perm_columns);
+    m->advice_queries.assign(host->advice_queries, host->advice_queries + 2 * (size_t)host->n_advice_queries);
+    m->fixed_queries.assign(host->fixed_queries, host->fixed_queries + 2 * (size_t)host->n_fixed_queries);
+    m->table_key.assign(host->lookup_table_key, host->lookup_table_key + L);
+    m->perm_columns.push_back(0); m->advice_queries.push_back(0); m->fixed_queries.push_back(0); m->table_key.push_back(0);      // .data() of an empty vector may be null: the prover refuses null arrays
+    h->in_prog.push_back(0); h->tab_prog.push_back(0);
+    for (auto* v : {&m->fixed_values, &m->fixed_polys, &m->fixed_cosets, &m->sigma_values, &m->sigma_polys, &m->sigma_cosets}) v->push_back(nullptr);
+    memcpy(m->transcript_repr, host->transcript_repr, 32);
+    zk_plonk_pk_desc shape;
+    memset(&shape, 0, sizeof shape);
+    shape.k = k; shape.extended_k = ek; shape.cs_degree = host->cs_degree; shape.blinding_factors = host->blinding_factors;
+    shape.n_fixed = host->n_fixed; shape.n_advice = host->n_advice; shape.n_instance = host->n_instance; shape.n_lookups = L; shape.n_perm_columns = host->n_perm_columns;
+    shape.n_advice_queries = host->n_advice_queries; shape.n_fixed_queries = host->n_fixed_queries;
+    shape.transcript = host->transcript; shape.draw_schedule = host->draw_schedule;
+    pk_fill_desc(h, shape, srs_g, srs_g_lagrange);
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    *pk = g_pk_next++;
+    g_pk_handles[{ctx, *pk}] = h;
+    return ZK_OK;
+}
+
+extern "C" int zk_plonk_pk_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_pk, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk) {
+    if (!ctx || !owner || !pk) return ZK_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pk_handles.find({owner, owner_pk});
+    if (it == g_pk_handles.end()) return ZK_ERR_ARG;
+    const PkHandle* src = it->second;
+    PkHandle* h = new PkHandle();
+    h->mem = src->mem;
+    h->mem->holders++;
+    const size_t L = src->desc.n_lookups;
+    h->in_prog.assign(L + 1, 0); h->tab_prog.assign(L + 1, 0);
+    int rc = zk_quotient_program_share(ctx, owner, src->program, &h->program);                  // (refuses contexts on different devices)
+    for (size_t l = 0; l < L && !rc; l++) {
+        rc = zk_quotient_program_share(ctx, owner, src->in_prog[l], &h->in_prog[l]);
+        if (!rc) rc = zk_quotient_program_share(ctx, owner, src->tab_prog[l], &h->tab_prog[l]);
+    }
+    if (rc) { pk_drop(ctx, h); return rc; }
+    pk_fill_desc(h, src->desc, srs_g, srs_g_lagrange);
+    *pk = g_pk_next++;
+    g_pk_handles[{ctx, *pk}] = h;
+    return ZK_OK;
+}
+
+extern "C" int zk_plonk_pk_release(zk_ctx* ctx, uint64_t pk) {
+    if (!ctx) return ZK_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pk_handles.find({ctx, pk});
+    if (it == g_pk_handles.end()) return ZK_ERR_ARG;
+    pk_drop(ctx, it->second);
+    g_pk_handles.erase(it);
+    return ZK_OK;
+}
+
+extern "C" int zk_plonk_pk_descriptor(zk_ctx* ctx, uint64_t pk, const zk_plonk_pk_desc** desc) {
+    if (!ctx || !desc) return ZK_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pk_handles.find({ctx, pk});
+    if (it == g_pk_handles.end()) return ZK_ERR_ARG;
+    *desc = &it->second->desc;
+    return ZK_OK;
+}
+
+extern "C" int zk_plonk_prove(zk_ctx* ctx, uint64_t pk, const void* const* advice, int advice_on_device, const void* const* instances, const uint32_t* instance_lens,
+                              zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len) {
+    const zk_plonk_pk_desc* d = nullptr;
+    int rc = zk_plonk_pk_descriptor(ctx, pk, &d);
+    if (rc) return rc;
+    return zk_plonk_create_proof(ctx, d, advice, advice_on_device, instances, instance_lens, rng, rng_user, proof_out, proof_cap, proof_len);
+}
+
+// zk_ctx_destroy (capi.hip): the keys this context still holds go with it (before its programs are released)
+void zk_internal_plonk_ctx_destroyed(zk_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    for (auto it = g_pk_handles.begin(); it != g_pk_handles.end();) {
+        if (it->first.first == ctx) { pk_drop(ctx, it->second); it = g_pk_handles.erase(it); }
+        else ++it;
+    }
+}
+
 extern "C" int zk_plonk_last_phase_ms(double out[9]) {
     if (!out) return ZK_ERR_ARG;
     for (int i = 0; i < 9; i++) out[i] = g_phase_ms[i];
@@ -777,7 +983,7 @@ extern "C" int zk_plonk_last_phase_ms(double out[9]) {
 }
 extern "C" int zk_plonk_trim(zk_ctx* ctx) {
     if (!ctx) return ZK_ERR_ARG;
-    Pool* p = nullptr;
+    std::shared_ptr<Pool> p;
     {
         std::lock_guard<std::mutex> lk(g_pools_mu);
         auto it = g_pools.find(ctx);
@@ -785,7 +991,8 @@ extern "C" int zk_plonk_trim(zk_ctx* ctx) {
         p = it->second;
         g_pools.erase(it);
     }
-    for (auto& kv : p->free_) for (void* d : kv.second) (void)zk_dev_free(ctx, d);
-    delete p;
+    std::map<size_t, std::vector<void*>> idle;
+    { std::lock_guard<std::mutex> lk(p->mu); p->retired = true; idle.swap(p->free_); }      // a proof still running on this context keeps its Arena's reference: its buffers are freed as it returns them
+    for (auto& kv : idle) for (void* d : kv.second) (void)zk_dev_free(ctx, d);
     return ZK_OK;
 }

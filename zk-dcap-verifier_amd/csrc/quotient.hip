@@ -43,10 +43,9 @@ struct QuotProgram {
     uint32_t col_fixed = 0, col_advice = 0, col_instance = 0, col_l0 = 0, col_llast = 0, col_lactive = 0, col_sigma = 0, col_z = 0,
              col_lk_z = 0, col_lk_a = 0, col_lk_s = 0;
     bool uses_xpow = false;
-    void* d_code = nullptr;
-    void* d_consts = nullptr;
-    void* d_cols = nullptr;
-    void* d_rot = nullptr;
+    void* d_code = nullptr;               // immutable after the load; the constants / column pointers / rotation offsets of a RUN live in the calling context's ws_quot,
+    int device = 0;                       // so contexts of one device can share a program (zk_quotient_program_share) and run it concurrently
+    ~QuotProgram() { if (d_code) { (void)hipSetDevice(device); (void)hipFree(d_code); } }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -653,38 +652,36 @@ int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* p
     if (!blob || !prog || len < 48 || (len & 3)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_load: bad blob pointer/length");
     std::vector<uint32_t> words(len / 4);
     memcpy(words.data(), blob, len);
-    QuotProgram* P = new QuotProgram();
+    std::shared_ptr<QuotProgram> P(new QuotProgram());
+    P->device = ctx->device;
     int rc = compile_program(ctx, words.data(), words.size(), *P);
-    if (rc) { delete P; return rc; }
-    if ((size_t)(P->n_slots > QUOT_NREG ? P->n_slots - QUOT_NREG : 0) * 64 * 32 > 160 * 1024) {
-        delete P;
+    if (rc) return rc;
+    if ((size_t)(P->n_slots > QUOT_NREG ? P->n_slots - QUOT_NREG : 0) * 64 * 32 > 160 * 1024)
         return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %u live intermediates; this build keeps at most 80 in LDS", P->n_slots);
-    }
     hipError_t e = hipMalloc(&P->d_code, P->code.size() * 16 + 16);
-    if (e == hipSuccess) e = hipMalloc(&P->d_consts, (size_t)P->n_consts * 32 + 32);
-    if (e == hipSuccess) e = hipMalloc(&P->d_cols, (size_t)P->n_cols * sizeof(void*) + 8);
-    if (e == hipSuccess) e = hipMalloc(&P->d_rot, (P->rotations.size() + 1) * 4);
     if (e == hipSuccess) e = hipMemcpy(P->d_code, P->code.data(), P->code.size() * 16, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        if (P->d_code) (void)hipFree(P->d_code);
-        if (P->d_consts) (void)hipFree(P->d_consts);
-        if (P->d_cols) (void)hipFree(P->d_cols);
-        if (P->d_rot) (void)hipFree(P->d_rot);
-        delete P;
-        return ctx->fail(ZK_ERR_HIP, "zk_quotient_program_load: device allocation failed");
+    if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "zk_quotient_program_load: device allocation failed");
+    *prog = ctx->next_handle++;
+    ctx->programs[*prog] = P;
+    return ZK_OK;
+}
+// a handle of `ctx` onto a program another context of the same device loaded: one compiled program (and one proving key) per process, however many
+// contexts prove concurrently.  Called WITHOUT either context's lock held (capi.hip): takes the owner's, then ctx's.
+int quotient_program_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_prog, uint64_t* prog) {
+    std::shared_ptr<QuotProgram> P;
+    {
+        std::lock_guard<std::mutex> lk(owner->mu);
+        auto it = owner->programs.find(owner_prog);
+        if (it != owner->programs.end()) P = it->second;
     }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!P) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_share: unknown program %llu", (unsigned long long)owner_prog);
+    if (owner->device != ctx->device) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_share: contexts on different devices");
     *prog = ctx->next_handle++;
     ctx->programs[*prog] = P;
     return ZK_OK;
 }
 
-static void free_program(QuotProgram* P) {
-    if (P->d_code) (void)hipFree(P->d_code);
-    if (P->d_consts) (void)hipFree(P->d_consts);
-    if (P->d_cols) (void)hipFree(P->d_cols);
-    if (P->d_rot) (void)hipFree(P->d_rot);
-    delete P;
-}
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns) {
     auto it = ctx->programs.find(prog);
     if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_info: unknown program");
@@ -709,12 +706,10 @@ int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]) {
 int quotient_program_release(zk_ctx* ctx, uint64_t prog) {
     auto it = ctx->programs.find(prog);
     if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_release: unknown program %llu", (unsigned long long)prog);
-    free_program(it->second);
     ctx->programs.erase(it);
     return ZK_OK;
 }
 void release_programs(zk_ctx* ctx) {
-    for (auto& kv : ctx->programs) free_program(kv.second);
     ctx->programs.clear();
 }
 
@@ -781,13 +776,19 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
         rot_off[i] = (uint32_t)v;
     }
     hipStream_t st = ctx->stream;
-    ZK_HIP(hipMemcpyAsync(P.d_consts, consts.data(), consts.size() * 32, hipMemcpyHostToDevice, st));
-    ZK_HIP(hipMemcpyAsync(P.d_cols, cols.data(), cols.size() * sizeof(void*), hipMemcpyHostToDevice, st));
-    ZK_HIP(hipMemcpyAsync(P.d_rot, rot_off.data(), rot_off.size() * 4, hipMemcpyHostToDevice, st));
+    // the run's constants | column pointers | rotation offsets, in this context's own buffer
+    const size_t off_cols = ((size_t)P.n_consts * 32 + 32 + 255) & ~(size_t)255, off_rot = (off_cols + (size_t)P.n_cols * sizeof(void*) + 8 + 255) & ~(size_t)255;
+    ZK_HIP(ctx->ws_quot.ensure(off_rot + (P.rotations.size() + 1) * 4));
+    void* const d_consts = ctx->ws_quot.p;
+    void* const d_cols = (char*)ctx->ws_quot.p + off_cols;
+    void* const d_rot = (char*)ctx->ws_quot.p + off_rot;
+    ZK_HIP(hipMemcpyAsync(d_consts, consts.data(), consts.size() * 32, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(d_cols, cols.data(), cols.size() * sizeof(void*), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(d_rot, rot_off.data(), rot_off.size() * 4, hipMemcpyHostToDevice, st));
     QuotArgs q;
     memset(&q, 0, sizeof q);
-    q.code = (const uint4*)P.d_code; q.n_instr = (uint32_t)P.code.size(); q.consts = P.d_consts;
-    q.cols = (const void* const*)P.d_cols; q.rot_off = (const uint32_t*)P.d_rot; q.size_log = size_log; q.out = a->out;
+    q.code = (const uint4*)P.d_code; q.n_instr = (uint32_t)P.code.size(); q.consts = d_consts;
+    q.cols = (const void* const*)d_cols; q.rot_off = (const uint32_t*)d_rot; q.size_log = size_log; q.out = a->out;
     q.uses_xpow = P.uses_xpow ? 1 : 0;
     q.xpow_mul = cm ? 1u << (P.ek - P.k) : 1u;
     q.xpow_add = cm ? (uint32_t)coset : 0u;

@@ -117,6 +117,14 @@ class Evaluator:
         self.program = program
         self.handle = self.backend.quotient_program_load(program.to_blob())
 
+    @classmethod
+    def shared(cls, other: "Evaluator", backend: Backend) -> "Evaluator":
+        """the same compiled program for another context on the same GPU (zk_quotient_program_share): nothing is compiled or uploaded again"""
+        self = cls.__new__(cls)
+        self.backend, self.program = backend, other.program
+        self.handle = backend.quotient_program_share(other.backend, other.handle)
+        return self
+
     def evaluate_h(self, *, fixed, advice, instance, l0, l_last, l_active_row, perm_cosets, perm_products,
                    lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out, coset: int | None = None, rows: tuple | None = None):
         """All columns are device buffers holding 2^extended_k Fr values (extended cosets);

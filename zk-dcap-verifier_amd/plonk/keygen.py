@@ -56,12 +56,26 @@ class ProvingKey:
     program: ev.Program
     lookup_compressors: list = field(default_factory=list)   # per lookup: (input Evaluator, table Evaluator) over the 2^k rows
     coset_parts: Optional[dict] = None   # params.by_cosets(): coset j -> {"fixed", "sigma", "l"}: the 2^k values of that coset only (this rank's cosets)
+    borrowed: bool = False               # shared_with(): the columns belong to another ProvingKey of the process (same GPU); only the program handles are this key's
+
+    @classmethod
+    def shared_with(cls, other: "ProvingKey", backend: Backend) -> "ProvingKey":
+        """The same proving key for another context on the same GPU (one context per host thread that proves concurrently): every column and every compiled
+        program is SHARED with `other` — one proving key per process (≈2.3 GB at k = 19) instead of one per context, one keygen instead of N.  `other` must
+        outlive the borrower's proofs; release() of a borrower returns only its program handles."""
+        assert other.coset_parts is None, "sharded keys are per rank"
+        ev_ = ev.Evaluator.shared(other.evaluator, backend)
+        comps = [(ev.Evaluator.shared(a, backend), ev.Evaluator.shared(b, backend)) for a, b in other.lookup_compressors]
+        return cls(other.vk, EvaluationDomain(other.vk.cs.degree(), other.vk.k, backend=backend), backend, other.fixed_values, other.fixed_polys, other.fixed_cosets,
+                   other.sigma_values, other.sigma_polys, other.sigma_cosets, other.l0, other.l_last, other.l_active_row, ev_, other.program, comps, None, True)
 
     def release(self):
         self.evaluator.release()
         for a, b in self.lookup_compressors:
             a.release()
             b.release()
+        if self.borrowed:
+            return
         for grp in (self.fixed_values, self.fixed_polys, self.fixed_cosets, self.sigma_values, self.sigma_polys, self.sigma_cosets,
                     [d for d in (self.l0, self.l_last, self.l_active_row) if d is not None],
                     *[v for part in (self.coset_parts or {}).values() for v in part.values()]):

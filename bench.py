@@ -900,53 +900,35 @@ def main(argv=None):
             # ONE proof spread over the ranks (BASELINE configs[4] / SURVEY 8e): both SRS tables sharded by index range, every commitment of
             # create_proof = per-rank partial MSMs + one all_gather of 128-byte points; everything else is computed redundantly on every rank.
             try:
-                from zk_dcap_verifier_amd.transcript import Blake2bWrite
-
-                def all_gather_points(part):
+                def all_gather_points(part):                       # setup only (keygen's commitments of the sharded key): 128-byte points through torch
                     mine = torch.from_numpy(np.ascontiguousarray(part).view(np.int64).copy()).to(tdev)
                     out = [torch.zeros_like(mine) for _ in range(world)]
                     dist.all_gather(out, mine)
                     return torch.stack(out).cpu().numpy().view(np.uint64)
-                held = {}
-                # torch tensors are handed to the library as raw device pointers: only where torch's memory IS the library's device memory
-                device_route = backend == "nccl" or os.environ.get("ZK_BENCH_PLUMBING_TEST") == "1"
-
-                def coset_exchange(nbytes):                        # the quotient's numerators: RCCL all_gather between HBM buffers, no host hop
-                    if held.get("n") != nbytes:
-                        held.update(n=nbytes, send=torch.zeros(nbytes // 8, dtype=torch.int64, device=tdev),
-                                    recv=torch.zeros(world * nbytes // 8, dtype=torch.int64, device=tdev))
-                        if tdev == "cuda":
-                            torch.cuda.synchronize()
-
-                    def run():
-                        be.sync()                                   # the library's stream wrote `send`
-                        dist.all_gather_into_tensor(held["recv"], held["send"])
-                        if tdev == "cuda":
-                            torch.cuda.synchronize()                # ... and will read `recv`
-                    return held["send"].data_ptr(), held["recv"].data_ptr(), run
-                sp = z.kzg.ParamsKZG.sharded(args.k, wl.params.g_host, wl.params.g_lagrange_host, rank, world, all_gather_points, backend=be,
-                                             coset_exchange=coset_exchange if device_route else None)
+                sp = z.kzg.ParamsKZG.sharded(args.k, wl.params.g_host, wl.params.g_lagrange_host, rank, world, all_gather_points, backend=be)
                 cs_, fixed_, asm_, _adv = circuit
                 spk = z.plonk.keygen(sp, cs_, fixed_, asm_)
-
+                # the per-proof path is the NATIVE prover in shard mode (zk_plonk_create_proof, csrc/prover.hip): its collective is the callback below — RCCL
+                # all_gather_into_tensor between two HBM tensors the library uses as its exchange buffers (no host hop on the data path)
+                n_cosets = 1 << (spk.domain.extended_k - args.k)
+                units = sp.my_units(n_cosets)
+                slots = -(-(n_cosets * sp.quotient_parts(n_cosets)) // world)
+                cap = max(slots * (units[0][2] if units else wl.n) * 32, 1 << 16)
+                xch = z.plonk.native.TorchExchange(world, cap, tdev, sync=be.sync)
+                snative = z.plonk.NativeProver(sp, spk, exchange=xch)
                 phase_ms = {}
 
                 def sharded_proof(seed):
                     for w_, m_ in zip(wl.work, wl.master):
                         w_.copy_from(m_)
-                    tr_ = Blake2bWrite()
+                    pr_ = snative.create_proof(wl.work, [], np.random.default_rng(seed))
                     phase_ms.clear()
-                    z.plonk.create_proof(sp, spk, wl.work, [], np.random.default_rng(seed), tr_, timings=phase_ms)
-                    return tr_.finalize()
-                route = "device" if device_route else "host"
-                try:
-                    sharded_proof(1000)
-                except Exception as e_:                            # keep the measurement: numerators through the host all_gather instead
-                    route = f"host ({e_})"
-                    sp.coset_exchange = None
-                    sharded_proof(1000)
+                    phase_ms.update(snative.phase_ms)
+                    return pr_
+                sharded_proof(1000)
                 barrier()
                 t = time.time()
+                c0, b0 = xch.calls, xch.bytes
                 for i_ in range(2):
                     pr_sharded = sharded_proof(1001 + i_)
                 barrier()
@@ -958,11 +940,13 @@ def main(argv=None):
                 same = bool(tt[1].item() == 1.0)
                 tt2 = torch.tensor([ds], dtype=torch.float64, device=tdev)
                 dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
-                extra["sharded_proof"] = {"ranks": world, "ms_per_proof": round(float(tt2.item()) * 1e3, 2), "identical_to_single_gpu_proof": same,
-                                          "quotient_exchange": route, "phase_ms_rank0": {k_: round(v, 2) for k_, v in phase_ms.items()},
+                extra["sharded_proof"] = {"ranks": world, "prover": "native (zk_plonk_create_proof, shard mode)", "ms_per_proof": round(float(tt2.item()) * 1e3, 2),
+                                          "identical_to_single_gpu_proof": same, "collective": f"{backend} all_gather_into_tensor between device tensors",
+                                          "allgathers_per_proof": (xch.calls - c0) // 2, "allgather_bytes_per_rank_per_proof": (xch.bytes - b0) // 2,
+                                          "phase_ms_rank0": {k_: round(v, 2) for k_, v in phase_ms.items()},
                                           "single_gpu_phase_ms": extra.get("single_proof", {}).get("phase_ms"),
-                                          "what": "create_proof with both SRS tables sharded by index range (71 commitments = partial MSMs + all_gather of 128-byte XYZZ points) "
-                                                  "and the quotient sharded by extended-domain coset (size-n coset NTTs + evaluate_h per rank, one all_gather of n*32 bytes per coset); RCCL"}
+                                          "what": "create_proof with both SRS tables sharded by index range (71 commitments = partial MSMs + all_gather of 128-byte XYZZ points, one per phase) "
+                                                  "and the quotient sharded by extended-domain coset (size-n coset NTTs + evaluate_h per rank, one all_gather of the numerators)"}
                 spk.release()
                 sp.release()
             except Exception as e:
@@ -1005,7 +989,8 @@ def main(argv=None):
         print(json.dumps(line), flush=True)
     if multi_hung:
         sys.stdout.flush()
-        os._exit(0)                                            # a collective is stuck in a daemon thread: no orderly teardown is possible
+        sys.stderr.flush()
+        os._exit(3)                                            # a collective is stuck in a daemon thread: no orderly teardown is possible; the bench line is out (rank 0), the launcher sees the failure
     if dist is not None:
         dist.destroy_process_group()
     for b in bes:

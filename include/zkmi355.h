@@ -41,6 +41,7 @@ extern "C" {
 #define ZK_ERR_NODEV (-3)   /* no usable GPU                                                  */
 #define ZK_ERR_PROGRAM (-4) /* malformed / unsupported quotient program                       */
 #define ZK_ERR_LIMIT (-5)   /* size limit of this build exceeded                              */
+#define ZK_ERR_COMM (-6)    /* the caller's collective (zk_allgather_fn) reported a failure   */
 
 typedef struct zk_ctx zk_ctx;
 
@@ -279,6 +280,13 @@ int zk_evaluate_h(zk_ctx* ctx, uint64_t pk, const void* const* advice_polys, con
  * fixed / sigma columns in Lagrange, coefficient and extended-coset form, l0 / l_last / l_active_row cosets, the compiled Evaluator (zk_quotient_program_load)
  * and, per lookup, the two expression programs that theta-compress its input and table expressions over the 2^k rows (ZKQ1 programs with extended_k = k);
  * lookups with equal lookup_table_key share their compressed table.  Queries are (column, rotation) pairs in cs.advice_queries / cs.fixed_queries order. */
+/* One proof over several GPUs (BASELINE configs[4]): the collective between the ranks is the CALLER's (RCCL ncclAllGather over xGMI; anything else
+ * in tests).  Gather `bytes` bytes at send_dev of every rank into recv_dev (rank r's block at recv_dev + r * bytes) — DEVICE pointers on the context's GPU —
+ * and return 0 once recv_dev is complete and send_dev may be overwritten (the library has synchronised its own stream before the call and uses the data right
+ * after it).  Every rank calls it the same number of times with the same sizes: once per commitment phase (128-byte points) and once per proof for the
+ * quotient's numerators. */
+typedef int (*zk_allgather_fn)(void* user, const void* send_dev, void* recv_dev, size_t bytes);
+
 typedef struct zk_plonk_pk_desc {
     uint32_t k, extended_k, cs_degree, blinding_factors;
     uint32_t n_fixed, n_advice, n_instance, n_lookups, n_perm_columns;
@@ -298,6 +306,22 @@ typedef struct zk_plonk_pk_desc {
                                                * 1: snark-verifier PoseidonTranscript<NativeLoader> (T = 3, RATE = 2, R_F = 8, R_P = 57), flag in bit 254 (stack B gen_proof, base.rs:200-212);
                                                * 2: snark-verifier EvmTranscript (Keccak-256, 32-byte big-endian words, uncompressed points; gen_evm_proof_shplonk, base.rs:193-199) */
     uint32_t draw_schedule;                   /* order in which the caller's rng is consumed (see zk_rng_fn): 1 = halo2's (bindings set this), 0 = this library's rounds 1-2 */
+    /* ---- one proof over shard_world GPUs, one process / context per GPU; shard_world <= 1 = single GPU and everything below is ignored ---------------------- *
+     * MSM: srs_g / srs_g_lagrange are tables of n / shard_world points holding bases [shard_rank * n / shard_world, ...) of params.g / params.g_lagrange; every
+     *   commitment phase is one partial MSM batch per rank on its slice of the scalars + ONE all-gather of 128-byte XYZZ points, summed on every rank.
+     * Quotient: the extended domain is 2^(extended_k - k) interleaved cosets of the 2^k domain and evaluate_h never mixes them: unit u = (coset u / parts, the
+     *   (u % parts)-th slice of n / parts rows), parts = shard_world / cosets when there are more ranks than cosets (else 1); rank r evaluates units
+     *   [r * slots, (r + 1) * slots), slots = ceil(units / shard_world), on size-n coset NTTs of the proof's columns, and ONE all-gather carries the numerators.
+     *   The proving key's cosets come per coset: for this rank's cosets in ascending order, n values per column — fixed_cosets / sigma_cosets / l0.. are unused.
+     * Everything else (lookups, grand products, iNTTs, evaluations, SHPLONK arithmetic) is computed on every rank from the same witness and the same rng stream,
+     * so every rank emits the same proof — byte for byte the single-GPU prover's. */
+    uint32_t shard_world, shard_rank;
+    zk_allgather_fn allgather; void* allgather_user;
+    void* xchg_send; void* xchg_recv; size_t xchg_cap;   /* optional caller-owned DEVICE exchange buffers (send: xchg_cap bytes, recv: shard_world x xchg_cap), e.g. two
+                                                          * torch tensors so that the callback can hand them to torch.distributed; NULL = the library allocates its own */
+    const void* const* coset_fixed;           /* [this rank's cosets][n_fixed]        DEVICE, n x 32 B each */
+    const void* const* coset_sigma;           /* [this rank's cosets][n_perm_columns]                         */
+    const void* const* coset_l;               /* [this rank's cosets][3]: l0, l_last, l_active_row            */
 } zk_plonk_pk_desc;
 /* the caller's RNG (`&mut rng` of create_proof): fill out_fr with n uniform field elements as Montgomery limbs (n x 32 B).  Called from a helper thread of the
  * library, once per Fr::random block.  draw_schedule 1 follows halo2_proofs v2023_01_20 draw by draw ([3P-MEM]) — including the Blind(Fr::random) every
@@ -339,6 +363,10 @@ typedef struct zk_plonk_pk_host {
     uint32_t values_on_device;
     const void* transcript_repr;              /* HOST 32 B */
     uint32_t transcript, draw_schedule;       /* as zk_plonk_pk_desc */
+    /* one proof over several GPUs (zk_plonk_pk_desc, last block): with shard_world > 1 the key keeps, instead of whole extended cosets, only the n-value cosets
+     * this rank's quotient units need, and srs_g / srs_g_lagrange of zk_plonk_pk_build are this rank's table slices; zk_plonk_prove then calls `allgather` */
+    uint32_t shard_world, shard_rank;
+    zk_allgather_fn allgather; void* allgather_user;
 } zk_plonk_pk_host;
 int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk);
 int zk_plonk_pk_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_pk, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk);

@@ -3,8 +3,12 @@
  * of the independent CPU prover for the toy / sgx-shaped circuits).  Then a SECOND context borrows the SRS tables and the key (zk_bases_share,
  * zk_plonk_pk_share) and must emit the same proof.  This is the call sequence of the Rust binding (shim/halo2_proofs_mi355x/src/pk_desc.rs), with gcc -std=c99:
  * no Python, no C++, no HIP on this side of the ABI.
- * usage: capi_prove FILE.zkpk      env ZK_TUNE="key=value,..." applies zk_tune_set pairs (the emulator build wants small launch shapes)
+ * With a second argument W > 1 the same proof is then made by W "ranks" — W threads of this process, one context each, every one holding 1/W of both SRS
+ * tables and a sharded key (zk_plonk_pk_host.shard_world) — whose zk_allgather_fn is a barrier + device-to-device copies: the multi-GPU call sequence of a
+ * Rust / C host (with RCCL's ncclAllGather in the callback's place), and every rank must emit the same expected bytes.
+ * usage: capi_prove FILE.zkpk [W]  env ZK_TUNE="key=value,..." applies zk_tune_set pairs (the emulator build wants small launch shapes)
  * exit: 0 proof == expected on both contexts, 3 no usable GPU, 1 anything else */
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,6 +45,59 @@ static void apply_tune(zk_ctx* ctx) {
         if (zk_tune_set(ctx, tok, atoi(eq + 1))) fprintf(stderr, "zk_tune_set(%s) refused\n", tok);
     }
     free(copy);
+}
+
+/* ---- W ranks in one process: the collective is a barrier and W x W device copies --------------------------------------------------------------------- */
+typedef struct {
+    pthread_barrier_t bar;
+    int world;
+    zk_ctx* ctx[8];
+    const void* send[8];
+    int failed;
+} fabric;
+typedef struct {
+    fabric* fab; int rank;
+    const zk_plonk_pk_host* host; const void* g; const void* g_lagrange; size_t n;
+    const void** advice; const void** inst; const uint32_t* inst_len;
+    stream st; const unsigned char* want; size_t want_len; int ok;
+} rank_job;
+static int gather(void* user, const void* send_dev, void* recv_dev, size_t bytes) {
+    rank_job* j = (rank_job*)user;
+    fabric* f = j->fab;
+    f->send[j->rank] = send_dev;
+    pthread_barrier_wait(&f->bar);                                   /* every rank's send buffer is complete and published */
+    int rc = 0;
+    for (int r = 0; r < f->world; r++) rc |= zk_dev_copy(f->ctx[j->rank], (char*)recv_dev + (size_t)r * bytes, f->send[r], bytes);
+    if (rc) f->failed = 1;
+    pthread_barrier_wait(&f->bar);                                   /* nobody overwrites a send buffer a peer is still copying */
+    return f->failed;
+}
+static void* rank_main(void* arg) {
+    rank_job* j = (rank_job*)arg;
+    zk_ctx* ctx = j->fab->ctx[j->rank];
+    const int W = j->fab->world;
+    const size_t n_loc = j->n / (size_t)W, lo = (size_t)j->rank * n_loc;
+    zk_plonk_pk_host host = *j->host;
+    host.shard_world = (uint32_t)W; host.shard_rank = (uint32_t)j->rank; host.allgather = gather; host.allgather_user = j;
+    uint64_t h_g = 0, h_gl = 0, pk = 0;
+    unsigned char* proof = (unsigned char*)malloc(j->want_len + 4096);
+    size_t len = 0;
+    int rc = zk_bases_register(ctx, (const char*)j->g + lo * 64, n_loc, &h_g);
+    if (!rc) rc = zk_bases_register(ctx, (const char*)j->g_lagrange + lo * 64, n_loc, &h_gl);
+    if (!rc) rc = zk_bases_enable_runs(ctx, h_gl);
+    if (!rc) rc = zk_plonk_pk_build(ctx, &host, h_g, h_gl, &pk);
+    if (rc) { fprintf(stderr, "rank %d setup -> %d: %s\n", j->rank, rc, zk_last_error(ctx)); j->fab->failed = 1; }
+    pthread_barrier_wait(&j->fab->bar);                              /* all ranks ready (or all see `failed`): the collectives below stay matched */
+    if (!j->fab->failed) {
+        rc = zk_plonk_prove(ctx, pk, j->advice, 0, j->inst, j->inst_len, serve, &j->st, proof, j->want_len + 4096, &len);
+        if (rc) fprintf(stderr, "rank %d zk_plonk_prove -> %d: %s\n", j->rank, rc, zk_last_error(ctx));
+        j->ok = !rc && len == j->want_len && !memcmp(proof, j->want, len) && j->st.at == j->st.n;
+    }
+    if (pk) zk_plonk_pk_release(ctx, pk);
+    if (h_g) zk_bases_release(ctx, h_g);
+    if (h_gl) zk_bases_release(ctx, h_gl);
+    free(proof);
+    return NULL;
 }
 
 int main(int argc, char** argv) {
@@ -143,6 +200,27 @@ int main(int argc, char** argv) {
     }
     CK(zk_bases_release(ctx, h_g)); CK(zk_bases_release(ctx, h_gl));
     zk_ctx_destroy(ctx);
+    const int W = argc > 2 ? atoi(argv[2]) : 1;
+    if (W > 1) {
+        if (W > 8 || n % (size_t)W) { fprintf(stderr, "W must divide n and be <= 8\n"); return 1; }
+        static fabric fab;
+        static rank_job jobs[8];
+        pthread_t th[8];
+        fab.world = W;
+        pthread_barrier_init(&fab.bar, NULL, (unsigned)W);
+        for (int r = 0; r < W; r++) {
+            if (zk_ctx_create(0, &fab.ctx[r])) { fprintf(stderr, "context of rank %d failed\n", r); return 1; }
+            ctx = fab.ctx[r];
+            apply_tune(ctx);
+            rank_job* j = &jobs[r];
+            j->fab = &fab; j->rank = r; j->host = &host; j->g = g; j->g_lagrange = g_lagrange; j->n = n;
+            j->advice = advice; j->inst = inst; j->inst_len = inst_len; j->st = st; j->st.at = 0; j->want = want; j->want_len = want_len; j->ok = 0;
+        }
+        for (int r = 0; r < W; r++) pthread_create(&th[r], NULL, rank_main, &jobs[r]);
+        for (int r = 0; r < W; r++) pthread_join(th[r], NULL);
+        for (int r = 0; r < W; r++) { if (!jobs[r].ok) { fprintf(stderr, "rank %d of %d: proof differs or failed\n", r, W); return 1; } zk_ctx_destroy(fab.ctx[r]); }
+        printf("%d ranks (sharded tables, sharded keys, all-gather callback): every rank emitted the expected bytes\n", W);
+    }
     printf("capi_prove OK\n");
     return 0;
 }

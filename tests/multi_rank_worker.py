@@ -97,6 +97,27 @@ def run_sharded_proof(rank: int, world: int, port: int, out_dir: str):
     tr = Blake2bWrite()
     plonk.create_proof(params, pk, advice, instances, np.random.default_rng(7), tr)
     ok = ok and tr.finalize() == tcp._golden() and "send" in held
+
+    # ... and through the NATIVE prover (zk_plonk_create_proof in shard mode, csrc/prover.hip): partial MSMs + one all-gather of 128-byte points per commitment
+    # phase, coset / half-coset quotient + one all-gather of the numerators, all through the caller's collective on "device" buffers (zk_allgather_fn)
+    params.coset_exchange = None
+    xch = plonk.native.TorchExchange(world, 1 << 16, "cpu", sync=be.sync)
+    native = plonk.NativeProver(params, pk, exchange=xch)
+    proofs = [native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(7)) for _ in range(2)]
+    n_phases = 7 + 1                                                   # advice, permuted pairs, grand products, random poly, h pieces, SHPLONK h and quotient; + the numerators
+    ok = ok and proofs == [tcp._golden()] * 2 and xch.calls == 2 * n_phases
+    # a failing collective ends the proof with ZK_ERR_COMM on every rank, and the next proof is unaffected
+    class Broken:
+        send = recv = None
+
+        def all_gather(self, *a):
+            raise RuntimeError("link down")
+    try:
+        plonk.NativeProver(params, pk, exchange=Broken()).create_proof([a.copy() for a in advice], instances, np.random.default_rng(7))
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "link down" in str(e)
+    ok = ok and native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(7)) == tcp._golden()
     np.save(os.path.join(out_dir, f"proof_rank{rank}.npy"), np.array([int(ok)]))
     dist.barrier()
     dist.destroy_process_group()

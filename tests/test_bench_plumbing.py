@@ -139,5 +139,6 @@ def test_bench_prove_mode_two_ranks_sharded_proof(built, tmp_path):
     line = json.loads([l for l in open(tmp_path / "rank0.txt").read().strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["mode"] == "prove"
     assert line["extra"]["sharded_proof"]["identical_to_single_gpu_proof"] is True, line["extra"]
-    assert line["extra"]["sharded_proof"]["quotient_exchange"] == "device", line["extra"]       # numerators gathered between "device" buffers
+    assert line["extra"]["sharded_proof"]["prover"].startswith("native"), line["extra"]           # zk_plonk_create_proof in shard mode, collective through the callback
+    assert line["extra"]["sharded_proof"]["allgathers_per_proof"] == 7 + 1, line["extra"]          # one per commitment phase + the quotient's numerators
     assert line["extra"]["msm_sharded_2^7"]["closed_form_check"] is True

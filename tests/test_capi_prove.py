@@ -13,11 +13,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 EMU_TUNE = "msm_sort_threads=64,msm_sort_wgs=3,msm_block=32,ntt_threads=32,ntt_tile_log=6,ntt_max_radix_log=4,msm_target_threads=64,msm_min_chunk=2,vec_block=32,quot_threads=32"
 
 
-def _run(exe, path, tune=None):
+def _run(exe, path, tune=None, world=None):
     env = dict(os.environ)
     if tune:
         env["ZK_TUNE"] = tune
-    return subprocess.run([os.path.join(ROOT, "tests", "csrc", exe), str(path)], capture_output=True, text=True, timeout=900, env=env)
+    return subprocess.run([os.path.join(ROOT, "tests", "csrc", exe), str(path)] + ([str(world)] if world else []), capture_output=True, text=True, timeout=900, env=env)
 
 
 @pytest.mark.parametrize("which,sched", [("toy", 1), ("toy", 0), ("sgx", 1)])
@@ -28,6 +28,17 @@ def test_plain_c_prover_reproduces_the_goldens_emulated(emu, orc, tmp_path, whic
     path.write_bytes(blob)
     r = _run("capi_prove_emu", path, EMU_TUNE)
     assert r.returncode == 0 and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_plain_c_prover_sharded_over_ranks_emulated(emu, orc, tmp_path, world):
+    """W ranks as W threads of the C program, each with 1 / W of both SRS tables and a sharded key built by zk_plonk_pk_build: 2 ranks own two cosets of the quotient
+    each, 8 ranks half a coset; the zk_allgather_fn is a barrier + device copies.  Every rank must emit the golden proof."""
+    import dump_pk_blob as dp
+    path = tmp_path / "pk.zkpk"
+    path.write_bytes(dp.toy_blob(emu, 6, 7, 1))
+    r = _run("capi_prove_emu", path, EMU_TUNE, world)
+    assert r.returncode == 0 and f"{world} ranks" in r.stdout and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_plain_c_prover_has_no_cpu_fallback(emu, orc, tmp_path):
@@ -48,5 +59,5 @@ def test_plain_c_prover_on_gpu(gpu, orc, tmp_path, which, k):
     blob = dp.toy_blob(gpu, 6, 7) if which == "toy" else dp.sgx_blob(gpu, k, 3)
     path = tmp_path / "pk.zkpk"
     path.write_bytes(blob)
-    r = _run("capi_prove", path)
+    r = _run("capi_prove", path, world=4 if k <= 8 else None)       # then 4 ranks (4 contexts on the one GPU): a coset of the quotient each
     assert r.returncode == 0 and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libzkmi355.so")
 
 ZK_OK = 0
-_ERR_NAMES = {-1: "ZK_ERR_ARG", -2: "ZK_ERR_HIP", -3: "ZK_ERR_NODEV", -4: "ZK_ERR_PROGRAM", -5: "ZK_ERR_LIMIT"}
+_ERR_NAMES = {-1: "ZK_ERR_ARG", -2: "ZK_ERR_HIP", -3: "ZK_ERR_NODEV", -4: "ZK_ERR_PROGRAM", -5: "ZK_ERR_LIMIT", -6: "ZK_ERR_COMM"}
 
 
 class ZkError(RuntimeError):

@@ -383,10 +383,32 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     const uint32_t n_sets = pk->n_perm_columns ? (pk->n_perm_columns + chunk - 1) / chunk : 0;
     const uint32_t n_pieces = pk->cs_degree - 1;
     // the descriptor is the caller's: refuse indices that would read outside its arrays
-    if ((pk->n_fixed && (!pk->fixed_values || !pk->fixed_polys || !pk->fixed_cosets)) || (pk->n_perm_columns && (!pk->perm_columns || !pk->sigma_values || !pk->sigma_polys || !pk->sigma_cosets)) ||
+    const uint32_t world = pk->shard_world > 1 ? pk->shard_world : 1, rank = world > 1 ? pk->shard_rank : 0;
+    const bool sharded = world > 1;
+    if ((pk->n_fixed && (!pk->fixed_values || !pk->fixed_polys)) || (pk->n_perm_columns && (!pk->perm_columns || !pk->sigma_values || !pk->sigma_polys)) ||
         (L && (!pk->lookup_input_programs || !pk->lookup_table_programs || !pk->lookup_table_key)) || (pk->n_advice_queries && !pk->advice_queries) ||
-        (pk->n_fixed_queries && !pk->fixed_queries) || !pk->l0 || !pk->l_last || !pk->l_active_row || !pk->transcript_repr)
+        (pk->n_fixed_queries && !pk->fixed_queries) || !pk->transcript_repr)
         return ZK_ERR_ARG;
+    if (!sharded && ((pk->n_fixed && !pk->fixed_cosets) || (pk->n_perm_columns && !pk->sigma_cosets) || !pk->l0 || !pk->l_last || !pk->l_active_row)) return ZK_ERR_ARG;
+    if (sharded && (rank >= world || n % world || !pk->allgather || (pk->n_fixed && !pk->coset_fixed) || (pk->n_perm_columns && !pk->coset_sigma) || !pk->coset_l)) return ZK_ERR_ARG;
+    // the quotient's units of this rank (see zk_plonk_pk_desc): (coset, first row, rows)
+    struct Unit { uint32_t coset; uint64_t lo, rows; };
+    std::vector<Unit> units;
+    std::vector<uint32_t> my_cosets;
+    const uint32_t n_cosets = 1u << (ek - k);
+    uint32_t parts = 1;
+    size_t slots = 0, unit_rows = n;
+    if (sharded) {
+        if (world > n_cosets && world % n_cosets == 0) { const uint32_t p = world / n_cosets; if ((p & (p - 1)) == 0 && n % p == 0) parts = p; }
+        const size_t n_units = (size_t)n_cosets * parts;
+        unit_rows = n / parts;
+        slots = (n_units + world - 1) / world;
+        for (size_t u = (size_t)rank * slots; u < (size_t)(rank + 1) * slots && u < n_units; u++) {
+            units.push_back({(uint32_t)(u / parts), (u % parts) * unit_rows, unit_rows});
+            if (my_cosets.empty() || my_cosets.back() != units.back().coset) my_cosets.push_back(units.back().coset);
+        }
+    }
+    const size_t n_loc = n / world, shard_lo = (size_t)rank * n_loc;
     for (uint32_t j = 0; j < pk->n_perm_columns; j++) {
         const uint32_t ty = pk->perm_columns[2 * j], ix = pk->perm_columns[2 * j + 1];
         if (ty > 2 || ix >= (ty == 0 ? pk->n_advice : ty == 1 ? pk->n_fixed : pk->n_instance)) return ZK_ERR_ARG;
@@ -454,10 +476,30 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         for (uint32_t i = 0; i < pk->n_advice; i++) { bdst[i] = (char*)adv[i] + usable * 32; bsrc[i] = draws.take(i); }
         if (pk->n_advice) PK(zk_dev_upload_batch(ctx, bdst.data(), bsrc.data(), pk->n_advice, (n - usable) * 32));
     }
+    // exchange buffers of a sharded proof: the caller's (e.g. two torch tensors, so that its callback can hand RCCL tensors) or the proof's own
+    void* xsend = nullptr; void* xrecv = nullptr;
+    if (sharded) {
+        const size_t most_cols = std::max<size_t>({pk->n_advice, 2 * (size_t)L, (size_t)n_sets + L, n_pieces, 1});
+        const size_t need = std::max(slots * unit_rows * 32, most_cols * 128);
+        if (pk->xchg_send && pk->xchg_recv) { if (pk->xchg_cap < need) return ZK_ERR_LIMIT; xsend = pk->xchg_send; xrecv = pk->xchg_recv; }
+        else { xsend = mem.get(need); xrecv = mem.get(need * world); if (!xsend || !xrecv) return ZK_ERR_HIP; }
+    }
     auto commit = [&](uint64_t table, const std::vector<void*>& cols) -> int {
         if (cols.empty()) return ZK_OK;
         std::vector<uint64_t> out(cols.size() * 12);
-        PK(zk_msm_batch_dev(ctx, table, (const void* const*)cols.data(), cols.size(), n, out.data()));
+        if (!sharded) PK(zk_msm_batch_dev(ctx, table, (const void* const*)cols.data(), cols.size(), n, out.data()));
+        else {
+            // this rank's index range of every column against its slice of the table; the 128-byte partial points of the phase travel in ONE all-gather
+            std::vector<const void*> slice(cols.size());
+            for (size_t i = 0; i < cols.size(); i++) slice[i] = (const char*)cols[i] + shard_lo * 32;
+            const size_t bytes = cols.size() * 128;
+            std::vector<uint64_t> part(cols.size() * 16), all((size_t)world * cols.size() * 16);
+            PK(zk_msm_batch_partial_dev(ctx, table, slice.data(), cols.size(), n_loc, part.data()));
+            PK(zk_dev_upload(ctx, xsend, part.data(), bytes));
+            if (pk->allgather(pk->allgather_user, xsend, xrecv, bytes)) return ZK_ERR_COMM;
+            PK(zk_dev_download(ctx, all.data(), xrecv, bytes * world));
+            PK(zk_g1_sum_xyzz_batch(all.data(), world, cols.size(), out.data()));
+        }
         for (size_t i = 0; i < cols.size(); i++) tr.write_point(&out[12 * i]);
         return ZK_OK;
     };
@@ -546,22 +588,52 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     PK(zk_lagrange_to_coeff_batch_dev(ctx, lag.data(), lag.size(), k));
     void* h_ext = mem.get(en * 32);
     if (!h_ext) return ZK_ERR_HIP;
-    {
+    auto quotient_args = [&](zk_quotient_args& a, void* const* ext, std::vector<const void*>& e_in, std::vector<const void*>& e_tab) {
+        const size_t nA = pk->n_advice, nI = pk->n_instance;
+        e_in.clear(); e_tab.clear();
+        for (uint32_t l = 0; l < L; l++) { e_in.push_back(ext[nA + nI + n_sets + L + 2 * l]); e_tab.push_back(ext[nA + nI + n_sets + L + 2 * l + 1]); }
+        memset(&a, 0, sizeof a);
+        a.advice = (const void* const*)ext; a.instance = (const void* const*)ext + nA;
+        a.perm_products = (const void* const*)ext + nA + nI; a.n_sets = n_sets;
+        a.lookup_product = (const void* const*)ext + nA + nI + n_sets; a.lookup_input = e_in.data(); a.lookup_table = e_tab.data();
+        a.challenges = one.v; a.beta = beta.v; a.gamma = gamma.v; a.theta = theta.v; a.y = y.v;
+    };
+    if (!sharded) {
         std::vector<void*> ext(lag.size());
         for (auto& e : ext) { e = mem.get(en * 32); if (!e) return ZK_ERR_HIP; }
         PK(zk_coeff_to_extended_batch_dev(ctx, (const void* const*)lag.data(), ext.data(), ext.size(), k, ek));
-        const size_t nA = pk->n_advice, nI = pk->n_instance;
         std::vector<const void*> e_in, e_tab;
-        for (uint32_t l = 0; l < L; l++) { e_in.push_back(ext[nA + nI + n_sets + L + 2 * l]); e_tab.push_back(ext[nA + nI + n_sets + L + 2 * l + 1]); }
         zk_quotient_args a;
-        memset(&a, 0, sizeof a);
-        a.fixed = pk->fixed_cosets; a.advice = (const void* const*)ext.data(); a.instance = (const void* const*)ext.data() + nA;
-        a.l0 = pk->l0; a.l_last = pk->l_last; a.l_active_row = pk->l_active_row;
-        a.perm_cosets = pk->sigma_cosets; a.perm_products = (const void* const*)ext.data() + nA + nI; a.n_sets = n_sets;
-        a.lookup_product = (const void* const*)ext.data() + nA + nI + n_sets; a.lookup_input = e_in.data(); a.lookup_table = e_tab.data();
-        a.challenges = one.v; a.beta = beta.v; a.gamma = gamma.v; a.theta = theta.v; a.y = y.v; a.out = h_ext;
+        quotient_args(a, ext.data(), e_in, e_tab);
+        a.fixed = pk->fixed_cosets; a.l0 = pk->l0; a.l_last = pk->l_last; a.l_active_row = pk->l_active_row; a.perm_cosets = pk->sigma_cosets; a.out = h_ext;
         PK(zk_quotient_run_dev(ctx, pk->program, &a));
         for (auto e : ext) mem.give_back(e);
+    } else {
+        // this rank brings the columns to ITS cosets only (size-n NTTs), evaluates the numerator on its units straight into the send buffer; one all-gather
+        // carries every rank's numerators (unit order = coset order, rows ascending: rank r's block starts at unit r * slots), then the cosets are interleaved
+        std::vector<void*> cols(lag.size());
+        for (auto& e : cols) { e = mem.get(col_bytes); if (!e) return ZK_ERR_HIP; }
+        int at = -1;
+        for (size_t s_ = 0; s_ < units.size(); s_++) {
+            const Unit& u = units[s_];
+            size_t ci = 0;
+            while (my_cosets[ci] != u.coset) ci++;
+            if ((int)u.coset != at) { PK(zk_coeff_to_coset_batch_dev(ctx, (const void* const*)lag.data(), cols.data(), cols.size(), k, ek, u.coset)); at = (int)u.coset; }
+            std::vector<const void*> e_in, e_tab;
+            zk_quotient_args a;
+            quotient_args(a, cols.data(), e_in, e_tab);
+            a.fixed = pk->coset_fixed + ci * pk->n_fixed; a.perm_cosets = pk->coset_sigma + ci * pk->n_perm_columns;
+            a.l0 = pk->coset_l[3 * ci]; a.l_last = pk->coset_l[3 * ci + 1]; a.l_active_row = pk->coset_l[3 * ci + 2];
+            a.out = (char*)xsend + s_ * unit_rows * 32;
+            if (parts == 1) PK(zk_quotient_run_coset_dev(ctx, pk->program, &a, u.coset));
+            else PK(zk_quotient_run_coset_rows_dev(ctx, pk->program, &a, u.coset, u.lo, u.rows));
+        }
+        PK(zk_dev_sync(ctx));
+        if (pk->allgather(pk->allgather_user, xsend, xrecv, slots * unit_rows * 32)) return ZK_ERR_COMM;
+        std::vector<const void*> srcs(n_cosets);
+        for (uint32_t j = 0; j < n_cosets; j++) srcs[j] = (const char*)xrecv + (size_t)j * col_bytes;
+        PK(zk_fr_interleave_dev(ctx, srcs.data(), n_cosets, n, h_ext));
+        for (auto e : cols) mem.give_back(e);
     }
     clk.lap(5);
     // ---- 7. divide, back to coefficients, commit the pieces ---------------------------------------------------------------------------------------------------------
@@ -784,6 +856,7 @@ struct PkMem {
     std::vector<void*> owned;                                         // device allocations, freed by whoever drops the last handle
     std::vector<const void*> fixed_values, fixed_polys, fixed_cosets, sigma_values, sigma_polys, sigma_cosets;
     void* l[3] = {nullptr, nullptr, nullptr};
+    std::vector<const void*> coset_fixed, coset_sigma, coset_l;      // a sharded key: [this rank's cosets][columns], n values each
     std::vector<uint32_t> perm_columns, advice_queries, fixed_queries, table_key;
     uint8_t transcript_repr[32];
     int holders = 0;
@@ -808,6 +881,7 @@ void pk_fill_desc(PkHandle* h, const zk_plonk_pk_desc& shape, uint64_t srs_g, ui
     d.fixed_values = m->fixed_values.data(); d.fixed_polys = m->fixed_polys.data(); d.fixed_cosets = m->fixed_cosets.data();
     d.sigma_values = m->sigma_values.data(); d.sigma_polys = m->sigma_polys.data(); d.sigma_cosets = m->sigma_cosets.data();
     d.l0 = m->l[0]; d.l_last = m->l[1]; d.l_active_row = m->l[2];
+    d.coset_fixed = m->coset_fixed.data(); d.coset_sigma = m->coset_sigma.data(); d.coset_l = m->coset_l.data();
     d.transcript_repr = m->transcript_repr;
 }
 void pk_drop(zk_ctx* ctx, PkHandle* h) {                              // g_pk_mu held
@@ -843,28 +917,56 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
     auto fail = [&](int rc) { std::lock_guard<std::mutex> lk(g_pk_mu); pk_drop(ctx, h); return rc; };
     auto alloc = [&](size_t bytes) -> void* { void* p = nullptr; if (zk_dev_alloc(ctx, bytes, &p) != ZK_OK) return nullptr; m->owned.push_back(p); return p; };
     // values -> (values, polys, cosets); `src` are host columns, or device columns that are borrowed as they are
-    auto three_forms = [&](const void* const* src, size_t count, bool on_device, std::vector<const void*>& values, std::vector<const void*>& polys, std::vector<const void*>& cosets) -> int {
-        std::vector<void*> dst, pl, cs;
+    // a sharded key keeps only the cosets this rank's quotient units live on (the unit rule of zk_plonk_pk_desc), n values per column
+    const uint32_t world = host->shard_world > 1 ? host->shard_world : 1;
+    std::vector<uint32_t> my_cosets;
+    if (world > 1) {
+        if (host->shard_rank >= world || n % world || !host->allgather) return fail(ZK_ERR_ARG);
+        const uint32_t n_cosets = 1u << (ek - k);
+        uint32_t parts = 1;
+        if (world > n_cosets && world % n_cosets == 0) { const uint32_t p = world / n_cosets; if ((p & (p - 1)) == 0 && n % p == 0) parts = p; }
+        const size_t n_units = (size_t)n_cosets * parts, slots = (n_units + world - 1) / world;
+        for (size_t u = (size_t)host->shard_rank * slots; u < (size_t)(host->shard_rank + 1) * slots && u < n_units; u++)
+            if (my_cosets.empty() || my_cosets.back() != u / parts) my_cosets.push_back((uint32_t)(u / parts));
+    }
+    // coeffs -> extended cosets (single GPU: `cosets`) or this rank's cosets (`by_coset`, [coset][column])
+    auto to_cosets = [&](std::vector<void*>& pl, std::vector<const void*>& cosets, std::vector<const void*>& by_coset) -> int {
+        const size_t count = pl.size();
+        if (world == 1) {
+            std::vector<void*> cs(count);
+            for (auto& c : cs) { c = alloc(ext_bytes); if (!c) return ZK_ERR_HIP; }
+            if (count) PK(zk_coeff_to_extended_batch_dev(ctx, (const void* const*)pl.data(), cs.data(), count, k, ek));
+            cosets.assign(cs.begin(), cs.end());
+            return ZK_OK;
+        }
+        for (uint32_t j : my_cosets) {
+            std::vector<void*> cs(count);
+            for (auto& c : cs) { c = alloc(col_bytes); if (!c) return ZK_ERR_HIP; }
+            if (count) PK(zk_coeff_to_coset_batch_dev(ctx, (const void* const*)pl.data(), cs.data(), count, k, ek, j));
+            by_coset.insert(by_coset.end(), cs.begin(), cs.end());
+        }
+        return ZK_OK;
+    };
+    auto three_forms = [&](const void* const* src, size_t count, bool on_device, std::vector<const void*>& values, std::vector<const void*>& polys, std::vector<const void*>& cosets,
+                           std::vector<const void*>& by_coset) -> int {
+        std::vector<void*> dst, pl;
         std::vector<const void*> hs;
         for (size_t i = 0; i < count; i++) {
             if (!src[i]) return ZK_ERR_ARG;
             if (on_device) values.push_back(src[i]);
             else { void* v = alloc(col_bytes); if (!v) return ZK_ERR_HIP; values.push_back(v); dst.push_back(v); hs.push_back(src[i]); }
-            void* p = alloc(col_bytes); void* c = alloc(ext_bytes);
-            if (!p || !c) return ZK_ERR_HIP;
-            pl.push_back(p); cs.push_back(c);
+            void* p = alloc(col_bytes);
+            if (!p) return ZK_ERR_HIP;
+            pl.push_back(p);
         }
         if (!dst.empty()) PK(zk_dev_upload_batch(ctx, dst.data(), hs.data(), dst.size(), col_bytes));
         for (size_t i = 0; i < count; i++) PK(zk_dev_copy(ctx, pl[i], values[i], col_bytes));
-        if (count) {
-            PK(zk_lagrange_to_coeff_batch_dev(ctx, pl.data(), count, k));
-            PK(zk_coeff_to_extended_batch_dev(ctx, (const void* const*)pl.data(), cs.data(), count, k, ek));
-        }
-        polys.assign(pl.begin(), pl.end()); cosets.assign(cs.begin(), cs.end());
-        return ZK_OK;
+        if (count) PK(zk_lagrange_to_coeff_batch_dev(ctx, pl.data(), count, k));
+        polys.assign(pl.begin(), pl.end());
+        return to_cosets(pl, cosets, by_coset);
     };
-    int rc = three_forms(host->fixed_values, host->n_fixed, host->values_on_device != 0, m->fixed_values, m->fixed_polys, m->fixed_cosets);
-    if (!rc) rc = three_forms(host->sigma_values, host->n_perm_columns, host->values_on_device != 0, m->sigma_values, m->sigma_polys, m->sigma_cosets);
+    int rc = three_forms(host->fixed_values, host->n_fixed, host->values_on_device != 0, m->fixed_values, m->fixed_polys, m->fixed_cosets, m->coset_fixed);
+    if (!rc) rc = three_forms(host->sigma_values, host->n_perm_columns, host->values_on_device != 0, m->sigma_values, m->sigma_polys, m->sigma_cosets, m->coset_sigma);
     if (rc) return fail(rc);
     {   // l0 = [row 0], l_last = [row n - bf - 1], l_active_row = [rows below it]: Lagrange columns -> extended cosets (keygen.rs)
         const size_t last = n - host->blinding_factors - 1;
@@ -873,21 +975,19 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
         memcpy(&col[0], one.v, 32);
         memcpy(&col[(n + last) * 4], one.v, 32);
         for (size_t i = 0; i < last; i++) memcpy(&col[(2 * n + i) * 4], one.v, 32);
-        void* tmp[3];
+        std::vector<void*> tmp(3, nullptr);
         const void* hs[3];
-        void* out[3];
         for (int i = 0; i < 3; i++) {
-            void* t = nullptr;
-            if (zk_dev_alloc(ctx, col_bytes, &t) != ZK_OK) { for (int j = 0; j < i; j++) (void)zk_dev_free(ctx, tmp[j]); return fail(ZK_ERR_HIP); }
-            tmp[i] = t; hs[i] = &col[(size_t)i * n * 4];
+            if (zk_dev_alloc(ctx, col_bytes, &tmp[i]) != ZK_OK) { for (int j = 0; j < i; j++) (void)zk_dev_free(ctx, tmp[j]); return fail(ZK_ERR_HIP); }
+            hs[i] = &col[(size_t)i * n * 4];
         }
-        rc = zk_dev_upload_batch(ctx, tmp, hs, 3, col_bytes);
-        for (int i = 0; i < 3 && !rc; i++) { out[i] = alloc(ext_bytes); if (!out[i]) rc = ZK_ERR_HIP; }
-        if (!rc) rc = zk_lagrange_to_coeff_batch_dev(ctx, tmp, 3, k);
-        if (!rc) rc = zk_coeff_to_extended_batch_dev(ctx, (const void* const*)tmp, out, 3, k, ek);
+        rc = zk_dev_upload_batch(ctx, tmp.data(), hs, 3, col_bytes);
+        if (!rc) rc = zk_lagrange_to_coeff_batch_dev(ctx, tmp.data(), 3, k);
+        std::vector<const void*> ext;
+        if (!rc) rc = to_cosets(tmp, ext, m->coset_l);
         for (int i = 0; i < 3; i++) (void)zk_dev_free(ctx, tmp[i]);
         if (rc) return fail(rc);
-        for (int i = 0; i < 3; i++) m->l[i] = out[i];
+        for (int i = 0; i < 3 && world == 1; i++) m->l[i] = (void*)ext[i];
     }
     rc = zk_quotient_program_load(ctx, host->evaluator_zkq1, host->evaluator_zkq1_len, &h->program);
     h->in_prog.assign(L, 0); h->tab_prog.assign(L, 0);
@@ -902,7 +1002,7 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
     m->table_key.assign(host->lookup_table_key, host->lookup_table_key + L);
     m->perm_columns.push_back(0); m->advice_queries.push_back(0); m->fixed_queries.push_back(0); m->table_key.push_back(0);      // .data() of an empty vector may be null: the prover refuses null arrays
     h->in_prog.push_back(0); h->tab_prog.push_back(0);
-    for (auto* v : {&m->fixed_values, &m->fixed_polys, &m->fixed_cosets, &m->sigma_values, &m->sigma_polys, &m->sigma_cosets}) v->push_back(nullptr);
+    for (auto* v : {&m->fixed_values, &m->fixed_polys, &m->fixed_cosets, &m->sigma_values, &m->sigma_polys, &m->sigma_cosets, &m->coset_fixed, &m->coset_sigma, &m->coset_l}) v->push_back(nullptr);
     memcpy(m->transcript_repr, host->transcript_repr, 32);
     zk_plonk_pk_desc shape;
     memset(&shape, 0, sizeof shape);
@@ -910,6 +1010,7 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
     shape.n_fixed = host->n_fixed; shape.n_advice = host->n_advice; shape.n_instance = host->n_instance; shape.n_lookups = L; shape.n_perm_columns = host->n_perm_columns;
     shape.n_advice_queries = host->n_advice_queries; shape.n_fixed_queries = host->n_fixed_queries;
     shape.transcript = host->transcript; shape.draw_schedule = host->draw_schedule;
+    shape.shard_world = host->shard_world; shape.shard_rank = host->shard_rank; shape.allgather = host->allgather; shape.allgather_user = host->allgather_user;
     pk_fill_desc(h, shape, srs_g, srs_g_lagrange);
     std::lock_guard<std::mutex> lk(g_pk_mu);
     *pk = g_pk_next++;

@@ -18,6 +18,33 @@ from ..kzg import ParamsKZG
 from .keygen import ProvingKey
 
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class TorchExchange:
+    """The collective of a sharded proof over torch.distributed (backend "nccl" = RCCL over xGMI on a multi-GPU node; "gloo" in the CPU tests, where the
+    emulator's device memory is host memory): two byte tensors the library uses as its exchange buffers (zk_plonk_pk_desc.xchg_send / xchg_recv), so that
+    the all-gather runs between HBM buffers with no host hop; `all_gather(send_ptr, recv_ptr, nbytes)` is what zk_allgather_fn calls."""
+
+    def __init__(self, world: int, cap_bytes: int, device: str = "cpu", sync=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.world, self.cap, self.device, self.sync = torch, dist, world, int(cap_bytes), device, sync
+        self.send = torch.zeros(self.cap, dtype=torch.uint8, device=device)
+        self.recv = torch.zeros(self.cap * world, dtype=torch.uint8, device=device)
+        if device != "cpu":
+            torch.cuda.synchronize()
+        self.calls, self.bytes = 0, 0
+
+    def all_gather(self, send_ptr: int, recv_ptr: int, nbytes: int) -> None:
+        assert send_ptr == self.send.data_ptr() and recv_ptr == self.recv.data_ptr() and nbytes <= self.cap, "the library must use the exchange buffers it was given"
+        if self.sync is not None:
+            self.sync()                                             # the library's stream wrote `send` (it has synchronised already; belt and braces)
+        self.dist.all_gather_into_tensor(self.recv[: self.world * nbytes], self.send[:nbytes])
+        if self.device != "cpu":
+            self.torch.cuda.synchronize()                           # ... and will read `recv` right after the callback returns
+        self.calls += 1
+        self.bytes += nbytes
 
 
 class PkDesc(C.Structure):
@@ -31,7 +58,10 @@ class PkDesc(C.Structure):
                 ("fixed_values", C.c_void_p), ("fixed_polys", C.c_void_p), ("fixed_cosets", C.c_void_p),
                 ("sigma_values", C.c_void_p), ("sigma_polys", C.c_void_p), ("sigma_cosets", C.c_void_p),
                 ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
-                ("transcript_repr", C.c_void_p), ("transcript", C.c_uint32), ("draw_schedule", C.c_uint32)]
+                ("transcript_repr", C.c_void_p), ("transcript", C.c_uint32), ("draw_schedule", C.c_uint32),
+                ("shard_world", C.c_uint32), ("shard_rank", C.c_uint32), ("allgather", ALLGATHER_FN), ("allgather_user", C.c_void_p),
+                ("xchg_send", C.c_void_p), ("xchg_recv", C.c_void_p), ("xchg_cap", C.c_size_t),
+                ("coset_fixed", C.c_void_p), ("coset_sigma", C.c_void_p), ("coset_l", C.c_void_p)]
 
 
 class NativeProver:
@@ -39,8 +69,11 @@ class NativeProver:
 
     TRANSCRIPTS = {"blake2b": 0, "poseidon": 1, "evm": 2}
 
-    def __init__(self, params: ParamsKZG, pk: ProvingKey, transcript: str = "blake2b", draw_schedule: int = 1):
-        assert params.world == 1 and pk.coset_parts is None, "the native prover is the single-GPU path (sharded proofs: plonk.create_proof)"
+    def __init__(self, params: ParamsKZG, pk: ProvingKey, transcript: str = "blake2b", draw_schedule: int = 1, exchange=None):
+        """exchange (sharded params only): the ranks' collective — an object with `all_gather(send_ptr, recv_ptr, nbytes)` and, optionally, the device
+        buffers `send` / `recv` / `cap` the library should exchange through (TorchExchange above); every rank must prove with the same witness and rng stream."""
+        assert (params.world == 1) == (pk.coset_parts is None), "a sharded SRS goes with a proving key built on it (keygen(params.sharded(..)))"
+        assert params.world == 1 or exchange is not None, "a sharded proof needs the ranks' all-gather"
         self.params, self.pk, self.be = params, pk, pk.backend
         cs = pk.vk.cs
         self._keep = []
@@ -78,7 +111,29 @@ class NativeProver:
         d.lookup_table_key = u32(key_ids)
         d.fixed_values, d.fixed_polys, d.fixed_cosets = ptrs(pk.fixed_values), ptrs(pk.fixed_polys), ptrs(pk.fixed_cosets)
         d.sigma_values, d.sigma_polys, d.sigma_cosets = ptrs(pk.sigma_values), ptrs(pk.sigma_polys), ptrs(pk.sigma_cosets)
-        d.l0, d.l_last, d.l_active_row = _dptr(pk.l0), _dptr(pk.l_last), _dptr(pk.l_active_row)
+        if params.world == 1:
+            d.l0, d.l_last, d.l_active_row = _dptr(pk.l0), _dptr(pk.l_last), _dptr(pk.l_active_row)
+        else:
+            # one proof over the ranks: this rank's table slices are behind the SRS handles already (ParamsKZG.sharded); the key's cosets come per coset
+            # (keygen on sharded params keeps only this rank's: pk.coset_parts), and the collective is the caller's
+            mine = sorted(pk.coset_parts)
+            d.shard_world, d.shard_rank = params.world, params.rank
+            d.coset_fixed = ptrs([c for j in mine for c in pk.coset_parts[j]["fixed"]])
+            d.coset_sigma = ptrs([c for j in mine for c in pk.coset_parts[j]["sigma"]])
+            d.coset_l = ptrs([c for j in mine for c in pk.coset_parts[j]["l"]])
+            self.exchange, self.comm_errors = exchange, []
+
+            def gather(_user, send, recv, nbytes):
+                try:
+                    exchange.all_gather(int(send), int(recv), int(nbytes))
+                    return 0
+                except BaseException as e:                          # never let an exception cross the FFI: the proof ends with ZK_ERR_COMM
+                    self.comm_errors.append(e)
+                    return 1
+            self._gather_cb = ALLGATHER_FN(gather)
+            d.allgather = self._gather_cb
+            if getattr(exchange, "send", None) is not None:
+                d.xchg_send, d.xchg_recv, d.xchg_cap = exchange.send.data_ptr(), exchange.recv.data_ptr(), exchange.cap
         d.transcript_repr = repr_bytes.ctypes.data
         d.transcript = self.TRANSCRIPTS[transcript]         # which Fiat-Shamir transcript / proof encoding (zk_plonk_pk_desc.transcript)
         d.draw_schedule = draw_schedule                     # 1: halo2's order of Fr::random draws; 0: rounds 1-2 of this repo (prover.py draw_plan)
@@ -111,6 +166,8 @@ class NativeProver:
                                           out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(ln))
         if errors:
             raise errors[0]
+        if getattr(self, "comm_errors", None):
+            raise self.comm_errors.pop()
         be._ck(rc)
         ph = (C.c_double * 9)()
         be.lib.zk_plonk_last_phase_ms(ph)

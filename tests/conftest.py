@@ -62,9 +62,13 @@ def emu(built):
 def gpu():
     """Backend on the real GPU through the product library — fails loudly if it is missing."""
     import zk_dcap_verifier_amd as z
-    if not os.path.exists(z.LIB_PATH):          # normally the built library travels with the tree
-        import __graft_entry__ as g
-        g.build(test_artifacts=False)
+    import __graft_entry__ as g
+    if not g.library_is_current():              # normally the built library travels with the tree; a binary older than the sources is rebuilt, never tested
+        g.build(test_artifacts=False, force=True)
+    for exe in ("capi_smoke", "capi_prove"):    # the plain-C consumers link against it
+        if not os.path.exists(os.path.join(ROOT, "tests", "csrc", exe)):
+            g.build(test_artifacts=True)
+            break
     be = z.Backend(0)
     assert "gfx950" in be.version() and "EMULATED" not in be.version()
     yield be

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "../zk-dcap-verifier_amd/csrc/ec.cuh"
 using namespace zk;
 
@@ -67,11 +68,110 @@ __global__ void k_fqsqr(uint32_t* out, uint32_t seed) {
     for (int i = 0; i < ITER / 4; i++) { x = Fq::sqr(x); y = Fq::sqr(y); }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x.v[0] ^ y.v[3];
 }
+// the plain-C coarsely integrated operand scanning form of the Montgomery product (round 1's first version; lives here since round 3 — the library has one product)
+__host__ __device__ __forceinline__ u256 fq_mul_cios(const u256& a, const u256& b) {
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint64_t s = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
+            t[j] = (uint32_t)s;
+            c = s >> 32;
+        }
+        uint32_t t8 = t[8] + (uint32_t)c;
+        uint32_t m = t[0] * FqParams::INV;
+        c = ((uint64_t)m * Fq::p(0) + t[0]) >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            uint64_t s = (uint64_t)m * Fq::p(j) + t[j] + c;
+            t[j - 1] = (uint32_t)s;
+            c = s >> 32;
+        }
+        uint64_t s = (uint64_t)t8 + c;
+        t[7] = (uint32_t)s;
+        t[8] = (uint32_t)(s >> 32);
+    }
+    u256 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.v[i] = t[i];
+    return Fq::reduce_once(o);
+}
+
+// ---- round 3 experiment: carry-free limbs.  9 limbs of 29 bits (261 >= 254 + headroom), Montgomery radix 2^261, product scanning with ONE 64-bit
+// accumulator per column: a partial product is < 2^58, a column sums at most 9 a_i b_j + 9 m_i p_j < 18 * 2^58 < 2^63, so `v_mad_u64_u32` accumulates with no
+// carry-out and no `v_addc_co_u32` at all: 81 + 81 mads + 9 mul_lo + 17 64-bit shifts + 17 masks, against 128 mads + 128 addc + 8 mul_lo of the 8 x 32-bit form.
+// Result < 2p for inputs < 2p (no final subtraction here: this measures the UPPER bound of the form; limb conversion at load / store is not counted either).
+struct u261 { uint32_t l[9]; };
+constexpr uint32_t M29 = (1u << 29) - 1;
+__host__ __device__ constexpr uint32_t fq_p29(int i) {          // limb i of p in base 2^29
+    return (uint32_t)(((i * 29) / 64 == ((i * 29 + 28) / 64) || (i * 29 + 28) / 64 > 3
+                           ? FqParams::P[(i * 29) / 64] >> ((i * 29) % 64)
+                           : (FqParams::P[(i * 29) / 64] >> ((i * 29) % 64)) | (FqParams::P[(i * 29) / 64 + 1] << (64 - (i * 29) % 64))) & M29);
+}
+__host__ __device__ __forceinline__ u261 mont29_mul(const u261& a, const u261& b) {
+    constexpr uint32_t INV29 = FqParams::INV & M29;                 // -p^-1 mod 2^29 = the low 29 bits of -p^-1 mod 2^32
+    const uint32_t P29_0 = fq_p29(0), P29_1 = fq_p29(1), P29_2 = fq_p29(2), P29_3 = fq_p29(3), P29_4 = fq_p29(4), P29_5 = fq_p29(5), P29_6 = fq_p29(6), P29_7 = fq_p29(7), P29_8 = fq_p29(8);
+    uint32_t m[9];
+    u261 r;
+    uint64_t acc = 0;
+#include "mont29_body.inc"
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+__host__ __device__ inline u261 to29(const u256& x) {
+    u261 o;
+    for (int i = 0; i < 9; i++) {
+        const int bit = i * 29, w = bit / 32, sh = bit % 32;
+        uint64_t v = x.v[w];
+        if (w + 1 < 8) v |= (uint64_t)x.v[w + 1] << 32;
+        o.l[i] = (uint32_t)(v >> sh) & M29;
+    }
+    return o;
+}
+__host__ __device__ inline u256 from29(const u261& x) {           // value < 2^256 assumed
+    u256 o;
+    for (int i = 0; i < 8; i++) o.v[i] = 0;
+    for (int i = 0; i < 9; i++) {
+        const int bit = i * 29, w = bit / 32, sh = bit % 32;
+        const uint64_t v = (uint64_t)x.l[i] << sh;
+        o.v[w] |= (uint32_t)v;
+        if (w + 1 < 8) o.v[w + 1] |= (uint32_t)(v >> 32);
+    }
+    return o;
+}
+__global__ void k_mont29(uint32_t* out, uint32_t seed) {
+    u256 x0 = Fq::one(), y0 = Fq::R2();
+    x0.v[0] ^= threadIdx.x + seed; y0.v[1] ^= blockIdx.x;
+    u261 x = to29(Fq::reduce_once(x0)), y = to29(y0);
+    for (int i = 0; i < ITER / 4; i++) { x = mont29_mul(x, y); y = mont29_mul(y, x); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ y.l[3] ^ x.l[8];
+}
+// host self-test of the 29-bit form against the library's product: a b 2^-261 * 2^5 = a b 2^-256 (mod p)
+static int mont29_selftest() {
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    for (int t = 0; t < 2000; t++) {
+        u256 a, b;
+        for (int i = 0; i < 8; i++) { a.v[i] = (uint32_t)next(); b.v[i] = (uint32_t)next(); }
+        a.v[7] &= 0x1fffffffu; b.v[7] &= 0x1fffffffu;                    // < 2^253 < p
+        u261 r = mont29_mul(to29(a), to29(b));
+        if (r.l[8] >> 24) return 1;                                       // must stay below 2^256
+        u256 v = Fq::reduce_once(from29(r));
+        v = Fq::reduce_once(v);
+        for (int i = 0; i < 5; i++) v = Fq::add(v, v);
+        if (!Fq::eq(v, Fq::mul(a, b))) return 2;
+    }
+    return 0;
+}
 __global__ void k_fqmul_cios(uint32_t* out, uint32_t seed) {
     u256 x = Fq::one(), y = Fq::R2();
     x.v[0] ^= threadIdx.x + seed; y.v[1] ^= blockIdx.x;
     x = Fq::reduce_once(x);
-    for (int i = 0; i < ITER / 4; i++) { x = Fq::mul_cios(x, y); y = Fq::mul_cios(y, x); }
+    for (int i = 0; i < ITER / 4; i++) { x = fq_mul_cios(x, y); y = fq_mul_cios(y, x); }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x.v[0] ^ y.v[3];
 }
 __global__ void k_fqadd(uint32_t* out, uint32_t seed) {
@@ -195,7 +295,13 @@ static double run(const char* name, K kern, double ops_per_thread, int block, in
     return rate;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    {
+        const int st = mont29_selftest();
+        printf("mont29 host self-test (9 x 29-bit limbs vs Fq::mul): %s\n", st ? "FAILED" : "ok");
+        if (st) return 1;
+        if (argc > 1 && !strcmp(argv[1], "--selftest")) return 0;
+    }
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     printf("device: %s  CUs=%d  clock=%d MHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000);
     for (int bpc : {4, 8}) {
@@ -223,6 +329,7 @@ int main() {
         run("fq_mul", k_fqmul, 2.0 * (ITER / 4), 256, bpc);
         run("fq_sqr", k_fqsqr, 2.0 * (ITER / 4), 256, bpc);
         run("fq_mul_cios", k_fqmul_cios, 2.0 * (ITER / 4), 256, bpc);
+        run("fq_mul_29bit_limbs_upper_bound", k_mont29, 2.0 * (ITER / 4), 256, bpc);
         run("fq_addsub", k_fqadd, 2.0 * ITER, 256, bpc);
     }
     for (int bpc : {1, 2, 4}) run("xyzz_madd", k_madd, 1.0 * (ITER / 8), 256, bpc);

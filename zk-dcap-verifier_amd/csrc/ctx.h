@@ -34,7 +34,9 @@ struct Tune {
     int ntt_full_twiddle_max_log = 24;   // up to this size inter-pass twiddles come from full HBM tables (32 B/element/pass)
     int ntt_ws_limit_mb = 24576; // a batched transform's out-of-place workspace (columns x N x 32 B) is capped here: larger batches run in slices of columns (k >= 22)
     int ntt_quarter_input = 1;   // coeff_to_extended: skip the arithmetic of the first two stages when 3/4 of the input is the zero padding
-    int ntt_debug_mode = 0;      // measurements only (WRONG results): 1 = passes without their butterfly stages, 2 = without global loads / stores
+#ifdef ZK_NTT_PROBE
+    int ntt_debug_mode = 0;      // `make probe` only (tools/ntt_probe.py; WRONG results): 1 = passes without their butterfly stages, 2 = without global loads / stores
+#endif
     int vec_block = 256;
     int quot_threads = 128;
     int quot_rows = 1;           // rows per thread of the quotient interpreter (2: one micro-op decode serves two rows)

@@ -238,38 +238,6 @@ struct Field {
     // a*b - c*d (as a*b + c*(p - d))
     static ZK_HD u256 mul2_sub(const u256& a, const u256& b, const u256& c, const u256& d) { return mul2_add(a, b, c, neg(d)); }
 
-    // the plain-C coarsely integrated operand scanning form (kept for the microbenchmark comparison)
-    static ZK_HD u256 mul_cios(const u256& a, const u256& b) {
-        uint32_t t[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) t[i] = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint64_t c = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                uint64_t s = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
-                t[j] = (uint32_t)s;
-                c = s >> 32;
-            }
-            uint32_t t8 = t[8] + (uint32_t)c;
-            uint32_t m = t[0] * FP::INV;
-            c = ((uint64_t)m * p(0) + t[0]) >> 32;
-#pragma unroll
-            for (int j = 1; j < 8; j++) {
-                uint64_t s = (uint64_t)m * p(j) + t[j] + c;
-                t[j - 1] = (uint32_t)s;
-                c = s >> 32;
-            }
-            uint64_t s = (uint64_t)t8 + c;
-            t[7] = (uint32_t)s;
-            t[8] = (uint32_t)(s >> 32);
-        }
-        u256 o;
-#pragma unroll
-        for (int i = 0; i < 8; i++) o.v[i] = t[i];
-        return reduce_once(o);
-    }
     // a*a*R^-1 with the 28 cross products taken once (36 operand products instead of 64; the 64 reduction products stay): field_sqr_body.inc
     static ZK_HD u256 sqr(const u256& a) {
         uint64_t acc = 0;

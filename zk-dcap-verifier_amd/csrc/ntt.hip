@@ -37,7 +37,6 @@ struct NttPassArgs {
     // fused operations
     uint32_t n_valid;       // first pass only (0 = all)
     int quarter_input;      // first pass only: n_valid <= N / 4, so rows >= R/4 of every tile are zero
-    int debug_mode;         // measurements only (results are wrong): 1 = no butterfly stages (memory time of a pass), 2 = no global loads / stores (its arithmetic time)
     // first pass only: input i *= w^((cs_stride * i) mod 2^cs_log) with w's two-level power tables (coset NTT: w = extended_omega, stride = coset)
     const void* cs_lo; const void* cs_hi; uint32_t cs_lo_bits; uint32_t cs_stride; uint32_t cs_log;
     int pre_zeta;
@@ -58,10 +57,13 @@ ZK_HD u256 zeta_pow(uint32_t k) {  // ZETA^k, k in {1, 2}
     for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)((k == 1 ? z1[i >> 1] : z2[i >> 1]) >> (32 * (i & 1)));
     return o;
 }
+// PROBE is a measurement-only template parameter: the product library instantiates 0 alone; `make probe` (-DZK_NTT_PROBE, tools/ntt_probe.py) also builds 1 = a pass
+// without its butterfly stages (its memory time) and 2 = without global loads / stores (its arithmetic time) — both give WRONG results by construction.
+template <int PROBE>
 ZK_HD u256 ntt_load_input(const NttPassArgs& a, size_t idx) {
     if (a.n_valid && idx >= a.n_valid) return Fr::zero();
     u256 v;
-    if (a.debug_mode == 2) { for (int i = 0; i < 8; i++) v.v[i] = (uint32_t)idx * 0x9e3779b9u + i; v.v[7] &= 0x0fffffffu; }
+    if (PROBE == 2) { for (int i = 0; i < 8; i++) v.v[i] = (uint32_t)idx * 0x9e3779b9u + i; v.v[7] &= 0x0fffffffu; }
     else v = load_u256(a.src, idx);
     if (a.pre_zeta) {
         uint32_t m = (uint32_t)idx % 3u;
@@ -100,6 +102,16 @@ ZK_HD u256 lds_get(const uint4* lo, const uint4* hi, uint32_t idx) {
     return o;
 }
 
+// Position of (tile row, column) in the two LDS planes.  A tile row is C 16-byte slots; the column is XOR-swizzled with bits of the row so that the final pass's
+// load loop — consecutive lanes = consecutive input rows, stored BIT-REVERSED, i.e. a stride of a whole multiple of C slots — spreads over all bank groups
+// instead of hitting one (profiles/r02: 45 % of that kernel's LDS cycles were conflicts).  The bits taken are the ones that differ between the 64 rows a wave
+// writes (the top six of the reversed index).  Every other access of the tile walks the columns of a row with consecutive lanes: a permutation inside one
+// C-slot row, conflict-free with or without the swizzle.
+ZK_HD uint32_t tile_at(uint32_t row, uint32_t col, uint32_t r, uint32_t c_log) {
+    const uint32_t sh = r > 6 ? r - 6 : 0;
+    return (row << c_log) + (col ^ ((row >> sh) & ((1u << c_log) - 1u)));
+}
+
 // all log R DIT stages on the tile held in LDS (rows were stored bit-reversed).  Two stages at a time are
 // done in registers (radix-4 step: 4 loads, 4 butterflies, 4 stores) so the tile makes half as many LDS
 // round trips and barriers as a radix-2 sweep; an odd last stage is a plain radix-2 step.
@@ -115,11 +127,10 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
         const uint32_t nq = (1u << (r - 2)) << c_log;
         for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) {
             const uint32_t col = q & (C - 1), bq = q >> c_log;
-            const uint32_t i0 = (bq << 2) * C + col;
-            const u256 x0 = lds_get(lo, hi, i0);
-            lds_put(lo, hi, i0 + C, x0);
-            lds_put(lo, hi, i0 + 2 * C, x0);
-            lds_put(lo, hi, i0 + 3 * C, x0);
+            const u256 x0 = lds_get(lo, hi, tile_at(bq << 2, col, r, c_log));
+            lds_put(lo, hi, tile_at((bq << 2) + 1, col, r, c_log), x0);
+            lds_put(lo, hi, tile_at((bq << 2) + 2, col, r, c_log), x0);
+            lds_put(lo, hi, tile_at((bq << 2) + 3, col, r, c_log), x0);
         }
         __syncthreads();
         s = 2;
@@ -133,8 +144,9 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
         for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) {
             const uint32_t col = q & (C - 1), bq = q >> c_log;
             const uint32_t grp = bq >> s, pos = bq & (h - 1);
-            const uint32_t i0 = ((grp << (s + 2)) + pos) * C + col, step = h * C;
-            u256 x0 = lds_get(lo, hi, i0), x1 = lds_get(lo, hi, i0 + step), x2 = lds_get(lo, hi, i0 + 2 * step), x3 = lds_get(lo, hi, i0 + 3 * step);
+            const uint32_t rb = (grp << (s + 2)) + pos;
+            const uint32_t i0 = tile_at(rb, col, r, c_log), i1 = tile_at(rb + h, col, r, c_log), i2 = tile_at(rb + 2 * h, col, r, c_log), i3 = tile_at(rb + 3 * h, col, r, c_log);
+            u256 x0 = lds_get(lo, hi, i0), x1 = lds_get(lo, hi, i1), x2 = lds_get(lo, hi, i2), x3 = lds_get(lo, hi, i3);
             if (pos) {
                 const u256 w1 = tw_at((size_t)pos << (r - 1 - s));
                 x1 = Fr::mul_lazy(x1, w1);
@@ -150,9 +162,9 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
             t2 = pos ? Fr::mul_lazy(t2, tw_at((size_t)pos << (r - 2 - s))) : Fr::red2p(t2);
             t3 = Fr::mul_lazy(t3, tw_at((size_t)(pos + h) << (r - 2 - s)));
             lds_put(lo, hi, i0, Fr::add_lazy(t0, t2));
-            lds_put(lo, hi, i0 + step, Fr::add_lazy(t1, t3));
-            lds_put(lo, hi, i0 + 2 * step, Fr::sub_lazy(t0, t2));
-            lds_put(lo, hi, i0 + 3 * step, Fr::sub_lazy(t1, t3));
+            lds_put(lo, hi, i1, Fr::add_lazy(t1, t3));
+            lds_put(lo, hi, i2, Fr::sub_lazy(t0, t2));
+            lds_put(lo, hi, i3, Fr::sub_lazy(t1, t3));
         }
         __syncthreads();
     }
@@ -162,7 +174,8 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
         for (uint32_t q = threadIdx.x; q < nbf; q += blockDim.x) {
             const uint32_t col = q & (C - 1), bq = q >> c_log;
             const uint32_t grp = bq >> s, pos = bq & (half - 1);
-            const uint32_t i0 = ((grp << (s + 1)) + pos) * C + col, i1 = i0 + half * C;
+            const uint32_t rb = (grp << (s + 1)) + pos;
+            const uint32_t i0 = tile_at(rb, col, r, c_log), i1 = tile_at(rb + half, col, r, c_log);
             const u256 x = Fr::red2p(lds_get(lo, hi, i0));
             u256 y = lds_get(lo, hi, i1);
             y = pos ? Fr::mul_lazy(y, tw_at((size_t)pos << (r - 1 - s))) : Fr::red2p(y);
@@ -175,6 +188,7 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
 
 // non-final pass: rows are `cols` apart inside a sub-transform of size 2^blk_log; in/out share
 // the same addresses; the output row j of column m is multiplied by omega_blk^(m*j).
+template <int PROBE>
 ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
     ZK_DYN_SHARED(uint4, smem);
     if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
@@ -192,15 +206,15 @@ ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
         const uint32_t col = e & (C - 1), row = e >> a.c_log;
         const size_t idx = base + ((size_t)row << cols_log) + col;
-        lds_put(lo, hi, bitrev(row, a.r) * C + col, ntt_load_input(a, idx));
+        lds_put(lo, hi, tile_at(bitrev(row, a.r), col, a.r, a.c_log), ntt_load_input<PROBE>(a, idx));
     }
     __syncthreads();
-    if (a.debug_mode != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, twl, a.quarter_input != 0);
+    if (PROBE != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, twl, a.quarter_input != 0);
     const uint32_t sh = a.log_n - a.blk_log;
     const uint32_t lomask = (1u << a.lo_bits) - 1;
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
         const uint32_t col = e & (C - 1), row = e >> a.c_log;
-        u256 v = lds_get(lo, hi, e);
+        u256 v = lds_get(lo, hi, tile_at(row, col, a.r, a.c_log));
         const uint32_t ex = ((m0 + col) * row) << sh;  // < 2^log_n
         if (ex) {
             // (the tile holds values in [0, 4p); the product with a canonical twiddle is stored in [0, 2p), an untouched value as it is: the next pass takes [0, 4p))
@@ -213,12 +227,13 @@ ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
                 v = Fr::mul_lazy(v, tw);
             }
         }
-        if (a.debug_mode != 2 || v.v[3] == 0x12345u) store_u256(a.dst, base + ((size_t)row << cols_log) + col, v);
+        if (PROBE != 2 || v.v[3] == 0x12345u) store_u256(a.dst, base + ((size_t)row << cols_log) + col, v);
     }
 }
 
 // final pass: the sub-transform is contiguous (size R); outer index o = j1 * P + jm; the result
 // row goes to out[j1 + Q * (jm + P * row)] — the digit reversal that restores natural order.
+template <int PROBE>
 ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
     ZK_DYN_SHARED(uint4, smem);
     if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
@@ -233,15 +248,15 @@ ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
         const uint32_t row = e & (R - 1), col = e >> a.r;
         const size_t o = ((size_t)(j10 + col) << a.p_log) + jm;
-        lds_put(lo, hi, bitrev(row, a.r) * C + col, ntt_load_input(a, (o << a.r) + row));
+        lds_put(lo, hi, tile_at(bitrev(row, a.r), col, a.r, a.c_log), ntt_load_input<PROBE>(a, (o << a.r) + row));
     }
     __syncthreads();
-    if (a.debug_mode != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, twl, a.quarter_input != 0);
+    if (PROBE != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, twl, a.quarter_input != 0);
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
         const uint32_t col = e & (C - 1), row = e >> a.c_log;
         const size_t out_idx = (size_t)(j10 + col) + (((size_t)jm + ((size_t)row << a.p_log)) << a.q_log);
-        const u256 v = ntt_post(a, lds_get(lo, hi, e), out_idx);
-        if (a.debug_mode != 2 || v.v[3] == 0x12345u) store_u256(a.dst, out_idx, v);
+        const u256 v = ntt_post(a, lds_get(lo, hi, tile_at(row, col, a.r, a.c_log)), out_idx);
+        if (PROBE != 2 || v.v[3] == 0x12345u) store_u256(a.dst, out_idx, v);
     }
 }
 
@@ -371,8 +386,14 @@ void release_twiddles(zk_ctx* ctx) {
 
 int ntt_set_lds_attr() {
 #ifndef ZK_EMU
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef ZK_NTT_PROBE
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
 #endif
     return 0;
 }
@@ -453,7 +474,6 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
         a.log_n = log_n; a.blk_log = blk_log; a.r = ts->radix_log[p];
         a.stage_tw = ts->d_stage[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits; a.tw_full = last ? nullptr : ts->d_full[p];
         if (first && nf.cs_stride) { a.cs_lo = nf.cs_lo; a.cs_hi = nf.cs_hi; a.cs_lo_bits = nf.cs_lo_bits; a.cs_stride = nf.cs_stride; a.cs_log = nf.cs_log; }
-        a.debug_mode = tn.ntt_debug_mode;
         if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; a.quarter_input = tn.ntt_quarter_input && nf.n_valid && (size_t)nf.n_valid * 4 <= N && a.r >= 2; }
         if (last) { a.post_scale = nf.post_scale; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
         const uint32_t room = tl > a.r ? tl - a.r : 0;
@@ -462,7 +482,12 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             a.c_log = room < cols_log ? room : cols_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
             const size_t lds = ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
-            ZK_LAUNCH(ntt_strided_pass_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
+#ifdef ZK_NTT_PROBE
+            if (tn.ntt_debug_mode == 1) { ZK_LAUNCH(ntt_strided_pass_kernel<1>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
+            else if (tn.ntt_debug_mode == 2) { ZK_LAUNCH(ntt_strided_pass_kernel<2>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
+            else
+#endif
+            ZK_LAUNCH(ntt_strided_pass_kernel<0>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();
         } else {
             // o = j1 * Pm + jm with j1 the digit of pass 0 (Q = R_0) and jm the digit of pass 1 (if 3 passes)
@@ -471,7 +496,12 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             a.c_log = room < a.q_log ? room : a.q_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
             const size_t lds = ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
-            ZK_LAUNCH(ntt_final_pass_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
+#ifdef ZK_NTT_PROBE
+            if (tn.ntt_debug_mode == 1) { ZK_LAUNCH(ntt_final_pass_kernel<1>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
+            else if (tn.ntt_debug_mode == 2) { ZK_LAUNCH(ntt_final_pass_kernel<2>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
+            else
+#endif
+            ZK_LAUNCH(ntt_final_pass_kernel<0>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();
             if (via_tmp)
                 for (size_t i = 0; i < count; i++)

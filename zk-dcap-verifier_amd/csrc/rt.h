@@ -1,13 +1,13 @@
 // Runtime glue.  The product build (default) is plain HIP for gfx950.
 //
 // With -DZK_EMU the SAME kernel sources are compiled as host C++ and every workgroup is run on
-// the CPU, one user-level context per work-item (tests/csrc/emu_rt.h).  That build exists only so the kernels' index logic
+// the CPU, one user-level context per work-item (emu_rt.h: a header only the TEST build has on its include path — `make emu`).  That build exists only so the kernels' index logic
 // (counting sort, sub-bucket splitting, tree rounds, NTT addressing ...) can be exercised by
 // `pytest -m "not gpu"` in a container without a GPU.  It is test infrastructure: the product
 // library libzkmi355.so is never built with ZK_EMU and has no CPU path.
 #pragma once
 #ifdef ZK_EMU
-#include "../../tests/csrc/emu_rt.h"
+#include "emu_rt.h"
 #else
 #include <hip/hip_runtime.h>
 #define ZK_LAUNCH(kern, grid, block, smem, stream, ...) \

@@ -87,7 +87,7 @@ pub fn gpu() -> Option<&'static Gpu> {
         assert_eq!(std::mem::size_of::<Fr>(), 32);
         assert_eq!(std::mem::size_of::<G1Affine>(), 64);
         assert_eq!(std::mem::size_of::<G1>(), 96);
-        let one: [u64; 4] = unsafe { std::mem::transmute(Fr::one()) };
+        let one: [u64; 4] = unsafe { std::mem::transmute(Fr::from(1u64)) }; // (spelled so that ff 0.12 and ff 0.13 both compile it: this file is shared with stack B)
         assert_eq!(one, [0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f]); // R mod r
         let gen: [u64; 8] = unsafe { std::mem::transmute(G1Affine::generator()) };
         assert_eq!(&gen[..4], &[0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f]); // mont(1) in Fq

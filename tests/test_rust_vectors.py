@@ -9,6 +9,9 @@ ZKV1 format (little endian): b"ZKV1" | kind u32 | payload
   kind 4  proof  len u64 | proof bytes | 8 x u64 first draws of the seeded ChaCha20 stream
   kind 5  draws  per_fr u32 (rng calls of one Fr::random) | n_squeezes u32 | n_squeezes x (rng calls so far u64, points written u64, scalars written u64) | total calls u64
                  — the order in which create_proof consumes `&mut rng`, read off a counting RNG at every transcript squeeze: pins zk_plonk_pk_desc.draw_schedule
+  kind 6  transcript events of VERIFYING a stack-B proof (shim/p256_k18_driver): which u32 (1 = PoseidonTranscript<NativeLoader>, 2 = EvmTranscript) | proof_len u64 | proof |
+                 n_events u32 | events: tag u8 + payload — 'c' common_scalar 32 B, 'p' common_point 64 B (x, y), 'S' read_scalar 32 B, 'P' read_point 64 B, 'Q' squeeze 32 B
+                 (all canonical little endian).  Replaying the SAME proof bytes through this repo's readers must reproduce every value: pins the sponge / buffer framing.
 plus vk_cs.json — the real circuit's census (A, F, L, equality columns, degree), to replace the estimates of tools/sgx_shaped_circuit.py.
 """
 import glob
@@ -53,6 +56,23 @@ def read_zkv(path):
         off += 8
         rows = [list(struct.unpack_from("<3Q", b, off + 24 * i)) for i in range(nsq)]
         return {"kind": "draws", "per_fr": per_fr, "at_squeeze": rows, "total": struct.unpack_from("<Q", b, off + 24 * nsq)[0]}
+    if kind == 6:
+        which = struct.unpack_from("<I", b, off)[0]
+        ln = struct.unpack_from("<Q", b, off + 4)[0]
+        off += 12
+        proof = b[off:off + ln]
+        off += ln
+        n_ev = struct.unpack_from("<I", b, off)[0]
+        off += 4
+        events = []
+        for _ in range(n_ev):
+            tag = chr(b[off])
+            size = 64 if tag in "pP" else 32
+            raw = b[off + 1:off + 1 + size]
+            off += 1 + size
+            events.append((tag, int.from_bytes(raw, "little") if size == 32 else (int.from_bytes(raw[:32], "little"), int.from_bytes(raw[32:], "little"))))
+        assert off == len(b), path
+        return {"kind": "events", "which": which, "proof": proof, "events": events}
     raise ValueError(f"{path}: unknown ZKV1 kind {kind}")
 
 
@@ -132,6 +152,108 @@ def test_draw_schedule_equals_rust_create_proof():
         want1, total1 = expected_squeeze_record(census, 1)
         want0, _ = expected_squeeze_record(census, 0)
         assert got == want1 and v["total"] == total1 * v["per_fr"], (p, "matches schedule 0" if got == want0 else "matches neither schedule", got, want1)
+
+
+def replay_events(v):
+    """feed the recorded proof through the PRODUCT's reader of that transcript flavour, event by event; returns the list of mismatches (empty = framing pinned)"""
+    from zk_dcap_verifier_amd.transcript import EvmRead, PoseidonRead
+    rd = {1: PoseidonRead, 2: EvmRead}[v["which"]](v["proof"])
+    bad = []
+    for i, (tag, val) in enumerate(v["events"]):
+        if tag == "c":
+            rd.common_scalar(val)
+        elif tag == "p":
+            rd.common_point(val)
+        elif tag == "S":
+            got = rd.read_scalar()
+        elif tag == "P":
+            got = rd.read_point()
+        elif tag == "Q":
+            got = rd.squeeze_challenge()
+        if tag in "SPQ" and got != val:
+            bad.append((i, tag, got, val))
+    if rd.pos != len(v["proof"]):
+        bad.append(("unread bytes", len(v["proof"]) - rd.pos))
+    return bad
+
+
+class _Recording:
+    """wraps one of the ORACLE's readers (the second writing of each transcript) and records the event sequence in the kind-6 layout"""
+
+    def __init__(self, inner):
+        self.inner, self.events = inner, []
+
+    pos = property(lambda self: self.inner.pos)
+    proof = property(lambda self: self.inner.proof)
+
+    def squeeze(self):
+        c = self.inner.squeeze()
+        self.events.append(("Q", c))
+        return c
+
+    def common_scalar(self, s):
+        self.events.append(("c", int(s)))
+        return self.inner.common_scalar(s)
+
+    def common_point(self, pt):
+        self.events.append(("p", pt))
+        return self.inner.common_point(pt)
+
+    def read_point(self):
+        pt = self.inner.read_point()
+        self.events.append(("P", pt))
+        return pt
+
+    def read_scalar(self):
+        s = self.inner.read_scalar()
+        self.events.append(("S", s))
+        return s
+
+    def payload(self, which, proof):
+        out = [struct.pack("<IQ", which, len(proof)), proof, struct.pack("<I", len(self.events))]
+        for tag, val in self.events:
+            out.append(tag.encode() + (val.to_bytes(32, "little") if not isinstance(val, tuple) else val[0].to_bytes(32, "little") + val[1].to_bytes(32, "little")))
+        return out
+
+
+@pytest.mark.parametrize("which", [1, 2])
+def test_transcript_event_record_round_trip(emu, orc, tmp_path, which):
+    """kind 6 written HERE — events of the oracle verifier reading a p256-shaped proof of the product prover through the oracle's own Poseidon / Keccak reader —
+    loads and replays cleanly through the product's reader (two separate writings of each transcript agree event by event), and a corrupted challenge is caught"""
+    import evm_ref
+    import poseidon_ref
+    import verifier
+    import test_create_proof as tcp
+    import zk_dcap_verifier_amd as z
+    from zk_dcap_verifier_amd import plonk
+    cs, fixed, asm, advice, instances = tcp.p256_shaped_circuit(7)
+    params = z.kzg.ParamsKZG.setup(7, tcp.TAU, backend=emu)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    proof = plonk.NativeProver(params, pk, transcript={1: "poseidon", 2: "evm"}[which]).create_proof([a.copy() for a in advice], instances, np.random.default_rng(18))
+    held = {}
+
+    def reader(proof_):
+        held["rec"] = _Recording({1: poseidon_ref.Reader, 2: evm_ref.Reader}[which](proof_))
+        return held["rec"]
+    assert verifier.verify_proof(pk.vk, tcp.TAU, instances, proof, reader=reader) is True
+    write_zkv(tmp_path / "e.zkv", 6, held["rec"].payload(which, proof))
+    v = read_zkv(tmp_path / "e.zkv")
+    assert v["kind"] == "events" and v["which"] == which and v["proof"] == proof and len(v["events"]) == len(held["rec"].events) > 40
+    assert replay_events(v) == []
+    i = next(i for i, e in enumerate(v["events"]) if e[0] == "Q")
+    v["events"][i] = ("Q", (v["events"][i][1] + 1) % (1 << 200))
+    assert replay_events(v) and replay_events(v)[0][0] == i
+    pk.release()
+    params.release()
+
+
+@pytest.mark.skipif(not _vectors(6), reason="no Rust transcript-event records under tests/golden/rust (shim/p256_k18_driver)")
+def test_transcript_events_equal_rust():
+    """snark-verifier's PoseidonTranscript / EvmTranscript, as the reference's stack B runs them (crates/p256-ecdsa/src/base.rs:193-244): every value their
+    verification of a real proof absorbed, read and squeezed must come out of this repo's readers on the same bytes"""
+    for p in _vectors(6):
+        bad = replay_events(read_zkv(p))
+        assert not bad, (p, bad[:3])
 
 
 @pytest.mark.skipif(not _vectors(1), reason="no Rust MSM vectors under tests/golden/rust (shim/README.md: needs a Rust toolchain)")

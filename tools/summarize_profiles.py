@@ -19,6 +19,70 @@ def last_json_line(path):
     return json.loads([l for l in open(path) if l.startswith("{")][-1])
 
 
+# instruction issue rates measured on the box by tools/microbench (profiles/r02/run66_microbench_fma_ingredients_lazy_bound.txt), lane-ops per clock per CU
+RATE_MAD64, RATE_SIMPLE, N_CU, N_SIMD = 39.6, 114.6, 256, 1024
+
+
+def valu_section(O, P, tag, rnd):
+    """VALU side of the integer roofline from two PMC passes of ONE proof (tools/collect_profiles.sh): per kernel the share of wave cycles spent issuing VALU /
+    stalled / parked, VALUBusy (= 4 * SQ_ACTIVE_INST_VALU / SIMDs / GRBM_GUI_ACTIVE-per-XCD: the gfx94x formula, ROCm 7.2 ships none for gfx950), the effective clock
+    under load (GRBM_GUI_ACTIVE / 8 / dispatch duration, MI355X_MICROARCH.md DVFS section) and, from the instruction mix, an ISSUE model that owes nothing to this
+    repo's own loops: cycles the VALU needs = 64 * (INT64 insts / 39.6 + other VALU insts / 114.6) / CUs, over the cycles the dispatch had."""
+    vp, mp = f"{O}/valu/v_counter_collection.csv", f"{O}/mix/m_counter_collection.csv"
+    if not (os.path.exists(vp) and os.path.exists(mp)):
+        print("no VALU counter passes in", O)
+        return
+
+    def per_kernel(path):
+        d = collections.defaultdict(lambda: collections.defaultdict(float))
+        seen = set()
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            d[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            key = (r["Dispatch_Id"], k)
+            if key not in seen:
+                seen.add(key)
+                d[k]["launches"] += 1
+                d[k]["ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        return d
+    v, m = per_kernel(vp), per_kernel(mp)
+    keep = ["msm_accumulate_kernel", "ntt_strided_pass_kernel", "ntt_final_pass_kernel", "quotient_kernel", "msm_scatter_kernel", "msm_hist_kernel", "msm_merge_kernel",
+            "msm_rowcol_kernel", "lpb_scatter_kernel", "pe_lincomb_kernel", "pe_eval_partial_kernel", "gp_batch_divide_kernel"]
+    out = {}
+    with open(f"{P}/{tag}_rocprofv3_pmc_valu.csv", "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE  and, separately,\n")
+        f.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR   -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras\n")
+        f.write("# per-wave shares are of SQ_WAVE_CYCLES (quad-cycles); valu_busy = 4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); eff_clock = GRBM_GUI_ACTIVE / 8 / duration;\n")
+        f.write(f"# issue_model = 64 * (INT64 insts / {RATE_MAD64} + (VALU - INT64) insts / {RATE_SIMPLE}) / {N_CU} CUs / (GRBM_GUI_ACTIVE / 8): the share of the dispatch's cycles the VALU needs at the MEASURED issue rates\n")
+        f.write("# of v_mad_u64_u32 and simple VALU instructions (tools/microbench) — an instruction-mix bound, independent of any loop of this repo\n")
+        f.write("kernel,launches,ms_per_launch,active_valu_per_wave_cycle,wait_inst_per_wave_cycle,wait_any_per_wave_cycle,valu_busy,eff_clock_ghz,valu_insts_per_launch,int64_share,int32_share,salu_per_valu,issue_model\n")
+        for k in keep:
+            if k not in v or k not in m or not v[k]["SQ_WAVE_CYCLES"]:
+                continue
+            a, b = v[k], m[k]
+            gui = a["GRBM_GUI_ACTIVE"] / 8
+            wc = a["SQ_WAVE_CYCLES"]
+            i64, i32, iv = b["SQ_INSTS_VALU_INT64"], b["SQ_INSTS_VALU_INT32"], b["SQ_INSTS_VALU"] or 1
+            scale = a["SQ_INSTS_VALU"] / iv if iv else 1.0            # the two passes may see a different number of launches (keygen): bring the mix to the first pass's count
+            need = 64 * (i64 * scale / RATE_MAD64 + (iv - i64) * scale / RATE_SIMPLE) / N_CU
+            rec = {"launches": int(a["launches"]), "ms_per_launch": a["ns"] / a["launches"] / 1e6, "active_valu_per_wave_cycle": a["SQ_ACTIVE_INST_VALU"] / wc,
+                   "wait_inst_per_wave_cycle": a["SQ_WAIT_INST_ANY"] / wc, "wait_any_per_wave_cycle": a["SQ_WAIT_ANY"] / wc,
+                   "valu_busy": 4 * a["SQ_ACTIVE_INST_VALU"] / N_SIMD / gui if gui else None, "eff_clock_ghz": gui / a["ns"] if a["ns"] else None,
+                   "valu_insts_per_launch": a["SQ_INSTS_VALU"] / a["launches"], "int64_share": i64 / iv, "int32_share": i32 / iv, "salu_per_valu": b["SQ_INSTS_SALU"] / iv,
+                   "issue_model": need / gui if gui else None}
+            out[k] = {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in rec.items()}
+            f.write(k + "," + ",".join("" if rec[c] is None else (f"{rec[c]:.4f}" if isinstance(rec[c], float) else str(rec[c])) for c in
+                                       ("launches", "ms_per_launch", "active_valu_per_wave_cycle", "wait_inst_per_wave_cycle", "wait_any_per_wave_cycle", "valu_busy", "eff_clock_ghz",
+                                        "valu_insts_per_launch", "int64_share", "int32_share", "salu_per_valu", "issue_model")) + "\n")
+    tjp = os.path.join(os.path.dirname(P), "traffic.json")
+    tj = json.load(open(tjp)) if os.path.exists(tjp) else {}
+    tj["valu_source"] = f"profiles/{rnd}/{tag}_rocprofv3_pmc_valu.csv"
+    tj["valu"] = out
+    json.dump(tj, open(tjp, "w"), indent=1)
+    for k, r in out.items():
+        print(k, r)
+
+
 def main():
     O, tag = sys.argv[1], sys.argv[2]
     rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
@@ -108,6 +172,7 @@ def main():
                 act = v["SQ_LDS_IDX_ACTIVE"] or 1
                 f.write(f"{k},{cnt[k]},{v['SQ_INSTS_LDS']:.0f},{v['SQ_LDS_IDX_ACTIVE']:.0f},{v['SQ_LDS_BANK_CONFLICT']:.0f},{v['SQ_LDS_BANK_CONFLICT'] / act:.4f},"
                         f"{v['SQ_LDS_IDX_ACTIVE'] / (v['SQ_WAVE_CYCLES'] or 1):.4f}\n")
+    valu_section(O, P, tag, rnd)
     for name in (f"{tag}_bench_default.json", f"{tag}_bench_under_rocprofv3.json"):
         open(f"{P}/{name}", "w").write(json.dumps(last_json_line(f"{O}/{name}")) + "\n")
 

@@ -673,10 +673,11 @@ def main(argv=None):
     proofs_per_hour = world * 3600.0 * proofs_total / dt
 
     extra = {"ops_per_proof": {"msm": wl.n_msm, "intt_2^k": wl.n_intt, "ntt_2^ek": wl.n_ext + 1, "quotient_rows": wl.en},
-             "kernel_ms_per_proof": {"msm_sort": round(sort_ms / proofs_total, 3), "msm_accumulate": round(acc_ms / proofs_total, 3),
-                                     "msm_reduce": round(red_ms / proofs_total, 3), "quotient": round(q_ms / proofs_total, 3) if q_ms else None},
-             "proofs_in_flight": inflight, "ms_per_proof": round(dt / proofs_total * 1e3, 3),
-             "note_kernel_ms": "HIP-event kernel times; with several proofs in flight kernels of different streams overlap, so they no longer add up to wall time"}
+             # NOT kernel time: the span between a HIP event pair on one stream while the other proofs' streams share the GPU (a kernel waits for CUs other streams hold);
+             # kernel time per proof = extra.single_proof.kernel_ms (a proof alone on the GPU) and profiles/*_kernel_trace_per_proof_inflight1.txt
+             "event_span_ms_per_proof_pipelined": {"msm_sort": round(sort_ms / proofs_total, 3), "msm_accumulate": round(acc_ms / proofs_total, 3),
+                                                   "msm_reduce": round(red_ms / proofs_total, 3), "quotient": round(q_ms / proofs_total, 3) if q_ms else None} if inflight > 1 else None,
+             "proofs_in_flight": inflight, "ms_per_proof": round(dt / proofs_total * 1e3, 3)}
     # roofline of the dominant kernel (msm_accumulate).  Algorithmic bytes = 96 B per (scalar, base) pair
     # (SURVEY 8d); one launch covers a whole batch, so bytes/launch = 96 * n * columns-per-launch.
     msm_columns = be_stats["msm_columns"]
@@ -694,6 +695,18 @@ def main(argv=None):
         except Exception:
             traffic = None
     XYZZ_MADD_PEAK = 13.82e9   # mixed additions/s of the same code (xyzz_madd_lazy) in a register-only loop (profiles/r02/run79_microbench_lazy_madd.txt; the canonical form: 13.10e9)
+    # An integer bound that owes nothing to this repo's loops: one XYZZ mixed addition in redundant form is 8 products + 2 squarings =
+    # 8 * 128 + 2 * 100 = 1224 partial products, each one v_mad_u64_u32 + one v_addc_co_u32; at the instruction issue rates measured on the box by tools/microbench
+    # (39.6 and 114.6 lane-ops per clock per CU: profiles/r02/run66_microbench_fma_ingredients_lazy_bound.txt) a lane needs 1224 * (1 / 39.6 + 1 / 114.6) clock-CUs
+    # per addition, so 256 CUs at the 2.4 GHz nominal clock cannot issue more than 14.77 G additions/s whatever the code around the products does.
+    MAD_RATE, SIMPLE_RATE, N_CU, CLK = 39.6, 114.6, 256, 2.4e9
+    ISSUE_BOUND = N_CU * CLK / (1224 * (1 / MAD_RATE + 1 / SIMPLE_RATE))
+    valu = {}
+    try:
+        valu = json.load(open(tj)).get("valu", {}) if os.path.exists(tj) else {}
+    except Exception:
+        valu = {}
+    acc_valu = valu.get("msm_accumulate_kernel", {})
     roofline = {"kernel": "msm_accumulate_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(acc_ms / max(acc_n, 1), 4), "launches": acc_n,
@@ -701,7 +714,16 @@ def main(argv=None):
                 "note": "the kernel is integer-ALU bound (v_mad_u64_u32), not HBM bound - DESIGN.md 3.2; int_alu gives the fraction of the "
                         "measured XYZZ mixed-add peak; with several proofs in flight a launch's event time includes cycles shared with other streams' kernels, so both fractions are lower bounds",
                 "int_alu": {"achieved_Gmadd_per_s": round(msm_pairs / acc_s / 1e9, 3), "peak_Gmadd_per_s": XYZZ_MADD_PEAK / 1e9,
-                            "frac": round(msm_pairs / acc_s / XYZZ_MADD_PEAK, 4)}}
+                            "frac": round(msm_pairs / acc_s / XYZZ_MADD_PEAK, 4),
+                            "issue_bound_Gmadd_per_s": round(ISSUE_BOUND / 1e9, 3), "issue_bound_frac": round(msm_pairs / acc_s / ISSUE_BOUND, 4),
+                            "issue_bound_is": "256 CUs x 2.4 GHz / (1224 partial products x (1/39.6 + 1/114.6) clk per v_mad_u64_u32 + v_addc_co_u32 pair): instruction issue rates from tools/microbench, not from a loop of this kernel",
+                            # counters of the last profiling session (separate rocprofv3 --pmc passes, one proof alone): VALU busy share, per-wave issue / stall split,
+                            # the chip's effective clock under this kernel and the instruction-mix issue model (tools/summarize_profiles.py valu_section)
+                            "pmc": {k_: acc_valu.get(k_) for k_ in ("valu_busy", "active_valu_per_wave_cycle", "wait_inst_per_wave_cycle", "wait_any_per_wave_cycle", "eff_clock_ghz", "int64_share", "issue_model")} if acc_valu else None,
+                            "pmc_source": json.load(open(tj)).get("valu_source") if acc_valu else None},
+                # the other throughput-bound kernels, same counters (profiles/traffic.json): NTT passes and the quotient interpreter
+                "other_kernels_pmc": {k_: {c_: valu[k_].get(c_) for c_ in ("ms_per_launch", "valu_busy", "active_valu_per_wave_cycle", "wait_inst_per_wave_cycle", "eff_clock_ghz", "int64_share", "issue_model")}
+                                      for k_ in ("ntt_strided_pass_kernel", "ntt_final_pass_kernel", "quotient_kernel") if k_ in valu} or None}
 
     if args.mode == "prove":
         # The same K steps once more with the witness starting in HOST memory (what the Rust boundary hands over: create_proof receives host-owned
@@ -773,7 +795,7 @@ def main(argv=None):
         best = min(lat, key=lambda x: x[0])
         extra["single_proof"] = {"ms": round(best[0] * 1e3, 2), "phase_ms": {k_: round(v, 2) for k_, v in best[1].items()}}
         # the same proof once more with HIP-event timing on: alone on the GPU the event pairs bracket only this proof's kernels, so these
-        # (unlike kernel_ms_per_proof above) are kernel times
+        # (unlike event_span_ms_per_proof_pipelined above) are kernel times
         be.timing(True)
         wl.step()
         alone = {lab: be.timing_get(lab) for lab in ("msm_sort", "msm_accumulate", "msm_reduce", "quotient")}
@@ -914,7 +936,9 @@ def main(argv=None):
                 units = sp.my_units(n_cosets)
                 slots = -(-(n_cosets * sp.quotient_parts(n_cosets)) // world)
                 cap = max(slots * (units[0][2] if units else wl.n) * 32, 1 << 16)
-                xch = z.plonk.native.TorchExchange(world, cap, tdev, sync=be.sync)
+                # the exchange buffers must be memory the LIBRARY can address: HBM tensors on a GPU box (whatever the process group is), host tensors under the emulator
+                lib_dev = "cuda" if (torch.cuda.is_available() and os.environ.get("ZK_BENCH_PLUMBING_TEST") != "1") else "cpu"
+                xch = z.plonk.native.TorchExchange(world, cap, lib_dev, sync=be.sync, stage_through_host=(lib_dev == "cuda" and backend != "nccl"))
                 snative = z.plonk.NativeProver(sp, spk, exchange=xch)
                 phase_ms = {}
 

@@ -122,6 +122,15 @@ __host__ __device__ __forceinline__ u261 mont29_mul(const u261& a, const u261& b
     r.l[8] = (uint32_t)acc;
     return r;
 }
+__host__ __device__ __forceinline__ u261 mont29_mul_v2(const u261& a, const u261& b) {
+    constexpr uint32_t INV29 = FqParams::INV & M29;
+    const uint32_t P29_0 = fq_p29(0), P29_1 = fq_p29(1), P29_2 = fq_p29(2), P29_3 = fq_p29(3), P29_4 = fq_p29(4), P29_5 = fq_p29(5), P29_6 = fq_p29(6), P29_7 = fq_p29(7), P29_8 = fq_p29(8);
+    uint32_t m[9];
+    u261 r;
+#include "mont29_body_v2.inc"
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
 __host__ __device__ inline u261 to29(const u256& x) {
     u261 o;
     for (int i = 0; i < 9; i++) {
@@ -150,6 +159,27 @@ __global__ void k_mont29(uint32_t* out, uint32_t seed) {
     for (int i = 0; i < ITER / 4; i++) { x = mont29_mul(x, y); y = mont29_mul(y, x); }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ y.l[3] ^ x.l[8];
 }
+__global__ void k_mont29_v2(uint32_t* out, uint32_t seed) {
+    u256 x0 = Fq::one(), y0 = Fq::R2();
+    x0.v[0] ^= threadIdx.x + seed; y0.v[1] ^= blockIdx.x;
+    u261 x = to29(Fq::reduce_once(x0)), y = to29(y0);
+    for (int i = 0; i < ITER / 4; i++) { x = mont29_mul_v2(x, y); y = mont29_mul_v2(y, x); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ y.l[3] ^ x.l[8];
+}
+// two independent product chains per lane (what a kernel with two in-flight field operations gives the scheduler)
+__global__ void k_mont29_x2(uint32_t* out, uint32_t seed) {
+    u256 x0 = Fq::one(), y0 = Fq::R2();
+    x0.v[0] ^= threadIdx.x + seed; y0.v[1] ^= blockIdx.x;
+    u261 x = to29(Fq::reduce_once(x0)), y = to29(y0), z = to29(Fq::R2()), w = x;
+    for (int i = 0; i < ITER / 8; i++) { x = mont29_mul(x, y); z = mont29_mul(z, w); y = mont29_mul(y, x); w = mont29_mul(w, z); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ y.l[3] ^ x.l[8] ^ z.l[1] ^ w.l[2];
+}
+__global__ void k_fqmul_lazy_x2(uint32_t* out, uint32_t seed) {
+    u256 x = Fq::one(), y = Fq::R2(), z = Fq::R2(), w = Fq::one();
+    x.v[0] ^= threadIdx.x + seed; y.v[1] ^= blockIdx.x; w.v[2] ^= threadIdx.x;
+    for (int i = 0; i < ITER / 8; i++) { x = Fq::mul_lazy(x, y); z = Fq::mul_lazy(z, w); y = Fq::mul_lazy(y, x); w = Fq::mul_lazy(w, z); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x.v[0] ^ y.v[3] ^ z.v[1] ^ w.v[2];
+}
 // host self-test of the 29-bit form against the library's product: a b 2^-261 * 2^5 = a b 2^-256 (mod p)
 static int mont29_selftest() {
     uint64_t st = 0x9E3779B97F4A7C15ull;
@@ -159,6 +189,7 @@ static int mont29_selftest() {
         for (int i = 0; i < 8; i++) { a.v[i] = (uint32_t)next(); b.v[i] = (uint32_t)next(); }
         a.v[7] &= 0x1fffffffu; b.v[7] &= 0x1fffffffu;                    // < 2^253 < p
         u261 r = mont29_mul(to29(a), to29(b));
+        { const u261 r2 = mont29_mul_v2(to29(a), to29(b)); for (int i = 0; i < 9; i++) if (r2.l[i] != r.l[i]) return 3; }
         if (r.l[8] >> 24) return 1;                                       // must stay below 2^256
         u256 v = Fq::reduce_once(from29(r));
         v = Fq::reduce_once(v);
@@ -330,6 +361,9 @@ int main(int argc, char** argv) {
         run("fq_sqr", k_fqsqr, 2.0 * (ITER / 4), 256, bpc);
         run("fq_mul_cios", k_fqmul_cios, 2.0 * (ITER / 4), 256, bpc);
         run("fq_mul_29bit_limbs_upper_bound", k_mont29, 2.0 * (ITER / 4), 256, bpc);
+        run("fq_mul_29bit_v2_ab_columns_first", k_mont29_v2, 2.0 * (ITER / 4), 256, bpc);
+        run("fq_mul_29bit_two_chains_per_lane", k_mont29_x2, 4.0 * (ITER / 8), 256, bpc);
+        run("fq_mul_lazy_two_chains_per_lane", k_fqmul_lazy_x2, 4.0 * (ITER / 8), 256, bpc);
         run("fq_addsub", k_fqadd, 2.0 * ITER, 256, bpc);
     }
     for (int bpc : {1, 2, 4}) run("xyzz_madd", k_madd, 1.0 * (ITER / 8), 256, bpc);

@@ -102,14 +102,15 @@ ZK_HD u256 lds_get(const uint4* lo, const uint4* hi, uint32_t idx) {
     return o;
 }
 
-// Position of (tile row, column) in the two LDS planes.  A tile row is C 16-byte slots; the column is XOR-swizzled with bits of the row so that the final pass's
-// load loop — consecutive lanes = consecutive input rows, stored BIT-REVERSED, i.e. a stride of a whole multiple of C slots — spreads over all bank groups
-// instead of hitting one (profiles/r02: 45 % of that kernel's LDS cycles were conflicts).  The bits taken are the ones that differ between the 64 rows a wave
-// writes (the top six of the reversed index).  Every other access of the tile walks the columns of a row with consecutive lanes: a permutation inside one
-// C-slot row, conflict-free with or without the swizzle.
+// Position of (tile row, column) in the two LDS planes: the linear index row * C + col with its low three bits XORed by the top three bits of the row.
+// A 16-byte LDS store is serviced in groups of 8 CONSECUTIVE lanes over 32 four-byte banks (MI355X_MICROARCH.md, LDS table): the 8 lanes of a group must hit 8
+// distinct 16-byte slots modulo 128 bytes.  Every access of the tile but one walks consecutive linear indices with consecutive lanes (8 slots of one aligned
+// block: any XOR with a per-block constant permutes them, conflict-free).  The exception is the final pass's load loop: consecutive lanes = consecutive input
+// rows, stored BIT-REVERSED, so lanes 0..7 differ in the TOP three bits of the stored row and share everything below — without the swizzle all eight land on
+// one slot (profiles/r02, r03 run84: 45 % of that kernel's LDS cycles were conflicts); with it they take the eight slots of eight different blocks.
 ZK_HD uint32_t tile_at(uint32_t row, uint32_t col, uint32_t r, uint32_t c_log) {
-    const uint32_t sh = r > 6 ? r - 6 : 0;
-    return (row << c_log) + (col ^ ((row >> sh) & ((1u << c_log) - 1u)));
+    const uint32_t lin = (row << c_log) + col;
+    return r + c_log < 6 ? lin : lin ^ ((lin >> (r + c_log - 3)) & 7u);      // (bits 0..2 never feed the shift: a bijection of the tile)
 }
 
 // all log R DIT stages on the tile held in LDS (rows were stored bit-reversed).  Two stages at a time are

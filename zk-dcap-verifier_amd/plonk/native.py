@@ -26,10 +26,13 @@ class TorchExchange:
     emulator's device memory is host memory): two byte tensors the library uses as its exchange buffers (zk_plonk_pk_desc.xchg_send / xchg_recv), so that
     the all-gather runs between HBM buffers with no host hop; `all_gather(send_ptr, recv_ptr, nbytes)` is what zk_allgather_fn calls."""
 
-    def __init__(self, world: int, cap_bytes: int, device: str = "cpu", sync=None):
+    def __init__(self, world: int, cap_bytes: int, device: str = "cpu", sync=None, stage_through_host: bool = False):
+        """device: where the LIBRARY's device memory lives as torch sees it — "cuda" on a GPU box, "cpu" under the kernel emulator (its device memory is host
+        memory).  stage_through_host: the process group cannot move device tensors (gloo with the library on a real GPU — a single-GPU dry run of the N > 1
+        path): the collective then runs on host copies, the buffers the library reads and writes stay device memory."""
         import torch
         import torch.distributed as dist
-        self.torch, self.dist, self.world, self.cap, self.device, self.sync = torch, dist, world, int(cap_bytes), device, sync
+        self.torch, self.dist, self.world, self.cap, self.device, self.sync, self.staged = torch, dist, world, int(cap_bytes), device, sync, stage_through_host
         self.send = torch.zeros(self.cap, dtype=torch.uint8, device=device)
         self.recv = torch.zeros(self.cap * world, dtype=torch.uint8, device=device)
         if device != "cpu":
@@ -40,7 +43,13 @@ class TorchExchange:
         assert send_ptr == self.send.data_ptr() and recv_ptr == self.recv.data_ptr() and nbytes <= self.cap, "the library must use the exchange buffers it was given"
         if self.sync is not None:
             self.sync()                                             # the library's stream wrote `send` (it has synchronised already; belt and braces)
-        self.dist.all_gather_into_tensor(self.recv[: self.world * nbytes], self.send[:nbytes])
+        if self.staged:
+            mine = self.send[:nbytes].cpu()
+            out = self.torch.empty(self.world * nbytes, dtype=self.torch.uint8)
+            self.dist.all_gather_into_tensor(out, mine)
+            self.recv[: self.world * nbytes].copy_(out)
+        else:
+            self.dist.all_gather_into_tensor(self.recv[: self.world * nbytes], self.send[:nbytes])
         if self.device != "cpu":
             self.torch.cuda.synchronize()                           # ... and will read `recv` right after the callback returns
         self.calls += 1

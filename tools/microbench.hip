@@ -101,86 +101,35 @@ __host__ __device__ __forceinline__ u256 fq_mul_cios(const u256& a, const u256& 
     return Fq::reduce_once(o);
 }
 
-// ---- round 3 experiment: carry-free limbs.  9 limbs of 29 bits (261 >= 254 + headroom), Montgomery radix 2^261, product scanning with ONE 64-bit
-// accumulator per column: a partial product is < 2^58, a column sums at most 9 a_i b_j + 9 m_i p_j < 18 * 2^58 < 2^63, so `v_mad_u64_u32` accumulates with no
-// carry-out and no `v_addc_co_u32` at all: 81 + 81 mads + 9 mul_lo + 17 64-bit shifts + 17 masks, against 128 mads + 128 addc + 8 mul_lo of the 8 x 32-bit form.
-// Result < 2p for inputs < 2p (no final subtraction here: this measures the UPPER bound of the form; limb conversion at load / store is not counted either).
-struct u261 { uint32_t l[9]; };
-constexpr uint32_t M29 = (1u << 29) - 1;
-__host__ __device__ constexpr uint32_t fq_p29(int i) {          // limb i of p in base 2^29
-    return (uint32_t)(((i * 29) / 64 == ((i * 29 + 28) / 64) || (i * 29 + 28) / 64 > 3
-                           ? FqParams::P[(i * 29) / 64] >> ((i * 29) % 64)
-                           : (FqParams::P[(i * 29) / 64] >> ((i * 29) % 64)) | (FqParams::P[(i * 29) / 64 + 1] << (64 - (i * 29) % 64))) & M29);
-}
-__host__ __device__ __forceinline__ u261 mont29_mul(const u261& a, const u261& b) {
-    constexpr uint32_t INV29 = FqParams::INV & M29;                 // -p^-1 mod 2^29 = the low 29 bits of -p^-1 mod 2^32
-    const uint32_t P29_0 = fq_p29(0), P29_1 = fq_p29(1), P29_2 = fq_p29(2), P29_3 = fq_p29(3), P29_4 = fq_p29(4), P29_5 = fq_p29(5), P29_6 = fq_p29(6), P29_7 = fq_p29(7), P29_8 = fq_p29(8);
-    uint32_t m[9];
-    u261 r;
-    uint64_t acc = 0;
-#include "mont29_body.inc"
-    r.l[8] = (uint32_t)acc;
-    return r;
-}
-__host__ __device__ __forceinline__ u261 mont29_mul_v2(const u261& a, const u261& b) {
-    constexpr uint32_t INV29 = FqParams::INV & M29;
-    const uint32_t P29_0 = fq_p29(0), P29_1 = fq_p29(1), P29_2 = fq_p29(2), P29_3 = fq_p29(3), P29_4 = fq_p29(4), P29_5 = fq_p29(5), P29_6 = fq_p29(6), P29_7 = fq_p29(7), P29_8 = fq_p29(8);
-    uint32_t m[9];
-    u261 r;
-#include "mont29_body_v2.inc"
-    r.l[8] = (uint32_t)acc;
-    return r;
-}
-__host__ __device__ inline u261 to29(const u256& x) {
-    u261 o;
-    for (int i = 0; i < 9; i++) {
-        const int bit = i * 29, w = bit / 32, sh = bit % 32;
-        uint64_t v = x.v[w];
-        if (w + 1 < 8) v |= (uint64_t)x.v[w + 1] << 32;
-        o.l[i] = (uint32_t)(v >> sh) & M29;
-    }
-    return o;
-}
-__host__ __device__ inline u256 from29(const u261& x) {           // value < 2^256 assumed
-    u256 o;
-    for (int i = 0; i < 8; i++) o.v[i] = 0;
-    for (int i = 0; i < 9; i++) {
-        const int bit = i * 29, w = bit / 32, sh = bit % 32;
-        const uint64_t v = (uint64_t)x.l[i] << sh;
-        o.v[w] |= (uint32_t)v;
-        if (w + 1 < 8) o.v[w + 1] |= (uint32_t)(v >> 32);
-    }
-    return o;
-}
+// ---- round 3 experiment: carry-free limbs.  9 limbs of 29 bits, Montgomery radix 2^261, product scanning with ONE 64-bit accumulator per column:
+// `v_mad_u64_u32` accumulates with no carry-out and no `v_addc_co_u32`: 81 + 81 mads + 9 mul_lo + 16 64-bit shifts + 17 masks, against 128 mads + 128 addc + 8 mul_lo of
+// the 8 x 32-bit form.  GO (profiles/r03/run84, run85: 179 vs 142 G products/s): the arithmetic now lives in csrc/field29.cuh (generated by tools/gen_mac29.py) and
+// these kernels time the library's own functions.  (run85 also timed a variant with the 17 a*b column sums as independent chains first: slower, 159 G/s.)
 __global__ void k_mont29(uint32_t* out, uint32_t seed) {
     u256 x0 = Fq::one(), y0 = Fq::R2();
     x0.v[0] ^= threadIdx.x + seed; y0.v[1] ^= blockIdx.x;
-    u261 x = to29(Fq::reduce_once(x0)), y = to29(y0);
-    for (int i = 0; i < ITER / 4; i++) { x = mont29_mul(x, y); y = mont29_mul(y, x); }
+    u261 x = Fq29::from32<0>(Fq::reduce_once(x0)), y = Fq29::from32<0>(y0);
+    for (int i = 0; i < ITER / 4; i++) { x = Fq29::mul(x, y); y = Fq29::mul(y, x); }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ y.l[3] ^ x.l[8];
 }
-__global__ void k_mont29_v2(uint32_t* out, uint32_t seed) {
+__global__ void k_sqr29(uint32_t* out, uint32_t seed) {
     u256 x0 = Fq::one(), y0 = Fq::R2();
     x0.v[0] ^= threadIdx.x + seed; y0.v[1] ^= blockIdx.x;
-    u261 x = to29(Fq::reduce_once(x0)), y = to29(y0);
-    for (int i = 0; i < ITER / 4; i++) { x = mont29_mul_v2(x, y); y = mont29_mul_v2(y, x); }
+    u261 x = Fq29::from32<0>(Fq::reduce_once(x0)), y = Fq29::from32<0>(y0);
+    for (int i = 0; i < ITER / 4; i++) { x = Fq29::sqr(x); y = Fq29::sqr(y); }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ y.l[3] ^ x.l[8];
 }
-// two independent product chains per lane (what a kernel with two in-flight field operations gives the scheduler)
-__global__ void k_mont29_x2(uint32_t* out, uint32_t seed) {
-    u256 x0 = Fq::one(), y0 = Fq::R2();
-    x0.v[0] ^= threadIdx.x + seed; y0.v[1] ^= blockIdx.x;
-    u261 x = to29(Fq::reduce_once(x0)), y = to29(y0), z = to29(Fq::R2()), w = x;
-    for (int i = 0; i < ITER / 8; i++) { x = mont29_mul(x, y); z = mont29_mul(z, w); y = mont29_mul(y, x); w = mont29_mul(w, z); }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ y.l[3] ^ x.l[8] ^ z.l[1] ^ w.l[2];
+__global__ void k_madd29(uint32_t* out, uint32_t seed) {
+    Affine g;
+    const uint64_t one[4] = BN254_FQ_R;
+    for (int i = 0; i < 8; i++) { g.x.v[i] = (uint32_t)(one[i >> 1] >> (32 * (i & 1))); }
+    g.y = Fq::dbl(g.x);
+    XYZZ29 acc = xyzz29_enter(xyzz_mdbl(g.x, g.y));
+    acc.x.l[0] ^= (threadIdx.x + seed) & 0xff;                           // (not a curve point any more: the formulas do not care, the timing is the same)
+    for (int i = 0; i < ITER / 8; i++) xyzz29_madd(acc, g.x, g.y);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x.l[0] ^ acc.zz.l[3];
 }
-__global__ void k_fqmul_lazy_x2(uint32_t* out, uint32_t seed) {
-    u256 x = Fq::one(), y = Fq::R2(), z = Fq::R2(), w = Fq::one();
-    x.v[0] ^= threadIdx.x + seed; y.v[1] ^= blockIdx.x; w.v[2] ^= threadIdx.x;
-    for (int i = 0; i < ITER / 8; i++) { x = Fq::mul_lazy(x, y); z = Fq::mul_lazy(z, w); y = Fq::mul_lazy(y, x); w = Fq::mul_lazy(w, z); }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = x.v[0] ^ y.v[3] ^ z.v[1] ^ w.v[2];
-}
-// host self-test of the 29-bit form against the library's product: a b 2^-261 * 2^5 = a b 2^-256 (mod p)
+// host self-test of the 29-bit form against the library's product: enter / leave round trip and a * b through both forms
 static int mont29_selftest() {
     uint64_t st = 0x9E3779B97F4A7C15ull;
     auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
@@ -188,13 +137,10 @@ static int mont29_selftest() {
         u256 a, b;
         for (int i = 0; i < 8; i++) { a.v[i] = (uint32_t)next(); b.v[i] = (uint32_t)next(); }
         a.v[7] &= 0x1fffffffu; b.v[7] &= 0x1fffffffu;                    // < 2^253 < p
-        u261 r = mont29_mul(to29(a), to29(b));
-        { const u261 r2 = mont29_mul_v2(to29(a), to29(b)); for (int i = 0; i < 9; i++) if (r2.l[i] != r.l[i]) return 3; }
-        if (r.l[8] >> 24) return 1;                                       // must stay below 2^256
-        u256 v = Fq::reduce_once(from29(r));
-        v = Fq::reduce_once(v);
-        for (int i = 0; i < 5; i++) v = Fq::add(v, v);
-        if (!Fq::eq(v, Fq::mul(a, b))) return 2;
+        if (!Fq::eq(Fq29::leave(Fq29::enter(a)), a)) return 1;
+        if (!Fq::eq(Fq29::leave(Fq29::mul(Fq29::enter(a), Fq29::enter(b))), Fq::mul(a, b))) return 2;
+        if (!Fq::eq(Fq29::leave(Fq29::sqr(Fq29::enter(a))), Fq::sqr(a))) return 3;
+        if (!Fq::eq(Fq29::leave(Fq29::mul(Fq29::from32<5>(a), Fq29::enter(b))), Fq::mul(a, b))) return 4;
     }
     return 0;
 }
@@ -360,13 +306,12 @@ int main(int argc, char** argv) {
         run("fq_mul", k_fqmul, 2.0 * (ITER / 4), 256, bpc);
         run("fq_sqr", k_fqsqr, 2.0 * (ITER / 4), 256, bpc);
         run("fq_mul_cios", k_fqmul_cios, 2.0 * (ITER / 4), 256, bpc);
-        run("fq_mul_29bit_limbs_upper_bound", k_mont29, 2.0 * (ITER / 4), 256, bpc);
-        run("fq_mul_29bit_v2_ab_columns_first", k_mont29_v2, 2.0 * (ITER / 4), 256, bpc);
-        run("fq_mul_29bit_two_chains_per_lane", k_mont29_x2, 4.0 * (ITER / 8), 256, bpc);
-        run("fq_mul_lazy_two_chains_per_lane", k_fqmul_lazy_x2, 4.0 * (ITER / 8), 256, bpc);
+        run("fq29_mul (9 x 29-bit limbs)", k_mont29, 2.0 * (ITER / 4), 256, bpc);
+        run("fq29_sqr", k_sqr29, 2.0 * (ITER / 4), 256, bpc);
         run("fq_addsub", k_fqadd, 2.0 * ITER, 256, bpc);
     }
     for (int bpc : {1, 2, 4}) run("xyzz_madd", k_madd, 1.0 * (ITER / 8), 256, bpc);
     for (int bpc : {1, 2, 4}) run("xyzz_madd_lazy", k_madd_lazy, 1.0 * (ITER / 8), 256, bpc);
+    for (int bpc : {1, 2, 4}) run("xyzz29_madd (29-bit limbs)", k_madd29, 1.0 * (ITER / 8), 256, bpc);
     return 0;
 }

@@ -530,7 +530,9 @@ ZK_KERNEL void msm_scan_apply_kernel(MsmPlan p) {
 // ------------------------------------------------------------------------------------------------
 // bucket accumulation: one thread per sub-bucket (<= L references), XYZZ mixed additions
 // ------------------------------------------------------------------------------------------------
-ZK_KERNEL void msm_accumulate_kernel(MsmPlan p) {
+// LIMB29 = 1: the chain runs on carry-free 29-bit limbs (ec.cuh xyzz29_madd, field29.cuh) — the same group elements, fewer VALU instructions per product
+template <int LIMB29, int WPE>
+ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(WPE) msm_accumulate_kernel(MsmPlan p) {
     const uint32_t col = blockIdx.y, B = p.B;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t* sm = plan_small(p, col);
@@ -551,10 +553,44 @@ ZK_KERNEL void msm_accumulate_kernel(MsmPlan p) {
     const uint32_t bend = off[b + 1];
     const uint32_t end = q + p.L < bend ? q + p.L : bend;
     const uint32_t out = plan_suboff(p, col, 0)[b] + k;   // bucket-major slot of this partial sum, as the merge levels expect it
-    XYZZ acc = xyzz_identity();
     uint32_t ref = sorted[q];
     const void* table = p.col_tables ? p.col_tables[col] : p.table;
     Affine pt = load_affine(table, ref & 0x7fffffffu);
+    XYZZ acc = xyzz_identity();
+    if (LIMB29) {
+        // the chain on carry-free limbs: the first point enters the 2^261 form, every further point is one xyzz29_madd_fast; the (rare) step that form does not cover —
+        // an identity base, a doubling, a cancellation — ends the fast loop and the 32-bit loop below finishes the chain from there
+        XYZZ29 a29 = xyzz29_identity();
+        bool fast = !affine_is_identity(pt);
+        if (fast) {
+            a29.x = Fq29::enter(pt.x);
+            a29.y = Fq29::enter((ref >> 31) ? Fq::neg(pt.y) : pt.y);
+            a29.zz = Fq29::one(); a29.zzz = Fq29::one();
+            a29.ident = false;
+            ++q;
+            if (q < end) { ref = sorted[q]; pt = load_affine(table, ref & 0x7fffffffu); }
+        }
+        while (fast && q < end) {
+            const uint32_t cur_ref = ref;
+            const Affine cur = pt;
+            const bool more = q + 1 < end;
+            if (more) ref = sorted[q + 1];
+            bool fetched = false;
+            fast = !affine_is_identity(cur) && xyzz29_madd_fast(a29, cur.x, (cur_ref >> 31) ? Fq::neg(cur.y) : cur.y, [&]() {
+                // the next point's 64-byte gather goes out here — late in the step, where few values are live (the kernel fits 128 VGPRs without spills), and
+                // still three products (about a third of the step) ahead of its first use
+                if (more) pt = load_affine(table, ref & 0x7fffffffu);
+                fetched = true;
+            });
+            if (fast) ++q;
+            else { ref = cur_ref; if (fetched) pt = cur; }            // this point again, in the complete form
+        }
+        acc = xyzz29_leave(a29);                                       // canonical coordinates of the library's form: the merge levels are unchanged
+        if (q >= end) {
+            store_xyzz(p.sub[0], (size_t)col * p.sub_stride[0] + out, acc);
+            return;
+        }
+    }
     while (true) {
         const uint32_t cur_ref = ref;
         const Affine cur = pt;
@@ -1057,7 +1093,14 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
 
     const int blk = tn.msm_block;
     EvTimer t_acc(ctx, "msm_accumulate");
-    ZK_LAUNCH(msm_accumulate_kernel, dim3((uint32_t)((cap[0] + blk - 1) / blk), nb), blk, 0, st, p);
+    if (blk > 256) return ctx->fail(ZK_ERR_ARG, "msm_block: at most 256 threads per workgroup");
+    {
+        const dim3 grid((uint32_t)((cap[0] + blk - 1) / blk), nb);
+        if (!tn.msm_limb29) { ZK_LAUNCH((msm_accumulate_kernel<0, 4>), grid, blk, 0, st, p); }
+        else if (tn.msm_acc_waves == 3) { ZK_LAUNCH((msm_accumulate_kernel<1, 3>), grid, blk, 0, st, p); }
+        else if (tn.msm_acc_waves == 2) { ZK_LAUNCH((msm_accumulate_kernel<1, 2>), grid, blk, 0, st, p); }
+        else { ZK_LAUNCH((msm_accumulate_kernel<1, 4>), grid, blk, 0, st, p); }
+    }
     ZK_CHECK_LAUNCH();
     t_acc.stop();
 

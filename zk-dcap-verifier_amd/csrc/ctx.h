@@ -35,6 +35,8 @@ struct Tune {
     int ntt_max_radix_log = 8;
     int ntt_full_twiddle_max_log = 24;   // up to this size inter-pass twiddles come from full HBM tables (32 B/element/pass)
     int ntt_ws_limit_mb = 24576; // a batched transform's out-of-place workspace (columns x N x 32 B) is capped here: larger batches run in slices of columns (k >= 22)
+    int ntt_limb29 = 1;          // NTT passes on carry-free 29-bit limbs (field29.cuh): 1 = the strided passes (-5 % there; the final pass measured +3 % and stays 32-bit), 2 = every pass, 0 = none
+    int ntt_waves = 4;           // waves per SIMD the 29-bit passes are compiled for (2: 256 VGPRs, 3: 168, 4: 128 with spills)
     int ntt_quarter_input = 1;   // coeff_to_extended: skip the arithmetic of the first two stages when 3/4 of the input is the zero padding
 #ifdef ZK_NTT_PROBE
     int ntt_debug_mode = 0;      // `make probe` only (tools/ntt_probe.py; WRONG results): 1 = passes without their butterfly stages, 2 = without global loads / stores
@@ -89,6 +91,7 @@ struct TwiddleSet {           // per (omega, log_n)
     void* d_full[3] = {nullptr, nullptr, nullptr};   // per non-final pass: inter-pass twiddles in store order
     uint32_t radix_log[3] = {0, 0, 0};
     int passes = 0;
+    int r261 = 0;             // a 29-bit-limb plan (tune ntt_limb29; 1 = strided passes, 2 = all): the tables of those passes hold w * 2^261 mod p instead of w * 2^256
 };
 
 struct QuotProgram;  // quotient.hip

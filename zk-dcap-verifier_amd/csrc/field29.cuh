@@ -155,6 +155,37 @@ struct Field29 {
         return o;
     }
 
+    // a (N-form, below 32 p) -> the same residue below 3 p, N-form: one quotient estimate from the top limb (q = floor(top * floor(2^285 / p) / 2^53) is the true
+    // quotient or up to 2 below it) and one limb-wise a - q p with signed carries.  A third of a product's cost: what ends a chain that grew by additions only.
+    static constexpr uint32_t mu285() {                               // floor(2^285 / p): 2^285 = 2^29 * 2^256, long division of (1 << 285) by p in 64-bit words
+        // p = P[3..0]; the quotient is below 2^32 (p > 2^253).  Binary long division over 286 bits.
+        uint64_t r[5] = {0, 0, 0, 0, 0};
+        uint32_t q = 0;
+        for (int bit = 285; bit >= 0; bit--) {
+            for (int i = 4; i > 0; i--) r[i] = (r[i] << 1) | (r[i - 1] >> 63);          // r = 2 r + bit of the dividend
+            r[0] = (r[0] << 1) | (bit == 285 ? 1u : 0u);
+            bool ge = r[4] != 0;
+            if (!ge) { ge = true; for (int i = 3; i >= 0; i--) if (r[i] != FP::P[i]) { ge = r[i] > FP::P[i]; break; } }
+            q = (bit < 32) ? (q << 1) | (ge ? 1u : 0u) : q;             // (quotient bits above 31 are zero)
+            if (ge) { uint64_t bo = 0; for (int i = 0; i < 4; i++) { const uint64_t pi = FP::P[i], d = r[i] - pi - bo; bo = (r[i] < pi || (r[i] == pi && bo)) ? 1 : 0; r[i] = d; } r[4] -= bo; }
+        }
+        return q;
+    }
+    static ZK_HD u261 reduce_small(const u261& a) {
+        constexpr uint32_t MU = mu285();
+        const uint32_t q = (uint32_t)(((uint64_t)a.l[8] * MU) >> 53);
+        u261 o;
+        int64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int64_t t = (int64_t)a.l[i] - (int64_t)((uint64_t)q * p29(i)) + c;
+            o.l[i] = (uint32_t)t & M29;
+            c = t >> 29;
+        }
+        o.l[8] = (uint32_t)((int64_t)a.l[8] - (int64_t)((uint64_t)q * p29(8)) + c);
+        return o;
+    }
+
     // ---- between the two Montgomery forms ------------------------------------------------------------------------------------------------------------------------
     static constexpr uint64_t pow2_mod_p_words(int e, int w) {          // word w of 2^e mod p (e >= 256), by doubling from R = 2^256 mod p
         uint64_t x[4] = {FP::R[0], FP::R[1], FP::R[2], FP::R[3]};

@@ -43,6 +43,8 @@ struct NttPassArgs {
     int post_scale;
     int post_zeta_inv;
     u256 scale;
+    // the passes on 29-bit limbs (ntt_*_pass29_kernel): constants of the fused operations as x * 2^261 mod p, canonical
+    u256 scale29, zeta29[2];
 };
 
 ZK_HD uint32_t bitrev(uint32_t x, uint32_t bits) {
@@ -184,6 +186,208 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
             lds_put(lo, hi, i1, Fr::sub_lazy(x, y));
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same passes on carry-free limbs (field29.cuh: 9 x 29 bits, Montgomery radix 2^261).  Data in HBM keeps the library's form (x * 2^256 in eight 32-bit words):
+// a twiddle enters a product as w * 2^261 (the stage tables and the full inter-pass tables of a 29-bit plan are generated that way; the two-level power tables
+// and the fused constants go through the limb conversion's shift by 5 or arrive as x * 2^261 in the arguments), so value * twiddle * 2^-261 stays in the library's
+// form with no correction.  The tile holds 36 bytes per element (two 16-byte planes + one 4-byte plane, same swizzled index).
+// Bounds, in multiples of p (a product returns below a b / 151 + 1, limbs 0..7 below 2^29):  tile values are N-form (limbs below 2^29 + 8) and below V.
+//   first step when it starts at stage 0 (every twiddle but one is 1: plain sums, V = 2 in):  t0, t2 = sums < 4;  t1 = x0 - x1 + 3p < 5;  t3 = (x2 - x3 + 3p) w < 1.04;
+//       out0 < 8, out1 < 6.1, out2 = t0 - t2 + 5p < 9, out3 = t1 - t3 + 3p < 8                                                            -> V = 9
+//   every other radix-4 step multiplies on ALL lanes (a wave mixes twiddle indices, so a "trivial twiddle" branch would run both sides anyway; index 0 of a
+//       table is 2^261 mod p):  x1', x3' < V/151 + 1 < 2;  t0, t2 < V + 2;  t1, t3 < V + 3;  t2', t3' < 2;  outputs < V + 6;  the odd last stage: V + 3
+//   so a pass of radix 2^7 ends below 24 p, of 2^8 below 27 p; the inter-pass twiddle product (or the final store's reduction) brings that below 2 p again.
+//   Limbs: a biased difference has limbs below 2^31 + 8 — fine against a product's or a table's exact limbs — and every output of a step is below 2^32 before
+//   its one carry round.
+// ------------------------------------------------------------------------------------------------
+struct Tile29 {
+    uint4* lo; uint4* hi; uint32_t* top;
+};
+ZK_HD void lds_put29(const Tile29& t, uint32_t idx, const u261& v) {
+    t.lo[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    t.hi[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    t.top[idx] = v.l[8];
+}
+ZK_HD u261 lds_get29(const Tile29& t, uint32_t idx) {
+    const uint4 l = t.lo[idx], h = t.hi[idx];
+    u261 o;
+    o.l[0] = l.x; o.l[1] = l.y; o.l[2] = l.z; o.l[3] = l.w;
+    o.l[4] = h.x; o.l[5] = h.y; o.l[6] = h.z; o.l[7] = h.w;
+    o.l[8] = t.top[idx];
+    return o;
+}
+__device__ __forceinline__ void ntt_tile_stages29(const Tile29& t, uint32_t r, uint32_t c_log, const Tile29& tw, bool quarter_input) {
+    const uint32_t C = 1u << c_log;
+    uint32_t s = 0;
+    if (quarter_input && r >= 2) {
+        const uint32_t nq = (1u << (r - 2)) << c_log;
+        for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) {
+            const uint32_t col = q & (C - 1), bq = q >> c_log;
+            const u261 x0 = lds_get29(t, tile_at(bq << 2, col, r, c_log));
+            lds_put29(t, tile_at((bq << 2) + 1, col, r, c_log), x0);
+            lds_put29(t, tile_at((bq << 2) + 2, col, r, c_log), x0);
+            lds_put29(t, tile_at((bq << 2) + 3, col, r, c_log), x0);
+        }
+        __syncthreads();
+        s = 2;
+    }
+    for (; s + 1 < r; s += 2) {
+        const uint32_t h = 1u << s;
+        const uint32_t nq = (1u << (r - 2)) << c_log;  // quads per step in the tile
+        for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) {
+            const uint32_t col = q & (C - 1), bq = q >> c_log;
+            const uint32_t grp = bq >> s, pos = bq & (h - 1);
+            const uint32_t rb = (grp << (s + 2)) + pos;
+            const uint32_t i0 = tile_at(rb, col, r, c_log), i1 = tile_at(rb + h, col, r, c_log), i2 = tile_at(rb + 2 * h, col, r, c_log), i3 = tile_at(rb + 3 * h, col, r, c_log);
+            u261 x0 = lds_get29(t, i0), x1 = lds_get29(t, i1), x2 = lds_get29(t, i2), x3 = lds_get29(t, i3);
+            u261 o0, o1, o2, o3;
+            if (s == 0) {                                   // (uniform: the first step of a pass that starts at stage 0) every twiddle but the last is 1
+                const u261 t0 = Fr29::add(x0, x1), t1 = Fr29::sub_bias<3, 30>(x0, x1), t2 = Fr29::add(x2, x3);
+                const u261 t3 = Fr29::mul(Fr29::sub_bias<3, 30>(x2, x3), lds_get29(tw, (size_t)1 << (r - 2)));
+                o0 = Fr29::add(t0, t2); o1 = Fr29::add(t1, t3);
+                o2 = Fr29::sub_bias<5, 30>(t0, t2); o3 = Fr29::sub_bias<3, 30>(t1, t3);
+            } else {
+                const u261 w1 = lds_get29(tw, (size_t)pos << (r - 1 - s));
+                x1 = Fr29::mul(x1, w1);
+                x3 = Fr29::mul(x3, w1);
+                const u261 t0 = Fr29::add(x0, x1), t1 = Fr29::sub_bias<3, 30>(x0, x1);
+                const u261 t2 = Fr29::mul(Fr29::add(x2, x3), lds_get29(tw, (size_t)pos << (r - 2 - s)));
+                const u261 t3 = Fr29::mul(Fr29::sub_bias<3, 30>(x2, x3), lds_get29(tw, (size_t)(pos + h) << (r - 2 - s)));
+                o0 = Fr29::add(t0, t2); o1 = Fr29::add(t1, t3);
+                o2 = Fr29::sub_bias<3, 30>(t0, t2); o3 = Fr29::sub_bias<3, 30>(t1, t3);
+            }
+            lds_put29(t, i0, Fr29::carry(o0));
+            lds_put29(t, i1, Fr29::carry(o1));
+            lds_put29(t, i2, Fr29::carry(o2));
+            lds_put29(t, i3, Fr29::carry(o3));
+        }
+        __syncthreads();
+    }
+    if (s < r) {
+        const uint32_t half = 1u << s;
+        const uint32_t nbf = (1u << (r - 1)) << c_log;  // butterflies of the stage in the tile
+        for (uint32_t q = threadIdx.x; q < nbf; q += blockDim.x) {
+            const uint32_t col = q & (C - 1), bq = q >> c_log;
+            const uint32_t grp = bq >> s, pos = bq & (half - 1);
+            const uint32_t rb = (grp << (s + 1)) + pos;
+            const uint32_t i0 = tile_at(rb, col, r, c_log), i1 = tile_at(rb + half, col, r, c_log);
+            const u261 x = lds_get29(t, i0);
+            u261 y = lds_get29(t, i1);
+            if (s == 0) {                                   // r = 1: the single stage of the pass, twiddle 1
+                lds_put29(t, i0, Fr29::carry(Fr29::add(x, y)));
+                lds_put29(t, i1, Fr29::carry(Fr29::sub_bias<3, 30>(x, y)));
+            } else {
+                y = Fr29::mul(y, lds_get29(tw, (size_t)pos << (r - 1 - s)));
+                lds_put29(t, i0, Fr29::carry(Fr29::add(x, y)));
+                lds_put29(t, i1, Fr29::carry(Fr29::sub_bias<3, 30>(x, y)));
+            }
+        }
+        __syncthreads();
+    }
+}
+// first load of a transform (fused pre-operations) or a later pass's reload: the library's form in, N-form limbs below 2 p out
+ZK_HD u261 ntt_load_input29(const NttPassArgs& a, size_t idx) {
+    if (a.n_valid && idx >= a.n_valid) return Fr29::zero();
+    u261 v = Fr29::from32<0>(load_u256(a.src, idx));
+    if (a.pre_zeta) {
+        const uint32_t m = (uint32_t)idx % 3u;
+        if (m) v = Fr29::mul(v, Fr29::from32<0>(m == 1 ? a.zeta29[0] : a.zeta29[1]));    // (no runtime index into the argument block: that would send it to scratch)
+    }
+    if (a.cs_stride) {
+        const uint32_t e = (a.cs_stride * (uint32_t)idx) & ((1u << a.cs_log) - 1u);
+        if (e) {
+            u261 w = Fr29::from32<5>(load_u256(a.cs_lo, e & ((1u << a.cs_lo_bits) - 1u)));      // w * 2^261, below 32 p
+            const uint32_t h = e >> a.cs_lo_bits;
+            if (h) w = Fr29::mul(w, Fr29::from32<5>(load_u256(a.cs_hi, h)));                      // below 8 p
+            v = Fr29::mul(v, w);
+        }
+    }
+    return v;
+}
+// last store of a transform: the tile value (below 32 p) leaves canonical — through the product of a fused scaling, or the quotient-estimate reduction
+ZK_HD u256 ntt_post29(const NttPassArgs& a, u261 v, size_t out_idx) {
+    bool below2p = false;
+    if (a.post_scale) { v = Fr29::mul(v, Fr29::from32<0>(a.scale29)); below2p = true; }
+    if (a.post_zeta_inv) {
+        const uint32_t m = (uint32_t)out_idx % 3u;
+        if (m) { v = Fr29::mul(v, Fr29::from32<0>(m == 1 ? a.zeta29[1] : a.zeta29[0])); below2p = true; }   // ZETA^-m = ZETA^(3-m)
+    }
+    if (!below2p) v = Fr29::reduce_small(v);                          // below 3 p
+    return Fr::normalize(Fr29::to32(v));                              // [0, 4p) -> canonical
+}
+ZK_HD Tile29 tile29_at(uint4* base, uint32_t count) {                 // planes of `count` elements: 16 B | 16 B | 4 B
+    Tile29 t;
+    t.lo = base; t.hi = base + count; t.top = reinterpret_cast<uint32_t*>(base + 2 * count);
+    return t;
+}
+
+template <int WPE>
+ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(WPE) ntt_strided_pass29_kernel(NttPassArgs a) {
+    ZK_DYN_SHARED(uint4, smem);
+    if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
+    const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
+    const Tile29 t = tile29_at(smem, tile);
+    const uint32_t half = R >> 1 ? R >> 1 : 1;
+    const Tile29 tw = tile29_at(smem + (tile * 36 + 15) / 16, half);   // R/2 stage twiddles (x 2^261, canonical) after the tile
+    for (uint32_t e = threadIdx.x; e < half; e += blockDim.x) lds_put29(tw, e, Fr29::from32<0>(load_u256(a.stage_tw, e)));
+    const uint32_t cols_log = a.blk_log - a.r;
+    const uint32_t tiles_per_blk_log = cols_log - a.c_log;
+    const uint32_t tb = blockIdx.x;
+    const size_t o = tb >> tiles_per_blk_log;
+    const uint32_t m0 = (tb & ((1u << tiles_per_blk_log) - 1)) << a.c_log;
+    const size_t base = (o << a.blk_log) + m0;
+    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+        const uint32_t col = e & (C - 1), row = e >> a.c_log;
+        const size_t idx = base + ((size_t)row << cols_log) + col;
+        lds_put29(t, tile_at(bitrev(row, a.r), col, a.r, a.c_log), ntt_load_input29(a, idx));
+    }
+    __syncthreads();
+    ntt_tile_stages29(t, a.r, a.c_log, tw, a.quarter_input != 0);
+    const uint32_t sh = a.log_n - a.blk_log;
+    const uint32_t lomask = (1u << a.lo_bits) - 1;
+    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+        const uint32_t col = e & (C - 1), row = e >> a.c_log;
+        u261 v = lds_get29(t, tile_at(row, col, a.r, a.c_log));
+        // the inter-pass twiddle on EVERY element (exponent 0 reads 2^261 mod p): the product is also what brings the pass's growth back below 2 p for the store
+        if (a.tw_full) {
+            v = Fr29::mul(v, Fr29::from32<0>(load_u256(a.tw_full, ((size_t)row << cols_log) + m0 + col)));
+        } else {
+            const uint32_t ex = ((m0 + col) * row) << sh;  // < 2^log_n
+            u261 w = Fr29::from32<5>(load_u256(a.tw_lo, ex & lomask));
+            const uint32_t h = ex >> a.lo_bits;
+            if (h) w = Fr29::mul(w, Fr29::from32<5>(load_u256(a.tw_hi, h)));                // below 8 p
+            v = Fr29::mul(v, Fr29::mul(w, Fr29::one()));                                      // (w below 2 p first: the store must stay below 2 p)
+        }
+        store_u256(a.dst, base + ((size_t)row << cols_log) + col, Fr29::to32(v));      // below 2 p, exact integer: the next pass takes it as it is
+    }
+}
+
+template <int WPE>
+ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(WPE) ntt_final_pass29_kernel(NttPassArgs a) {
+    ZK_DYN_SHARED(uint4, smem);
+    if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
+    const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
+    const Tile29 t = tile29_at(smem, tile);
+    const uint32_t half = R >> 1 ? R >> 1 : 1;
+    const Tile29 tw = tile29_at(smem + (tile * 36 + 15) / 16, half);
+    for (uint32_t e = threadIdx.x; e < half; e += blockDim.x) lds_put29(tw, e, Fr29::from32<0>(load_u256(a.stage_tw, e)));
+    const uint32_t tb = blockIdx.x;
+    const uint32_t jm = tb & ((1u << a.p_log) - 1);
+    const uint32_t j10 = (tb >> a.p_log) << a.c_log;
+    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+        const uint32_t row = e & (R - 1), col = e >> a.r;
+        const size_t o = ((size_t)(j10 + col) << a.p_log) + jm;
+        lds_put29(t, tile_at(bitrev(row, a.r), col, a.r, a.c_log), ntt_load_input29(a, (o << a.r) + row));
+    }
+    __syncthreads();
+    ntt_tile_stages29(t, a.r, a.c_log, tw, a.quarter_input != 0);
+    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+        const uint32_t col = e & (C - 1), row = e >> a.c_log;
+        const size_t out_idx = (size_t)(j10 + col) + (((size_t)jm + ((size_t)row << a.p_log)) << a.q_log);
+        store_u256(a.dst, out_idx, ntt_post29(a, lds_get29(t, tile_at(row, col, a.r, a.c_log)), out_idx));
     }
 }
 
@@ -338,10 +542,16 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleS
     int passes;
     plan_passes(log_n, ctx->tune, rl, &passes);
     for (auto& t : ctx->twiddles)
-        if (t.log_n == log_n && Fr::eq(t.omega, omega) && t.passes == passes && t.radix_log[0] == rl[0] && t.radix_log[1] == rl[1] &&
+        if (t.log_n == log_n && Fr::eq(t.omega, omega) && t.passes == passes && t.radix_log[0] == rl[0] && t.radix_log[1] == rl[1] && t.r261 == ctx->tune.ntt_limb29 &&
             t.radix_log[2] == rl[2] && (t.d_full[0] != nullptr) == (passes > 1 && (int)log_n <= ctx->tune.ntt_full_twiddle_max_log)) { *out = &t; return ZK_OK; }
     TwiddleSet ts;
     ts.log_n = log_n; ts.omega = omega; ts.passes = passes;
+    ts.r261 = ctx->tune.ntt_limb29;           // 1: the strided passes only (measured: the final pass gains nothing, profiles/r03), 2: every pass
+    // a 29-bit plan multiplies with twiddles in the form w * 2^261: its stage and inter-pass tables hold 32 * (w * 2^256) mod p, canonical (the two-level power
+    // tables stay in the library's form: the quotient kernel reads them too)
+    u256 c32 = Fr::zero();
+    c32.v[0] = 32;
+    c32 = Fr::to_mont(c32);
     for (int i = 0; i < 3; i++) ts.radix_log[i] = rl[i];
     ts.lo_bits = log_n < 10 ? log_n : 10;
     const int blk = 256;
@@ -357,6 +567,10 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleS
         ZK_HIP(hipMalloc(&ts.d_stage[i], (size_t)half * 32));
         ZK_LAUNCH(fr_pow_table_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, fr_pow2k_host(omega, log_n - rl[i]), half, ts.d_stage[i]);
         ZK_CHECK_LAUNCH();
+        if (ts.r261 == 2 || (ts.r261 == 1 && i + 1 < passes)) {
+            ZK_LAUNCH(fr_vec_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, 3, (const void*)ts.d_stage[i], (const void*)ts.d_stage[i], ts.d_stage[i], (size_t)half, c32);
+            ZK_CHECK_LAUNCH();
+        }
     }
     if ((int)log_n <= ctx->tune.ntt_full_twiddle_max_log) {
         uint32_t blk_log = log_n;
@@ -367,6 +581,10 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleS
             ZK_LAUNCH(ntt_full_twiddle_kernel, (uint32_t)((cnt + blk - 1) / blk), blk, 0, ctx->stream, (const void*)ts.d_lo, (const void*)ts.d_hi, ts.lo_bits,
                       cols_log, rl[i], log_n - blk_log, ts.d_full[i]);
             ZK_CHECK_LAUNCH();
+            if (ts.r261) {
+                ZK_LAUNCH(fr_vec_kernel, 1024, blk, 0, ctx->stream, 3, (const void*)ts.d_full[i], (const void*)ts.d_full[i], ts.d_full[i], cnt, c32);
+                ZK_CHECK_LAUNCH();
+            }
             blk_log -= rl[i];
         }
     }
@@ -389,6 +607,12 @@ int ntt_set_lds_attr() {
 #ifndef ZK_EMU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass29_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass29_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass29_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass29_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass29_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass29_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #ifdef ZK_NTT_PROBE
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -477,12 +701,27 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
         if (first && nf.cs_stride) { a.cs_lo = nf.cs_lo; a.cs_hi = nf.cs_hi; a.cs_lo_bits = nf.cs_lo_bits; a.cs_stride = nf.cs_stride; a.cs_log = nf.cs_log; }
         if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; a.quarter_input = tn.ntt_quarter_input && nf.n_valid && (size_t)nf.n_valid * 4 <= N && a.r >= 2; }
         if (last) { a.post_scale = nf.post_scale; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
+        const bool l29 = ts->r261 == 2 || (ts->r261 == 1 && !last);
+        if (l29) {
+            u256 c32 = Fr::zero();
+            c32.v[0] = 32;
+            c32 = Fr::to_mont(c32);
+            a.scale29 = Fr::mul(nf.scale, c32);
+            a.zeta29[0] = Fr::mul(zeta_pow(1), c32);
+            a.zeta29[1] = Fr::mul(zeta_pow(2), c32);
+        }
         const uint32_t room = tl > a.r ? tl - a.r : 0;
         if (!last) {
             const uint32_t cols_log = blk_log - a.r;
             a.c_log = room < cols_log ? room : cols_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
-            const size_t lds = ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
+            const size_t lds = l29 ? ((((size_t)36 << (a.r + a.c_log)) + 15) & ~(size_t)15) + ((size_t)18 << a.r) + 64     // 36-byte elements: tile + R/2 stage twiddles
+                                   : ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
+            if (l29 && tn.ntt_threads > 256) return ctx->fail(ZK_ERR_ARG, "ntt_threads: the 29-bit passes take at most 256 threads per workgroup");
+            if (l29 && tn.ntt_waves == 3) { ZK_LAUNCH(ntt_strided_pass29_kernel<3>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
+            else if (l29 && tn.ntt_waves == 4) { ZK_LAUNCH(ntt_strided_pass29_kernel<4>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
+            else if (l29) { ZK_LAUNCH(ntt_strided_pass29_kernel<2>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
+            else
 #ifdef ZK_NTT_PROBE
             if (tn.ntt_debug_mode == 1) { ZK_LAUNCH(ntt_strided_pass_kernel<1>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
             else if (tn.ntt_debug_mode == 2) { ZK_LAUNCH(ntt_strided_pass_kernel<2>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
@@ -496,7 +735,13 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             a.p_log = P == 3 ? ts->radix_log[1] : 0;
             a.c_log = room < a.q_log ? room : a.q_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
-            const size_t lds = ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
+            const size_t lds = l29 ? ((((size_t)36 << (a.r + a.c_log)) + 15) & ~(size_t)15) + ((size_t)18 << a.r) + 64
+                                   : ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
+            if (l29 && tn.ntt_threads > 256) return ctx->fail(ZK_ERR_ARG, "ntt_threads: the 29-bit passes take at most 256 threads per workgroup");
+            if (l29 && tn.ntt_waves == 3) { ZK_LAUNCH(ntt_final_pass29_kernel<3>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
+            else if (l29 && tn.ntt_waves == 4) { ZK_LAUNCH(ntt_final_pass29_kernel<4>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
+            else if (l29) { ZK_LAUNCH(ntt_final_pass29_kernel<2>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
+            else
 #ifdef ZK_NTT_PROBE
             if (tn.ntt_debug_mode == 1) { ZK_LAUNCH(ntt_final_pass_kernel<1>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
             else if (tn.ntt_debug_mode == 2) { ZK_LAUNCH(ntt_final_pass_kernel<2>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }

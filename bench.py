@@ -694,13 +694,17 @@ def main(argv=None):
             traffic, traffic_source = tjd.get("msm_accumulate_bytes_per_launch"), tjd.get("source", "").split(" (")[0]
         except Exception:
             traffic = None
-    XYZZ_MADD_PEAK = 13.82e9   # mixed additions/s of the same code (xyzz_madd_lazy) in a register-only loop (profiles/r02/run79_microbench_lazy_madd.txt; the canonical form: 13.10e9)
-    # An integer bound that owes nothing to this repo's loops: one XYZZ mixed addition in redundant form is 8 products + 2 squarings =
-    # 8 * 128 + 2 * 100 = 1224 partial products, each one v_mad_u64_u32 + one v_addc_co_u32; at the instruction issue rates measured on the box by tools/microbench
-    # (39.6 and 114.6 lane-ops per clock per CU: profiles/r02/run66_microbench_fma_ingredients_lazy_bound.txt) a lane needs 1224 * (1 / 39.6 + 1 / 114.6) clock-CUs
-    # per addition, so 256 CUs at the 2.4 GHz nominal clock cannot issue more than 14.77 G additions/s whatever the code around the products does.
-    MAD_RATE, SIMPLE_RATE, N_CU, CLK = 39.6, 114.6, 256, 2.4e9
-    ISSUE_BOUND = N_CU * CLK / (1224 * (1 / MAD_RATE + 1 / SIMPLE_RATE))
+    # The bucket step in the kernel that ran: on carry-free 29-bit limbs (msm_limb29, the default since round 3: 1467 v_mad_u64_u32, no addc, ~650 other VALU instructions per
+    # mixed addition — the kernel's own ISA census) or round 2's 32-bit redundant form (1160 mad + addc pairs + ~700 others).
+    limb29 = bool(be.tune_get("msm_limb29")) if hasattr(be, "tune_get") else True
+    # register-loop rate of the same step (tools/microbench, 4 blocks per CU: profiles/r03/run93_microbench_mad_issue_rate.txt) ...
+    XYZZ_MADD_PEAK = 17.70e9 if limb29 else 13.84e9
+    # ... and an integer bound that owes nothing to this repo's loops: instruction ISSUE rates measured on the box — v_mad_u64_u32 with 12 independent accumulators
+    # per lane 55.2 lane-ops per clock per CU (the 39.6 of rounds 1-2 came from a latency-limited four-chain loop), simple VALU 114.6 — times the step's instruction census, at the
+    # 2.4 GHz nominal clock.  Under these kernels the chip runs at 1.8-2.0 GHz (roofline.int_alu.pmc.eff_clock_ghz), which is most of the distance to this bound.
+    MAD_RATE, SIMPLE_RATE, N_CU, CLK = 55.2, 114.6, 256, 2.4e9
+    step_cycles = (1467 / MAD_RATE + 650 / SIMPLE_RATE) if limb29 else (1160 / MAD_RATE + (1160 + 700) / SIMPLE_RATE)
+    ISSUE_BOUND = N_CU * CLK / step_cycles
     valu = {}
     try:
         valu = json.load(open(tj)).get("valu", {}) if os.path.exists(tj) else {}
@@ -716,14 +720,16 @@ def main(argv=None):
                 "int_alu": {"achieved_Gmadd_per_s": round(msm_pairs / acc_s / 1e9, 3), "peak_Gmadd_per_s": XYZZ_MADD_PEAK / 1e9,
                             "frac": round(msm_pairs / acc_s / XYZZ_MADD_PEAK, 4),
                             "issue_bound_Gmadd_per_s": round(ISSUE_BOUND / 1e9, 3), "issue_bound_frac": round(msm_pairs / acc_s / ISSUE_BOUND, 4),
-                            "issue_bound_is": "256 CUs x 2.4 GHz / (1224 partial products x (1/39.6 + 1/114.6) clk per v_mad_u64_u32 + v_addc_co_u32 pair): instruction issue rates from tools/microbench, not from a loop of this kernel",
+                            "issue_bound_is": ("256 CUs x 2.4 GHz / (1467 v_mad_u64_u32 / 55.2 + 650 other VALU / 114.6 lane-ops per clk per CU): the 29-bit-limb step's instruction census at the issue rates tools/microbench measured" if limb29 else
+                                               "256 CUs x 2.4 GHz / (1160 v_mad_u64_u32 / 55.2 + 1860 v_addc + other VALU / 114.6): the 32-bit step's instruction census at the issue rates tools/microbench measured"),
+                            "step": "xyzz29_madd_fast (9 x 29-bit limbs)" if limb29 else "xyzz_madd_lazy (8 x 32-bit limbs)",
                             # counters of the last profiling session (separate rocprofv3 --pmc passes, one proof alone): VALU busy share, per-wave issue / stall split,
                             # the chip's effective clock under this kernel and the instruction-mix issue model (tools/summarize_profiles.py valu_section)
                             "pmc": {k_: acc_valu.get(k_) for k_ in ("valu_busy", "active_valu_per_wave_cycle", "wait_inst_per_wave_cycle", "wait_any_per_wave_cycle", "eff_clock_ghz", "int64_share", "issue_model")} if acc_valu else None,
                             "pmc_source": json.load(open(tj)).get("valu_source") if acc_valu else None},
                 # the other throughput-bound kernels, same counters (profiles/traffic.json): NTT passes and the quotient interpreter
                 "other_kernels_pmc": {k_: {c_: valu[k_].get(c_) for c_ in ("ms_per_launch", "valu_busy", "active_valu_per_wave_cycle", "wait_inst_per_wave_cycle", "eff_clock_ghz", "int64_share", "issue_model")}
-                                      for k_ in ("ntt_strided_pass_kernel", "ntt_final_pass_kernel", "quotient_kernel") if k_ in valu} or None}
+                                      for k_ in ("ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "quotient_kernel") if k_ in valu} or None}
 
     if args.mode == "prove":
         # The same K steps once more with the witness starting in HOST memory (what the Rust boundary hands over: create_proof receives host-owned

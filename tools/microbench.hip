@@ -22,6 +22,19 @@ __global__ void k_mad64(uint32_t* out, uint32_t seed) {
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(x0 ^ x1 ^ x2 ^ x3) ^ (uint32_t)((x0 ^ x1 ^ x2 ^ x3) >> 32);
 }
+// the same instruction with 12 independent accumulators per lane and no carry-out consumer: its ISSUE rate (the 4-chain loop above is latency-limited at low occupancy)
+__global__ void k_mad64_x12(uint32_t* out, uint32_t seed) {
+    uint32_t a = threadIdx.x + seed, b = blockIdx.x * 3 + 7;
+    uint64_t x[12];
+    for (int j = 0; j < 12; j++) x[j] = a + j * b;
+    for (int i = 0; i < ITER / 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x[j]) : "v"(a), "v"(b) : "vcc");
+    }
+    uint64_t r = 0;
+    for (int j = 0; j < 12; j++) r ^= x[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+}
 __global__ void k_mullo(uint32_t* out, uint32_t seed) {
     uint32_t a = threadIdx.x + seed | 1, x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3;
     for (int i = 0; i < ITER; i++) { x0 = x0 * a + 1; x1 = x1 * a + 1; x2 = x2 * a + 1; x3 = x3 * a + 1; }
@@ -283,6 +296,7 @@ int main(int argc, char** argv) {
     printf("device: %s  CUs=%d  clock=%d MHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000);
     for (int bpc : {4, 8}) {
         run("mad_u64_u32", k_mad64, 4.0 * ITER, 256, bpc);
+        run("mad_u64_u32_12_chains", k_mad64_x12, 12.0 * (ITER / 3), 256, bpc);
         run("mul_lo_u32", k_mullo, 4.0 * ITER, 256, bpc);
         run("mul_hi_u32", k_mulhi, 4.0 * ITER, 256, bpc);
         run("mul_u24", k_mul24, 4.0 * ITER, 256, bpc);

@@ -19,8 +19,9 @@ def last_json_line(path):
     return json.loads([l for l in open(path) if l.startswith("{")][-1])
 
 
-# instruction issue rates measured on the box by tools/microbench (profiles/r02/run66_microbench_fma_ingredients_lazy_bound.txt), lane-ops per clock per CU
-RATE_MAD64, RATE_SIMPLE, N_CU, N_SIMD = 39.6, 114.6, 256, 1024
+# instruction issue rates measured on the box by tools/microbench, lane-ops per clock per CU: v_mad_u64_u32 with 12 independent accumulators per lane (profiles/r03/run93_microbench_mad_issue_rate.txt:
+# 55.2; the four-chain loop of rounds 1-2 read 39.6 because it is latency-limited) and simple VALU instructions (114.6, run66)
+RATE_MAD64, RATE_SIMPLE, N_CU, N_SIMD = 55.2, 114.6, 256, 1024
 
 
 def valu_section(O, P, tag, rnd):
@@ -46,7 +47,7 @@ def valu_section(O, P, tag, rnd):
                 d[k]["ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         return d
     v, m = per_kernel(vp), per_kernel(mp)
-    keep = ["msm_accumulate_kernel", "ntt_strided_pass_kernel", "ntt_final_pass_kernel", "quotient_kernel", "msm_scatter_kernel", "msm_hist_kernel", "msm_merge_kernel",
+    keep = ["msm_accumulate_kernel", "ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "ntt_final_pass29_kernel", "quotient_kernel", "msm_scatter_kernel", "msm_hist_kernel", "msm_merge_kernel",
             "msm_rowcol_kernel", "lpb_scatter_kernel", "pe_lincomb_kernel", "pe_eval_partial_kernel", "gp_batch_divide_kernel"]
     out = {}
     with open(f"{P}/{tag}_rocprofv3_pmc_valu.csv", "w") as f:
@@ -136,7 +137,7 @@ def main():
                 d[k][1] += float(r["Counter_Value"])
         return d
     fe, wr = agg(f"{O}/fetch/f_counter_collection.csv", "FETCH_SIZE"), agg(f"{O}/write/w_counter_collection.csv", "WRITE_SIZE")
-    keep = ["msm_accumulate_kernel", "quotient_kernel", "ntt_strided_pass_kernel", "ntt_final_pass_kernel", "msm_hist_kernel", "msm_scatter_kernel", "lpb_scatter_kernel",
+    keep = ["msm_accumulate_kernel", "quotient_kernel", "ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "ntt_final_pass29_kernel", "msm_hist_kernel", "msm_scatter_kernel", "lpb_scatter_kernel",
             "lpb_hist_kernel", "msm_merge_kernel", "msm_rowcol_kernel", "pe_eval_partial_kernel", "pe_lincomb_kernel", "gp_batch_divide_kernel"]
     traffic = {}
     with open(f"{P}/{tag}_rocprofv3_pmc_hbm_traffic.csv", "w") as f:
@@ -152,7 +153,8 @@ def main():
     tj = {"source": f"profiles/{rnd}/{tag}_rocprofv3_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 --inflight 1 --no-extras; "
                     "bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 per the gfx950 correction of MI355X_MICROARCH.md HBM section)",
           "msm_accumulate_bytes_per_launch": round(traffic["msm_accumulate_kernel"]), "quotient_bytes_per_launch": round(traffic["quotient_kernel"]),
-          "ntt_strided_pass_bytes_per_launch": round(traffic["ntt_strided_pass_kernel"]), "ntt_final_pass_bytes_per_launch": round(traffic["ntt_final_pass_kernel"])}
+          "ntt_strided_pass_bytes_per_launch": round(traffic.get("ntt_strided_pass29_kernel") or traffic["ntt_strided_pass_kernel"]),      # (the 29-bit-limb kernel when the plan uses it)
+          "ntt_final_pass_bytes_per_launch": round(traffic.get("ntt_final_pass_kernel") or traffic["ntt_final_pass29_kernel"])}
     json.dump(tj, open(os.path.join(os.path.dirname(P), "traffic.json"), "w"), indent=1)
     d = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
@@ -166,7 +168,8 @@ def main():
         f.write("# LDS has no hit rate; what the counters give for the LDS-staged bucket pass (msm_hist / msm_scatter: counting sort of (scalar, window) pairs on LDS atomics) and for the\n")
         f.write("# lookup radix sort is the share of LDS cycles lost to bank conflicts: conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (both in LDS-array cycles), and LDS busy share of wave cycles\n")
         f.write("kernel,launches,SQ_INSTS_LDS,SQ_LDS_IDX_ACTIVE,SQ_LDS_BANK_CONFLICT,conflict_frac,lds_active_over_wave_cycles\n")
-        for k in ["msm_hist_kernel", "msm_scatter_kernel", "msm_rowcol_kernel", "lpb_hist_kernel", "lpb_scatter_kernel", "ntt_strided_pass_kernel", "ntt_final_pass_kernel", "quotient_kernel"]:
+        for k in ["msm_hist_kernel", "msm_scatter_kernel", "msm_rowcol_kernel", "lpb_hist_kernel", "lpb_scatter_kernel", "ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel",
+                  "ntt_final_pass29_kernel", "quotient_kernel"]:
             if k in d:
                 v = d[k]
                 act = v["SQ_LDS_IDX_ACTIVE"] or 1

@@ -262,3 +262,32 @@ def test_proof_bytes_replayed_through_a_fresh_transcript_reach_the_same_state(em
     assert t.state.digest() == twin.state.digest()
     pk.release()
     params.release()
+
+
+def _full_chain_x4(be, k, table_bits):
+    """BASELINE configs[4] / SURVEY 8d cfg 5: the full-DCAP-chain op-mix = cfg 2's census with the advice and lookup counts x 4 (synthetic: the reference's README lists that circuit
+    as a roadmap item) — 100 advice columns, 44 lookups, 58 equality columns (20 permutation sets), 96 gates — through the native prover, accepted by verify_proof"""
+    import os, sys
+    import verifier
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sgx_shaped_circuit as sc
+    cs, fixed, asm, advice = sc.build(z, be, k, census="full_chain_x4", table_bits=table_bits)
+    assert (cs.num_advice_columns, len(cs.lookups), len(cs.permutation_columns), cs.degree()) == (100, 44, 58, 5)
+    params = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    proof = plonk.NativeProver(params, pk).create_proof(advice, [], np.random.default_rng(3))
+    n_sets = -(-58 // 3)
+    assert len(proof) >= 32 * (100 + 3 * 44 + n_sets + 1 + 4 + 2)
+    assert verifier.verify_proof(pk.vk, tcp.TAU, [], proof) is True
+    pk.release()
+    params.release()
+
+
+def test_full_chain_x4_census_emulated(emu, orc):
+    _full_chain_x4(emu, 9, 6)
+
+
+@pytest.mark.gpu
+def test_full_chain_x4_census_gpu(gpu, orc):
+    _full_chain_x4(gpu, 13, 12)

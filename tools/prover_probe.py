@@ -33,6 +33,8 @@ def main():
     master = [be.to_device(a) for a in advice]
     work = [be.alloc(n * 32) for _ in advice]
     times, proof = [], None
+    native = z.plonk.NativeProver(params, pk) if os.environ.get("ZK_PROVER") == "native" else None      # the C++ per-proof driver (zk_plonk_create_proof) instead of the Python twin
+    out["prover"] = "native" if native else "python twin"
     for r in range(reps + 1):
         host_witness = os.environ.get("ZK_HOST_WITNESS") == "1"      # PCIe-inclusive: hand create_proof the host columns (as the Rust boundary would)
         if not host_witness:
@@ -42,13 +44,20 @@ def main():
         t = time.time()
         tr = Blake2bWrite()
         tm = {}
-        info = z.plonk.create_proof(params, pk, advice if host_witness else work, [], np.random.default_rng(r), tr, timings=tm)
-        proof = tr.finalize()
+        if native:
+            proof = native.create_proof(advice if host_witness else work, [], np.random.default_rng(r))
+            tm, info = dict(native.phase_ms), {"proof_bytes": len(proof)}
+        else:
+            info = z.plonk.create_proof(params, pk, advice if host_witness else work, [], np.random.default_rng(r), tr, timings=tm)
+            proof = tr.finalize()
         times.append(time.time() - t)
     be.timing(True)                                    # once more with HIP-event kernel timing (alone on the GPU: the event pairs bracket only this proof's kernels)
     for w, m in zip(work, master):
         w.copy_from(m)
-    z.plonk.create_proof(params, pk, work, [], np.random.default_rng(99), Blake2bWrite())
+    if native:
+        native.create_proof(work, [], np.random.default_rng(99))
+    else:
+        z.plonk.create_proof(params, pk, work, [], np.random.default_rng(99), Blake2bWrite())
     out["kernel_ms"] = {lab: round(be.timing_get(lab)[0] or 0.0, 3) for lab in ("msm_sort", "msm_accumulate", "msm_reduce", "quotient")}
     out["msm_pairs"] = be.stat_get("msm_pairs")
     be.timing(False)

@@ -26,7 +26,14 @@ def build(z, be, k: int, seed: int = 20241008, table_bits: int = TABLE_BITS, cen
     from SURVEY §3.1) or "reference_exact" (build_reference_exact below: the base64 part exactly as the reference configures and assigns it)."""
     if census == "reference_exact":
         return build_reference_exact(z, be, k, seed)
-    assert census == "chip_estimate", census
+    # "full_chain_x4": BASELINE configs[4] / SURVEY 8d cfg 5 — the full DCAP chain (root -> intermediate -> leaf certificate ECDSA + QE3 + isv_report signatures,
+    # several SHA-256) does not exist in the reference (README.md:23-47 is a roadmap); its op-mix is cfg 2's with the advice and lookup counts x 4, synthetic, at k = 21
+    assert census in ("chip_estimate", "full_chain_x4"), census
+    scale = 4 if census == "full_chain_x4" else 1
+    return _build_chip_estimate(z, be, k, seed, table_bits, N_GATE_COLS * scale, N_LOOKUP_COLS * scale, N_TABLE_COLS + (N_FIXED - N_TABLE_COLS) * scale, N_GATES * scale)
+
+
+def _build_chip_estimate(z, be, k, seed, table_bits, N_GATE_COLS, N_LOOKUP_COLS, N_FIXED, N_GATES):
     plonk, F = z.plonk, z.fields
     Advice, Fixed = plonk.Advice, plonk.Fixed
     n = 1 << k

@@ -310,9 +310,9 @@ struct Draws {
     std::atomic<bool> abandoned{false};                                // the proof ended early (an error): stop asking the caller for randomness nobody will use
     void start(zk_rng_fn rng, void* user) {
         items.resize(counts.size());
-        for (size_t i = 0; i < counts.size(); i++) items[i].resize(counts[i] * 4 + 4);
         th = std::thread([this, rng, user]() {
             for (size_t i = 0; i < counts.size() && !abandoned.load(); i++) {
+                items[i].resize(counts[i] * 4 + 4);                    // (allocated here, off the proof's critical path: the random polynomial alone is n x 32 bytes — 10 ms of zero-fill at k = 21)
                 if (counts[i]) rng(user, counts[i], items[i].data());
                 { std::lock_guard<std::mutex> lk(mu); done = i + 1; }
                 cv.notify_all();

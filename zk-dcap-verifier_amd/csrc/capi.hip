@@ -117,7 +117,7 @@ static int* tune_slot(zk_ctx* ctx, const char* key) {
 #ifdef ZK_NTT_PROBE
         {"ntt_debug_mode", &t.ntt_debug_mode},
 #endif
-        {"quot_rows", &t.quot_rows}, {"quot_remat_ops", &t.quot_remat_ops}, {"quot_remat_distance", &t.quot_remat_distance}};
+        {"quot_rows", &t.quot_rows}, {"quot_limb29", &t.quot_limb29}, {"quot_remat_ops", &t.quot_remat_ops}, {"quot_remat_distance", &t.quot_remat_distance}};
     for (auto& e : tab) if (!strcmp(e.k, key)) return e.v;
     return nullptr;
 }

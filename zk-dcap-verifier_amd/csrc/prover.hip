@@ -266,6 +266,8 @@ struct Transcript {
 struct Pool {
     std::mutex mu;
     std::map<size_t, std::vector<void*>> free_;
+    std::vector<std::vector<uint64_t>> draw_bufs;                     // host buffers of the rng draws of finished proofs (one per proof in flight on the context), reused: a proof
+                                                                      // draws n + O(columns) field elements — 16 MiB at k = 19 — and fresh pages every proof cost mmap churn
     bool retired = false;                                             // zk_plonk_trim ran while a proof of this context still held buffers: they are freed as they come back
 };
 std::mutex g_pools_mu;
@@ -303,25 +305,36 @@ struct Arena {                                                        // everyth
 
 // ---- the caller's Fr::random draws, made on a helper thread in the order the phases consume them ---------------------------------------------------------
 struct Draws {
-    std::vector<std::vector<uint64_t>> items;                         // each: count x 4 limbs
-    std::vector<size_t> counts;
+    std::vector<uint64_t> buf;                                        // all items back to back (count x 4 limbs each), borrowed from the context's pool
+    std::vector<size_t> counts, offs;
+    std::shared_ptr<Pool> pool;
     std::mutex mu; std::condition_variable cv; size_t done = 0;
     std::thread th;
     std::atomic<bool> abandoned{false};                                // the proof ended early (an error): stop asking the caller for randomness nobody will use
-    void start(zk_rng_fn rng, void* user) {
-        items.resize(counts.size());
-        th = std::thread([this, rng, user]() {
+    void start(zk_rng_fn rng, void* user, std::shared_ptr<Pool> p) {
+        pool = std::move(p);
+        size_t total = 4;
+        for (size_t c : counts) { offs.push_back(total); total += c * 4; }
+        {
+            std::lock_guard<std::mutex> lk(pool->mu);
+            if (!pool->draw_bufs.empty()) { buf.swap(pool->draw_bufs.back()); pool->draw_bufs.pop_back(); }
+        }
+        th = std::thread([this, rng, user, total]() {
+            if (buf.size() < total) buf.resize(total);                 // (first proof of a context only; on the helper thread, off the proof's critical path)
             for (size_t i = 0; i < counts.size() && !abandoned.load(); i++) {
-                items[i].resize(counts[i] * 4 + 4);                    // (allocated here, off the proof's critical path: the random polynomial alone is n x 32 bytes — 10 ms of zero-fill at k = 21)
-                if (counts[i]) rng(user, counts[i], items[i].data());
+                if (counts[i]) rng(user, counts[i], buf.data() + offs[i]);
                 { std::lock_guard<std::mutex> lk(mu); done = i + 1; }
                 cv.notify_all();
             }
         });
     }
-    const uint64_t* take(size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done > i; }); return items[i].data(); }
+    const uint64_t* take(size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done > i; }); return buf.data() + offs[i]; }
     void finish() { if (!counts.empty()) (void)take(counts.size() - 1); }     // a successful proof leaves the caller's stream where halo2 would: every planned draw made
-    ~Draws() { abandoned.store(true); if (th.joinable()) th.join(); }
+    ~Draws() {
+        abandoned.store(true);
+        if (th.joinable()) th.join();
+        if (pool && !buf.empty()) { std::lock_guard<std::mutex> lk(pool->mu); if (!pool->retired && pool->draw_bufs.size() < 8) pool->draw_bufs.emplace_back(std::move(buf)); }
+    }
 };
 
 struct Query { const void* poly; Fe point; Fe eval; };                 // ProverQuery { point, poly } + its evaluation
@@ -438,7 +451,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     for (uint32_t l = 0; l < L; l++) { d_lb[l] = plan(bf); if (upstream) plan(1); }
     const size_t d_rp = plan(n);
     if (upstream) for (uint32_t i = 0; i < 1 + n_pieces; i++) plan(1);
-    draws.start(rng, rng_user);
+    draws.start(rng, rng_user, mem.pool);
 
     // ---- 1. vk, instances ----------------------------------------------------------------------------------------------------------------------------
     tr.common_scalar(Fr::to_mont(load32(pk->transcript_repr)));

@@ -34,6 +34,7 @@ struct QuotProgram {
     uint32_t n_perm_cols = 0, n_sets = 0, n_lookups = 0;
     std::vector<uint32_t> perm_cols;      // pairs (type, index)
     std::vector<uint4> code;
+    std::vector<uint4> code29;            // the same micro-program annotated for the 29-bit-limb interpreter (bias class / reduce flags from the bound analysis); empty = not available
     std::vector<u256> graph_consts;       // constants that come with the program
     std::vector<int32_t> rotations;       // distinct rotations (rows)
     uint32_t n_slots = 0, n_cols = 0;
@@ -43,9 +44,10 @@ struct QuotProgram {
     uint32_t col_fixed = 0, col_advice = 0, col_instance = 0, col_l0 = 0, col_llast = 0, col_lactive = 0, col_sigma = 0, col_z = 0,
              col_lk_z = 0, col_lk_a = 0, col_lk_s = 0;
     bool uses_xpow = false;
+    void* d_code29 = nullptr;
     void* d_code = nullptr;               // immutable after the load; the constants / column pointers / rotation offsets of a RUN live in the calling context's ws_quot,
     int device = 0;                       // so contexts of one device can share a program (zk_quotient_program_share) and run it concurrently
-    ~QuotProgram() { if (d_code) { (void)hipSetDevice(device); (void)hipFree(d_code); } }
+    ~QuotProgram() { if (d_code) { (void)hipSetDevice(device); (void)hipFree(d_code); } if (d_code29) { (void)hipSetDevice(device); (void)hipFree(d_code29); } }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -72,6 +74,7 @@ struct QuotArgs {
     int uses_xpow;
     uint32_t xpow_mul, xpow_add;   // X of row idx = extended_omega^(idx * xpow_mul + xpow_add): (1, 0) on the whole extended domain, (2^(ek-k), j) on coset j
     uint32_t row_base;             // first row of this launch (a launch may cover a slice of the rows: out[i] = numerator of row row_base + i)
+    uint32_t lds_slots;            // quotient29_kernel: slots that live in LDS (its 4-byte plane starts after their two 16-byte planes)
     void* out;
 };
 
@@ -190,6 +193,114 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_k
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same interpreter on carry-free 29-bit limbs (field29.cuh; round 3).  Every value of a row — slots, accumulator, X power — is x * 2^261 in N-form limbs; a column
+// operand enters through the limb conversion's shift by 5 (x * 2^256 -> x * 2^261, below 32 p), a constant arrives as x * 2^261 mod p (quotient_run multiplies the
+// run's constant table by 32).  There is no modular correction in the loop: a product returns below a b / 151 + 1 (in multiples of p), sums add their bounds, a
+// difference a - b + K p adds K, and the COMPILER tracks those bounds statically (bound29_pass): it picks K = 2^(class + 1) > bound(b) for every subtraction / negation
+// and flags the (rare) result that must be brought back below 3 p.  Sums and differences take one parallel carry round before they are stored, so every stored value
+// has N-form limbs and every product sees N-form operands.  One product with 2^256 mod p takes the row's result back to the library's form.
+// w0 of a 29-bit instruction: op [0,8) | writes the accumulator [8] | bias class [9,13) | reduce the result [13] | slot [16,32).
+// ------------------------------------------------------------------------------------------------
+struct Bias29Table { uint32_t l[10][9]; };
+constexpr Bias29Table make_bias29_table() {
+    Bias29Table t{};
+    for (int c = 0; c < 10; c++) {
+        const Fr29::Limbs9 b = Fr29::bias(2u << c, 30);               // K = 2^(c + 1): 2, 4, ..., 1024
+        for (int i = 0; i < 9; i++) t.l[c][i] = b.l[i];
+    }
+    return t;
+}
+#ifdef ZK_EMU
+static const Bias29Table BIAS29 = make_bias29_table();
+#else
+__constant__ const Bias29Table BIAS29 = make_bias29_table();
+#endif
+
+ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) quotient29_kernel(QuotArgs q) {
+    ZK_DYN_SHARED(uint4, smem);
+    const uint32_t T = blockDim.x, tid = threadIdx.x;
+    const uint32_t idx0 = q.row_base + blockIdx.x * T + tid;
+    const uint32_t mask = (1u << q.size_log) - 1u;
+    uint32_t* const top_plane = reinterpret_cast<uint32_t*>(smem + (size_t)2 * q.lds_slots * T);      // limb 8 of every LDS slot, after the two 16-byte planes
+    u261 acc = Fr29::zero(), xpow = Fr29::one(), rg0 = Fr29::zero();
+    if (q.uses_xpow) {  // extended_omega^(position of this row in the extended domain), as x * 2^261 below 8 p
+        const uint32_t xi = idx0 * q.xpow_mul + q.xpow_add;
+        const u261 lo = Fr29::from32<5>(load_u256(q.tw_lo, xi & ((1u << q.lo_bits) - 1u)));
+        const uint32_t h = xi >> q.lo_bits;
+        xpow = Fr29::mul(lo, h ? Fr29::from32<5>(load_u256(q.tw_hi, h)) : Fr29::one());
+    }
+    auto prefetch = [&](uint32_t src) -> u256 {        // memory operands only, still in the library's 32-bit words; everything else is resolved later
+        const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
+        if (kind == K_COL) return load_u256(q.cols[pay >> 8], (idx0 + q.rot_off[pay & 0xffu]) & mask);
+        if (kind == K_CONST) return load_u256(q.consts, pay);
+        return Fr::zero();
+    };
+    auto resolve = [&](uint32_t src, const u256& pre) -> u261 {
+        const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
+        switch (kind) {
+            case K_SLOT: {
+                if (pay == 0) return rg0;
+                const uint32_t ls = pay - QUOT_NREG;
+                const uint4 l = smem[(2 * ls) * T + tid], h = smem[(2 * ls + 1) * T + tid];
+                u261 o;
+                o.l[0] = l.x; o.l[1] = l.y; o.l[2] = l.z; o.l[3] = l.w; o.l[4] = h.x; o.l[5] = h.y; o.l[6] = h.z; o.l[7] = h.w;
+                o.l[8] = top_plane[ls * T + tid];
+                return o;
+            }
+            case K_ACC: return acc;
+            case K_XPOW: return xpow;
+            case K_COL: return Fr29::from32<5>(pre);
+            default: return Fr29::from32<0>(pre);        // K_CONST (x * 2^261 mod p already) or K_NONE (zero)
+        }
+    };
+    auto biased = [&](const u261& a, const u261& b, uint32_t cls, bool with_a) -> u261 {   // a - b + K p (or K p - b), K = 2^(cls + 1)
+        u261 o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.l[i] = (with_a ? a.l[i] : 0u) + BIAS29.l[cls][i] - b.l[i];
+        return o;
+    };
+    uint4 ins = q.n_instr ? q.code[0] : make_uint4(M_MOV | (1u << 8), K_NONE << 28, K_NONE << 28, K_NONE << 28);
+    u256 pa = prefetch(ZK_UNIFORM(ins.y)), pb = prefetch(ZK_UNIFORM(ins.z)), pc_ = prefetch(ZK_UNIFORM(ins.w));
+    for (uint32_t pc = 0; pc < q.n_instr; pc++) {
+        const uint32_t w0 = ZK_UNIFORM(ins.x), sa = ZK_UNIFORM(ins.y), sb = ZK_UNIFORM(ins.z), sc = ZK_UNIFORM(ins.w);
+        uint4 nxt = ins;
+        u256 na = pa, nb = pb, nc = pc_;
+        if (pc + 1 < q.n_instr) {                      // the next instruction's loads go out before this one's arithmetic
+            nxt = q.code[pc + 1];
+            na = prefetch(ZK_UNIFORM(nxt.y)); nb = prefetch(ZK_UNIFORM(nxt.z)); nc = prefetch(ZK_UNIFORM(nxt.w));
+        }
+        const uint32_t op = w0 & 0xffu, cls = (w0 >> 9) & 0xfu;
+        const u261 a = resolve(sa, pa);
+        u261 res;
+        switch (op) {
+            case M_ADD: res = Fr29::carry(Fr29::add(a, resolve(sb, pb))); break;
+            case M_SUB: res = Fr29::carry(biased(a, resolve(sb, pb), cls, true)); break;
+            case M_MUL: res = Fr29::mul(a, resolve(sb, pb)); break;
+            case M_SQR: res = Fr29::sqr(a); break;
+            case M_DBL: res = Fr29::carry(Fr29::dbl(a)); break;
+            case M_NEG: res = Fr29::carry(biased(a, a, cls, false)); break;
+            case M_MULADD: res = Fr29::carry(Fr29::add(Fr29::mul(a, resolve(sb, pb)), resolve(sc, pc_))); break;
+            case M_FOLD2: res = Fr29::mul2(acc, resolve(sc, pc_), a, resolve(sb, pb)); break;
+            default: res = a; break;
+        }
+        if ((w0 >> 13) & 1u) res = Fr29::reduce_small(res);
+        if ((w0 >> 8) & 1u) acc = res;
+        else {
+            const uint32_t slot = w0 >> 16;
+            if (slot == 0) rg0 = res;
+            else {
+                const uint32_t ls = slot - QUOT_NREG;
+                smem[(2 * ls) * T + tid] = make_uint4(res.l[0], res.l[1], res.l[2], res.l[3]);
+                smem[(2 * ls + 1) * T + tid] = make_uint4(res.l[4], res.l[5], res.l[6], res.l[7]);
+                top_plane[ls * T + tid] = res.l[8];
+            }
+        }
+        ins = nxt; pa = na; pb = nb; pc_ = nc;
+    }
+    store_u256(q.out, idx0 - q.row_base, Fr29::leave(acc));
+}
+
+// ------------------------------------------------------------------------------------------------
 // compiler: ZKQ1 blob -> micro-program
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -303,6 +414,55 @@ struct Builder {
 };
 
 }  // namespace
+
+// Static bound analysis of a finished micro-program for the 29-bit-limb interpreter (quotient29_kernel): bounds in multiples of p, rounded up.
+//   column 32 (the shifted limb conversion), constant 1, X power 8;  product a b / 151 + 1;  sum a + b;  a - b + K p -> a + K with K = 2^(class + 1) >= b + 1.
+// A result above 128 is flagged for reduce_small (-> 3), so a subtrahend never needs K above 256.  The pass cannot fail on a program the 32-bit interpreter accepts except by running out of bias classes
+// (a subtrahend above 1023 p, which the reduce flag rules out); it then leaves code29 empty and the program runs on the 32-bit interpreter.
+static void bound29_pass(QuotProgram& P) {
+    P.code29.clear();
+    std::vector<double> slot(P.n_slots + 1, 0.0);
+    double acc = 0.0;
+    auto bound_of = [&](uint32_t src) -> double {
+        const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
+        switch (kind) {
+            case K_SLOT: return pay < slot.size() ? slot[pay] : 1e9;
+            case K_CONST: return 1.0;
+            case K_COL: return 32.0;
+            case K_ACC: return acc;
+            case K_XPOW: return 8.0;
+            default: return 0.0;
+        }
+    };
+    auto prod = [](double a, double b) { return a * b / 151.0 + 1.0; };
+    std::vector<uint4> out;
+    for (const uint4& ins : P.code) {
+        const uint32_t op = ins.x & 0xffu;
+        const double a = bound_of(ins.y), b = bound_of(ins.z), c = bound_of(ins.w);
+        double r = a;
+        uint32_t cls = 0;
+        auto class_for = [&](double sub) { uint32_t k = 0; while ((double)(2u << k) < sub + 1.0 && k < 10) k++; return k; };
+        switch (op) {
+            case M_ADD: r = a + b; break;
+            case M_SUB: cls = class_for(b); r = a + (double)(2u << cls); break;
+            case M_MUL: r = prod(a, b); break;
+            case M_SQR: r = prod(a, a); break;
+            case M_DBL: r = 2 * a; break;
+            case M_NEG: cls = class_for(a); r = (double)(2u << cls); break;
+            case M_MULADD: r = prod(a, b) + c; break;
+            case M_FOLD2: r = (acc * c + a * b) / 151.0 + 1.0; break;
+            default: r = a; break;
+        }
+        if (cls > 7) return;                                          // K above 256: no bias class (top limbs would crowd 32 bits): stay on the 32-bit interpreter
+        uint32_t w0 = ins.x | (cls << 9);
+        if (r > 128.0) { w0 |= 1u << 13; r = 3.0; }
+        if ((ins.x >> 8) & 1u) acc = r;
+        else { const uint32_t sl = ins.x >> 16; if (sl < slot.size()) slot[sl] = r; }
+        out.push_back(make_uint4(w0, ins.y, ins.z, ins.w));
+    }
+    if (acc > 140.0) return;                                          // (the last product with 2^256 mod p must return below 2 p)
+    P.code29.swap(out);
+}
 
 static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, QuotProgram& P) {
     Reader r{words, nwords};
@@ -645,6 +805,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         P.code.push_back(make_uint4(w0, w[0], w[1], w[2]));
     }
     P.n_slots = n_slots ? n_slots : 1;
+    bound29_pass(P);
     return ZK_OK;
 }
 
@@ -660,6 +821,10 @@ int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* p
         return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %u live intermediates; this build keeps at most 80 in LDS", P->n_slots);
     hipError_t e = hipMalloc(&P->d_code, P->code.size() * 16 + 16);
     if (e == hipSuccess) e = hipMemcpy(P->d_code, P->code.data(), P->code.size() * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !P->code29.empty()) {
+        e = hipMalloc(&P->d_code29, P->code29.size() * 16 + 16);
+        if (e == hipSuccess) e = hipMemcpy(P->d_code29, P->code29.data(), P->code29.size() * 16, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "zk_quotient_program_load: device allocation failed");
     *prog = ctx->next_handle++;
     ctx->programs[*prog] = P;
@@ -717,6 +882,7 @@ int quotient_set_lds_attr() {
 #ifndef ZK_EMU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient29_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
     return 0;
 }
@@ -764,6 +930,14 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
         u256 cur = Fr::mul(beta, zeta);
         for (uint32_t j = 0; j < P.n_perm_cols; j++) { consts[P.c_delta + j] = cur; cur = Fr::mul(cur, delta); }
     }
+    // the 29-bit-limb interpreter (tune quot_limb29) takes the run's constants as x * 2^261 mod p: the whole table times 32
+    const bool l29 = ctx->tune.quot_limb29 && P.d_code29 && ctx->tune.quot_rows < 2;
+    if (l29) {
+        u256 c32 = Fr::zero();
+        c32.v[0] = 32;
+        c32 = Fr::to_mont(c32);
+        for (auto& cst : consts) cst = Fr::mul(cst, c32);
+    }
     if (coset >= (int)(1u << (P.ek - P.k))) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_dev: coset %d out of range", coset);
     const bool cm = coset >= 0;
     const uint32_t size_log = cm ? P.k : P.ek;
@@ -787,7 +961,7 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
     ZK_HIP(hipMemcpyAsync(d_rot, rot_off.data(), rot_off.size() * 4, hipMemcpyHostToDevice, st));
     QuotArgs q;
     memset(&q, 0, sizeof q);
-    q.code = (const uint4*)P.d_code; q.n_instr = (uint32_t)P.code.size(); q.consts = d_consts;
+    q.code = (const uint4*)(l29 ? P.d_code29 : P.d_code); q.n_instr = (uint32_t)P.code.size(); q.consts = d_consts;
     q.cols = (const void* const*)d_cols; q.rot_off = (const uint32_t*)d_rot; q.size_log = size_log; q.out = a->out;
     q.uses_xpow = P.uses_xpow ? 1 : 0;
     q.xpow_mul = cm ? 1u << (P.ek - P.k) : 1u;
@@ -809,11 +983,13 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
     const uint32_t lds_slots = P.n_slots > QUOT_NREG ? P.n_slots - QUOT_NREG : 0;
     while (T > 64 && (size_t)lds_slots * T * 32 > 32 * 1024) T >>= 1;
     if (T < 1) T = 1;
-    const uint32_t NR = (ctx->tune.quot_rows >= 2 && rows % ((size_t)T * 2) == 0) ? 2u : 1u;      // rows per thread
-    const size_t lds = (size_t)lds_slots * T * 32 * NR;
+    const uint32_t NR = (!l29 && ctx->tune.quot_rows >= 2 && rows % ((size_t)T * 2) == 0) ? 2u : 1u;      // rows per thread
+    const size_t lds = l29 ? (size_t)lds_slots * T * 36 + 16 : (size_t)lds_slots * T * 32 * NR;
+    q.lds_slots = lds_slots;
     if (lds > 160 * 1024) return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %zu bytes of LDS", lds);
     EvTimer tq(ctx, "quotient");
-    if (NR == 2) { ZK_LAUNCH(quotient_kernel<2>, (uint32_t)(rows / T / 2), T, lds, st, q); }
+    if (l29) { ZK_LAUNCH(quotient29_kernel, (uint32_t)(rows / T), T, lds, st, q); if (ctx->timing) ctx->last_ms["quotient29_launches"] += 1.0; }
+    else if (NR == 2) { ZK_LAUNCH(quotient_kernel<2>, (uint32_t)(rows / T / 2), T, lds, st, q); }
     else { ZK_LAUNCH(quotient_kernel<1>, (uint32_t)(rows / T), T, lds, st, q); }
     ZK_CHECK_LAUNCH();
     tq.stop();

@@ -190,3 +190,27 @@ def test_msm_linearity_and_ntt_roundtrip_at_bench_sizes(gpu, orc, pyref):
 def test_run_length_msm_gpu(gpu, orc, pyref):
     from test_emu_kernels import _check_run_length_msm
     _check_run_length_msm(gpu, orc, pyref, 40000)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_ntt_and_domain_on_the_other_limb_forms(gpu, orc, pyref, mode):
+    """ntt_limb29 0 (all passes 32-bit) and 2 (all passes on 29-bit limbs) against the oracle; 1 — strided passes 29-bit, final pass 32-bit — is the default everywhere else"""
+    gpu.tune(ntt_limb29=mode)
+    try:
+        for log_n in (4, 10, 14, 17):
+            pc.check_ntt(gpu, orc, pyref, log_n, seed=40 + log_n)
+        pc.check_domain(gpu, orc, pyref, 5, 12)
+        pc.check_domain_batch(gpu, orc, pyref, 4, 6, 3)
+        gpu.tune(ntt_full_twiddle_max_log=0)
+        pc.check_ntt(gpu, orc, pyref, 14, seed=7)
+    finally:
+        gpu.tune(ntt_limb29=1, ntt_full_twiddle_max_log=24)
+
+
+def test_msm_on_the_32_bit_bucket_chain(gpu, orc, pyref):
+    gpu.tune(msm_limb29=0)
+    try:
+        for n in (100, 4096, 20000):
+            pc.check_msm(gpu, orc, pyref, n, seed=900 + n)
+    finally:
+        gpu.tune(msm_limb29=1)

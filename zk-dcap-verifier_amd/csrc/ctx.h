@@ -43,7 +43,7 @@ struct Tune {
 #endif
     int vec_block = 256;
     int quot_threads = 128;
-    int quot_limb29 = 0;         // 1: quotient interpreter on carry-free 29-bit limbs (quotient29_kernel) — measured SLOWER than the 32-bit interpreter (11.1 vs 9.4 ms per proof, profiles/r03): kept selectable, off
+    int quot_limb29 = 0;         // 1: quotient interpreter on carry-free 29-bit limbs (quotient29_kernel) — measured SLOWER than the 32-bit interpreter (9.9 vs 9.4 ms per proof, profiles/r03 run99): kept selectable, off
     int quot_rows = 1;           // rows per thread of the quotient interpreter (2: one micro-op decode serves two rows)
     int quot_remat_ops = 4;      // quotient compiler: a shared sub-expression of at most this many operations ...
     int quot_remat_distance = 24;   // ... is recomputed when its previous copy lies further back than this many micro-ops

@@ -201,20 +201,23 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_k
 // has N-form limbs and every product sees N-form operands.  One product with 2^256 mod p takes the row's result back to the library's form.
 // w0 of a 29-bit instruction: op [0,8) | writes the accumulator [8] | bias class [9,13) | reduce the result [13] | slot [16,32).
 // ------------------------------------------------------------------------------------------------
-struct Bias29Table { uint32_t l[10][9]; };
-constexpr Bias29Table make_bias29_table() {
-    Bias29Table t{};
-    for (int c = 0; c < 10; c++) {
-        const Fr29::Limbs9 b = Fr29::bias(2u << c, 30);               // K = 2^(c + 1): 2, 4, ..., 1024
-        for (int i = 0; i < 9; i++) t.l[c][i] = b.l[i];
-    }
+// K p for K = 2^(cls + 1), written so that every limb 0..7 dominates an N-form limb: digits of (2p << cls) plus 2^30 on limbs 0..7, each 2^30 paid for by 2 units of
+// the next limb (2^30 * 2^(29 i) = 2 * 2^(29 (i + 1))).  Computed from the compile-time digits of 2p and the UNIFORM class with a few scalar shifts — a table in
+// constant memory cost a scalar load + a full s_waitcnt per subtraction (35 % of the wave cycles parked, profiles/r03 run98).
+struct TwoP29 { uint32_t d[9]; };
+constexpr TwoP29 make_two_p29() {
+    TwoP29 t{};
+    uint32_t carry = 0;
+    for (int i = 0; i < 9; i++) { const uint32_t v = 2u * Fr29::p29(i) + carry; t.d[i] = i < 8 ? (v & Fr29::M29) : v; carry = i < 8 ? v >> 29 : 0; }
     return t;
 }
-#ifdef ZK_EMU
-static const Bias29Table BIAS29 = make_bias29_table();
-#else
-__constant__ const Bias29Table BIAS29 = make_bias29_table();
-#endif
+ZK_HD uint32_t bias29_limb(int i, uint32_t cls) {                       // limb i of the dominant form of 2^(cls + 1) p, cls <= 7
+    constexpr TwoP29 tp = make_two_p29();
+    uint32_t digit = tp.d[i] << cls;                                   // (2p << cls): this limb's bits shifted up, the previous limb's top bits shifted in
+    if (i > 0) digit |= tp.d[i - 1] >> (29 - cls);
+    if (i < 8) digit &= Fr29::M29;
+    return digit + (i < 8 ? (1u << 30) : 0u) - (i > 0 ? 2u : 0u);
+}
 
 ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) quotient29_kernel(QuotArgs q) {
     ZK_DYN_SHARED(uint4, smem);
@@ -256,7 +259,7 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) quotient29_kernel(QuotAr
     auto biased = [&](const u261& a, const u261& b, uint32_t cls, bool with_a) -> u261 {   // a - b + K p (or K p - b), K = 2^(cls + 1)
         u261 o;
 #pragma unroll
-        for (int i = 0; i < 9; i++) o.l[i] = (with_a ? a.l[i] : 0u) + BIAS29.l[cls][i] - b.l[i];
+        for (int i = 0; i < 9; i++) o.l[i] = (with_a ? a.l[i] : 0u) + bias29_limb(i, cls) - b.l[i];
         return o;
     };
     uint4 ins = q.n_instr ? q.code[0] : make_uint4(M_MOV | (1u << 8), K_NONE << 28, K_NONE << 28, K_NONE << 28);

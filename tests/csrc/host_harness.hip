@@ -16,6 +16,7 @@ static void f29_raw(int op, const u261* a, const u261* b, const u261* c, const u
             case 6: o[i] = F29::template sub_bias<5, 31>(a[i], b[i]); break;
             case 7: o[i] = F29::template neg_bias<3, 30>(a[i]); break;
             case 8: o[i] = F29::add(a[i], F29::dbl(b[i])); break;
+            case 10: o[i] = F29::mul_shoup(a[i], b[i], c[i]); break;                                               // a * w with w's precomputed quotient
             default: o[i] = F29::one(); break;
         }
     }
@@ -28,6 +29,7 @@ static void f29_forms(int op, const u256* a, const u256* b, u256* o, u261* o9, s
             case 1: o9[i] = F29::mul(F29::enter(a[i]), F29::enter(b[i])); o[i] = F29::leave(o9[i]); break;     // a * b in the library's form
             case 2: o9[i] = F29::mul(F29::template from32<5>(a[i]), F29::enter(b[i])); o[i] = F29::leave(o9[i]); break;   // the shifted conversion as one operand
             case 3: o9[i] = F29::template from32<0>(a[i]); o[i] = F29::to32(o9[i]); break;                      // limb conversion alone
+            case 5: o9[i] = F29::shoup_quotient(a[i]); o[i] = a[i]; break;                                        // floor(a 2^261 / p)
             default: o9[i] = F29::sqr(F29::enter(a[i])); o[i] = F29::leave(o9[i]); break;
         }
     }

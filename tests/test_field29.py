@@ -163,6 +163,60 @@ def test_between_the_two_montgomery_forms(hh, orc, pyref, field):
     assert got == xs and all(value(l) == x and all(v <= M29 for v in l[:8]) for l, x in zip(l9, xs))               # limb conversion is exact
 
 
+def model_shoup(mod, a, w, wq):
+    """the generated body, column for column: q from columns 7 .. 16 of a * wq, r = low 261 bits of a * w + q * (2^261 - p)"""
+    npl = limbs_of(RAD - mod)
+    acc, q = 0, [0] * 9
+    for k in range(7, 17):
+        acc += sum(a[i] * wq[k - i] for i in range(max(0, k - 8), min(k, 8) + 1))
+        assert acc < 1 << 64
+        if k >= 9:
+            q[k - 9] = acc & M29
+        acc >>= 29
+    q[8] = acc
+    assert acc < 1 << 32
+    acc, r = 0, [0] * 9
+    for k in range(9):
+        acc += sum(a[i] * w[k - i] + q[i] * npl[k - i] for i in range(k + 1))
+        assert acc < 1 << 64
+        r[k] = acc & M29
+        acc >>= 29
+    return r, q
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_shoup_product_with_a_precomputed_quotient(hh, orc, pyref, field):
+    """mul_shoup: a * w mod p for a constant w, wq = floor(w 2^261 / p) — what the NTT butterflies multiply their twiddles with.  shoup_quotient is exact; the product equals the
+    column model limb for limb, is congruent to a * w, below 3 p, for every a below 2^261 with limbs up to 2^30 (q is the true quotient or one below)."""
+    mod = pyref.P if field == 0 else pyref.R
+    rnd = random.Random(41 + field)
+    ws = [0, 1, 2, mod - 1, mod - 2, (mod + 1) // 2, 1 << 253] + [rnd.randrange(0, mod) for _ in range(80)]
+    W = orc.ints_to_limbs(ws)
+    o, o9 = np.zeros_like(W), np.zeros((len(ws), 9), dtype=np.uint32)
+    hh.hh_f29_forms(C.c_int(field), C.c_int(5), P(W), P(W), P(o), P(o9), C.c_size_t(len(ws)))
+    wq = [[int(v) for v in row] for row in o9]
+    assert [value(l) for l in wq] == [w * RAD // mod for w in ws] and all(v <= M29 for l in wq for v in l)
+    avals = [0, 1, mod - 1, mod, 3 * mod - 1, 32 * mod, 150 * mod, RAD - 1] + [rnd.randrange(0, RAD) for _ in range(40)] + [rnd.randrange(0, 8 * mod) for _ in range(40)]
+    A, Wl, Wq = [], [], []
+    for j in range(len(ws)):
+        for loose in (None, 30):
+            a = rnd.choice(avals)
+            A.append(limbs_of(a, loose, rnd)); Wl.append(limbs_of(ws[j])); Wq.append(wq[j])
+    A.append([(1 << 30) - 1] * 8 + [(1 << 28) - 1]); Wl.append(limbs_of(mod - 1)); Wq.append(limbs_of((mod - 1) * RAD // mod))     # every limb at its bound (the integer is still below 2^261)
+    assert value(A[-1]) < RAD
+    got = run_raw(hh, field, 10, A, Wl, Wq)
+    low = 0
+    for a, w, q_, g in zip(A, Wl, Wq, got):
+        want, q = model_shoup(mod, a, w, q_)
+        va, vw = value(a), value(w)
+        assert g == want and all(v <= M29 for v in g)
+        assert value(g) % mod == va * vw % mod and value(g) < 3 * mod
+        exact = va * value(q_) // RAD
+        assert value(q) in (exact, exact - 1) and value(g) == va * vw - value(q) * mod
+        low += value(q) != exact
+    print("quotient one below the exact one in", low, "of", len(A))
+
+
 def _affine(orc, p, xyzz16):
     x, y, zz, zzz = orc.limbs_to_ints(xyzz16.reshape(4, 4))
     if zz == 0:

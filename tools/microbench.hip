@@ -125,6 +125,14 @@ __global__ void k_mont29(uint32_t* out, uint32_t seed) {
     for (int i = 0; i < ITER / 4; i++) { x = Fq29::mul(x, y); y = Fq29::mul(y, x); }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ y.l[3] ^ x.l[8];
 }
+__global__ void k_shoup29(uint32_t* out, uint32_t seed) {            // a * w with w's precomputed quotient (field29.cuh mul_shoup): the NTT's twiddle product
+    u256 x0 = Fq::one(), w0 = Fq::R2(), w1 = Fq::one();
+    x0.v[0] ^= threadIdx.x + seed; w1.v[1] ^= blockIdx.x;
+    u261 x = Fq29::from32<0>(Fq::reduce_once(x0));
+    const u261 wa = Fq29::from32<0>(w0), wb = Fq29::from32<0>(w1), qa = Fq29::shoup_quotient(w0), qb = Fq29::shoup_quotient(w1);
+    for (int i = 0; i < ITER / 4; i++) { x = Fq29::mul_shoup(x, wa, qa); x = Fq29::mul_shoup(x, wb, qb); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ x.l[3] ^ x.l[8];
+}
 __global__ void k_sqr29(uint32_t* out, uint32_t seed) {
     u256 x0 = Fq::one(), y0 = Fq::R2();
     x0.v[0] ^= threadIdx.x + seed; y0.v[1] ^= blockIdx.x;
@@ -322,6 +330,7 @@ int main(int argc, char** argv) {
         run("fq_mul_cios", k_fqmul_cios, 2.0 * (ITER / 4), 256, bpc);
         run("fq29_mul (9 x 29-bit limbs)", k_mont29, 2.0 * (ITER / 4), 256, bpc);
         run("fq29_sqr", k_sqr29, 2.0 * (ITER / 4), 256, bpc);
+        run("fq29_mul_shoup (constant operand, precomputed quotient)", k_shoup29, 2.0 * (ITER / 4), 256, bpc);
         run("fq_addsub", k_fqadd, 2.0 * ITER, 256, bpc);
     }
     for (int bpc : {1, 2, 4}) run("xyzz_madd", k_madd, 1.0 * (ITER / 8), 256, bpc);

@@ -37,6 +37,8 @@ struct Field29 {
         if (sh > 35 && w + 1 < 4) v |= FP::P[w + 1] << (64 - sh);
         return (uint32_t)(v & M29);
     }
+    // limb i of 2^261 - p (the Shoup product adds q * (2^261 - p) where a Montgomery product adds m * p)
+    static ZK_HD constexpr uint32_t np29(int i) { return i == 0 ? (1u << 29) - p29(0) : M29 - p29(i); }
     struct Limbs9 { uint32_t l[9]; };
     // x (four 64-bit words, below 2^256) in base 2^29
     static constexpr Limbs9 digits_of(const uint64_t (&x)[4]) {
@@ -125,6 +127,62 @@ struct Field29 {
         u261 r;
 #include "field29_mul2_body.inc"
         return r;
+    }
+
+    // a * w mod p for a CONSTANT w (a twiddle factor): w canonical, wq = shoup_quotient(w) = floor(w 2^261 / p).  q = floor(a wq / 2^261) is taken from the columns 7 .. 16
+    // of a * wq only — the columns below add less than 2^-26 of a unit, so q is the true quotient or one below — and r = a w - q p is read off the low 261 bits of
+    // a w + q (2^261 - p).  For any a below 2^261 (limbs below 2^30): r is N-form with limbs below 2^29, congruent to a w, below 3 p.  143 mads against the 162 + 9 multiplications of
+    // the Montgomery product, and NO Montgomery factor: a, r stay in whatever form a is in.
+    static ZK_HD u261 mul_shoup(const u261& a, const u261& w, const u261& wq) {
+        uint64_t acc = 0;
+        uint32_t q[9];
+        u261 r;
+#include "field29_shoup_body.inc"
+        return r;
+    }
+    // p^-1 mod 2^261 (Hensel, bit by bit), as limbs
+    static constexpr Limbs9 pinv261() {
+        uint64_t x[5] = {0, 0, 0, 0, 0}, px[5] = {0, 0, 0, 0, 0};        // px = p * x mod 2^320
+        for (int bit = 0; bit < 261; bit++) {
+            const uint64_t have = (px[bit / 64] >> (bit % 64)) & 1, want = bit == 0 ? 1 : 0;
+            if (have == want) continue;
+            x[bit / 64] |= (uint64_t)1 << (bit % 64);
+            uint64_t sh[5] = {0, 0, 0, 0, 0};                             // p << bit
+            for (int i = 0; i < 4; i++) {
+                const int w = i + bit / 64, s = bit % 64;
+                if (w < 5) sh[w] |= FP::P[i] << s;
+                if (s && w + 1 < 5) sh[w + 1] |= FP::P[i] >> (64 - s);
+            }
+            uint64_t c = 0;
+            for (int i = 0; i < 5; i++) { const uint64_t t = px[i] + sh[i], t2 = t + c; c = (t < px[i] || t2 < t) ? 1 : 0; px[i] = t2; }
+        }
+        Limbs9 o{};
+        for (int i = 0; i < 9; i++) {
+            const int bit = i * 29, w = bit / 64, s = bit % 64;
+            uint64_t v = x[w] >> s;
+            if (s > 35 && w + 1 < 5) v |= x[w + 1] << (64 - s);
+            o.l[i] = (uint32_t)(v & M29);
+        }
+        return o;
+    }
+    // floor(w 2^261 / p) for a canonical w: w 2^261 = wq p + rho with rho = w 2^261 mod p (a Montgomery product with 2^522 mod p, made canonical), hence wq = -rho p^-1 mod 2^261
+    static ZK_HD u261 shoup_quotient(const u256& w) {
+        constexpr Limbs9 c522 = pow2_mod_p(522), pinv = pinv261();
+        const u261 rho = from32<0>(F32::reduce_once(to32(mul(from32<0>(w), constant(c522)))));     // (the product is below 2 p)
+        uint32_t nr[9];                                                // 2^261 - rho (rho = 0 only for w = 0: every limb wraps to 0, wq = 0)
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { const uint32_t t = 0u - rho.l[i] - borrow; nr[i] = t & M29; borrow = (rho.l[i] | borrow) ? 1 : 0; }
+        u261 o;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) acc += (uint64_t)nr[i] * pinv.l[k - i];
+            o.l[k] = (uint32_t)acc & M29;
+            acc >>= 29;
+        }
+        return o;
     }
 
     // ---- sums -----------------------------------------------------------------------------------------------------------------------------------------------------

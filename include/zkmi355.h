@@ -251,6 +251,13 @@ int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args
 int zk_quotient_run_coset_rows_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset, uint64_t row_lo, uint64_t row_count);
 int zk_coeff_to_coset_batch_dev(zk_ctx* ctx, const void* const* coeffs_dev, void* const* outs_dev, size_t count, uint32_t k, uint32_t extended_k, uint32_t coset);
 int zk_fr_interleave_dev(zk_ctx* ctx, const void* const* cosets_dev, size_t count, size_t n, void* out_dev);   /* out[i * count + j] = cosets[j][i] */
+/* The pieces of h(X) straight from the numerator's values on cosets 0 .. pieces-1 (vanishing::Argument::construct: divide_by_vanishing_poly + extended_to_coeff + the split
+ * into cs_degree - 1 polynomials of n coefficients).  deg h < pieces * n, and on coset j X^n is a constant s_j, so `pieces` cosets determine h: per coset one inverse size-n
+ * transform, then a pieces x pieces Vandermonde solve per coefficient index.  The 2^(extended_k - k) - pieces other cosets of the extended domain need never be evaluated —
+ * a quarter of the extended transforms and of the quotient rows at cs_degree = 4 (halo2-lib circuits), nothing when cs_degree - 1 is a power of two (the sgx circuit: 5).
+ * numer_dev[j]: n values (DEVICE, clobbered), out_dev[i]: n coefficients (DEVICE, distinct buffers).  pieces <= min(8, 2^(extended_k - k)).  Same field elements as the
+ * extended route (h is unique). */
+int zk_cosets_to_pieces_dev(zk_ctx* ctx, void* const* numer_dev, uint32_t pieces, uint32_t k, uint32_t extended_k, void* const* out_dev);
 
 /* proving-key level form — the shape of halo2's own call (polynomials in, polynomial out):
  * zk_pk_load uploads what keygen_pk holds for the evaluator — fixed columns, permutation (sigma) columns, l0, l_last,
@@ -322,6 +329,8 @@ typedef struct zk_plonk_pk_desc {
     const void* const* coset_fixed;           /* [this rank's cosets][n_fixed]        DEVICE, n x 32 B each */
     const void* const* coset_sigma;           /* [this rank's cosets][n_perm_columns]                         */
     const void* const* coset_l;               /* [this rank's cosets][3]: l0, l_last, l_active_row            */
+    /* shard_world <= 1 with coset_l set and cs_degree - 1 < 2^(extended_k - k): the three arrays hold cosets 0 .. cs_degree-2 and the extended forms above are not read —
+     * the numerator is evaluated on those cosets only and the pieces of h(X) come from zk_cosets_to_pieces_dev (what zk_plonk_pk_build sets up by default) */
 } zk_plonk_pk_desc;
 /* the caller's RNG (`&mut rng` of create_proof): fill out_fr with n uniform field elements as Montgomery limbs (n x 32 B).  Called from a helper thread of the
  * library, once per Fr::random block.  draw_schedule 1 follows halo2_proofs v2023_01_20 draw by draw ([3P-MEM]) — including the Blind(Fr::random) every

@@ -20,10 +20,11 @@ def _run(exe, path, tune=None, world=None):
     return subprocess.run([os.path.join(ROOT, "tests", "csrc", exe), str(path)] + ([str(world)] if world else []), capture_output=True, text=True, timeout=900, env=env)
 
 
-@pytest.mark.parametrize("which,sched", [("toy", 1), ("toy", 0), ("sgx", 1)])
+@pytest.mark.parametrize("which,sched", [("toy", 1), ("toy", 0), ("sgx", 1), ("p256", 1)])
 def test_plain_c_prover_reproduces_the_goldens_emulated(emu, orc, tmp_path, which, sched):
+    """("p256": a degree-4 circuit — zk_plonk_pk_build keeps three cosets of the key instead of its extended forms and the prover takes h(X) from them: tests/test_piece_cosets.py)"""
     import dump_pk_blob as dp
-    blob = dp.toy_blob(emu, 6, 7, sched) if which == "toy" else dp.sgx_blob(emu, 8, 3, "chip_estimate", sched)
+    blob = dp.toy_blob(emu, 6, 7, sched) if which == "toy" else dp.p256_blob(emu, 7, 18, sched) if which == "p256" else dp.sgx_blob(emu, 8, 3, "chip_estimate", sched)
     path = tmp_path / "pk.zkpk"
     path.write_bytes(blob)
     r = _run("capi_prove_emu", path, EMU_TUNE)
@@ -53,10 +54,10 @@ def test_plain_c_prover_has_no_cpu_fallback(emu, orc, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which,k", [("toy", 6), ("sgx", 8), ("sgx", 12)])
+@pytest.mark.parametrize("which,k", [("toy", 6), ("sgx", 8), ("sgx", 12), ("p256", 10)])
 def test_plain_c_prover_on_gpu(gpu, orc, tmp_path, which, k):
     import dump_pk_blob as dp
-    blob = dp.toy_blob(gpu, 6, 7) if which == "toy" else dp.sgx_blob(gpu, k, 3)
+    blob = dp.toy_blob(gpu, 6, 7) if which == "toy" else dp.p256_blob(gpu, k, 18) if which == "p256" else dp.sgx_blob(gpu, k, 3)
     path = tmp_path / "pk.zkpk"
     path.write_bytes(blob)
     r = _run("capi_prove", path, world=4 if k <= 8 else None)       # then 4 ranks (4 contexts on the one GPU): a coset of the quotient each

@@ -17,7 +17,7 @@ ZKPK1 layout (little endian, every section 8-byte aligned):
     u64 n_draws | n_draws x 32 B   — the caller's Fr::random stream in the order create_proof asks for it (the C program's zk_rng_fn serves it sequentially)
     u64 proof_len | expected proof bytes (the golden of the independent CPU prover when the circuit has one)
 
-usage: dump_pk_blob.py OUT.zkpk [toy|sgx] [k] [seed]     (runs keygen on the emulator build when no GPU is present — setup only; the C program does the proving)
+usage: dump_pk_blob.py OUT.zkpk [toy|sgx|p256] [k] [seed]     (runs keygen on the emulator build when no GPU is present — setup only; the C program does the proving)
 """
 import os
 import struct
@@ -102,6 +102,13 @@ def sgx_blob(be, k=8, seed=3, census="chip_estimate", draw_schedule=1) -> bytes:
     return build_blob(be, cs, fixed, asm, adv, [], k, t.TAU, seed, draw_schedule, golden)
 
 
+def p256_blob(be, k=7, seed=18, draw_schedule=1) -> bytes:
+    """the census of the reference's stack-B circuit (degree 4: three h pieces, so zk_plonk_pk_build keeps three cosets of the key's columns and no extended form)"""
+    import test_create_proof as t
+    cs, fixed, asm, advice, instances = t.p256_shaped_circuit(k)
+    return build_blob(be, cs, fixed, asm, advice, instances, k, t.TAU, seed, draw_schedule, None)
+
+
 def main():
     import zk_dcap_verifier_amd as z
     out = sys.argv[1]
@@ -113,7 +120,7 @@ def main():
         be.tune(msm_sort_threads=64, msm_sort_wgs=3, msm_block=32, ntt_threads=32, ntt_tile_log=6, ntt_max_radix_log=4, msm_target_threads=64, msm_min_chunk=2, vec_block=32, quot_threads=32)
     k = int(sys.argv[3]) if len(sys.argv) > 3 else (6 if which == "toy" else 8)
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else (7 if which == "toy" else 3)
-    blob = toy_blob(be, k, seed) if which == "toy" else sgx_blob(be, k, seed)
+    blob = toy_blob(be, k, seed) if which == "toy" else p256_blob(be, k, seed) if which == "p256" else sgx_blob(be, k, seed)
     open(out, "wb").write(blob)
     print("wrote", out, len(blob), "bytes")
 

@@ -21,12 +21,23 @@ def main():
     if tune:
         be.tune(**tune)
     out = {"k": k, "tune": tune, "host_witness": os.environ.get("ZK_HOST_WITNESS") == "1"}
-    t = time.time(); cs, fixed, asm, advice = sc.build(z, be, k, census=os.environ.get("ZK_CENSUS", "chip_estimate")); out["census"] = os.environ.get("ZK_CENSUS", "chip_estimate"); out["build_witness_s"] = round(time.time() - t, 3)
+    census = os.environ.get("ZK_CENSUS", "chip_estimate")
+    instances = []
+    t = time.time()
+    if census == "p256":                               # BASELINE configs[0]: the reference's stack-B circuit shape (crates/p256-ecdsa, k = 18; degree 4, 3 advice, 1 lookup, 15 instance values)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_create_proof as tcp
+        cs, fixed, asm, advice, instances = tcp.p256_shaped_circuit(k)
+    else:
+        cs, fixed, asm, advice = sc.build(z, be, k, census=census)
+    out["census"] = census; out["build_witness_s"] = round(time.time() - t, 3)
     t = time.time(); params = z.kzg.ParamsKZG.setup(k, TAU, backend=be); out["srs_setup_s"] = round(time.time() - t, 3)
     if os.environ.get("ZK_BY_COSETS") == "1":          # the multi-GPU quotient unit on one GPU: 2^(ek-k) coset NTTs of size n instead of one of size 2^ek
         params.quotient_by_cosets = True
         out["quotient_by_cosets"] = True
-    t = time.time(); pk = z.plonk.keygen(params, cs, fixed, asm); out["keygen_s"] = round(time.time() - t, 3)
+    piece_cosets = os.environ.get("ZK_PIECE_COSETS", "1") != "0"      # 0: keep the extended forms although cs_degree - 1 cosets would do (A/B of zk_cosets_to_pieces_dev)
+    t = time.time(); pk = z.plonk.keygen(params, cs, fixed, asm, piece_cosets=piece_cosets); out["keygen_s"] = round(time.time() - t, 3)
+    out["pieces_from_cosets"] = pk.pieces_from_cosets
     out["program"] = be.quotient_program_info(pk.evaluator.handle)
     out["program"]["opmix"] = be.quotient_program_opmix(pk.evaluator.handle)
     n = 1 << k
@@ -45,19 +56,19 @@ def main():
         tr = Blake2bWrite()
         tm = {}
         if native:
-            proof = native.create_proof(advice if host_witness else work, [], np.random.default_rng(r))
+            proof = native.create_proof(advice if host_witness else work, instances, np.random.default_rng(r))
             tm, info = dict(native.phase_ms), {"proof_bytes": len(proof)}
         else:
-            info = z.plonk.create_proof(params, pk, advice if host_witness else work, [], np.random.default_rng(r), tr, timings=tm)
+            info = z.plonk.create_proof(params, pk, advice if host_witness else work, instances, np.random.default_rng(r), tr, timings=tm)
             proof = tr.finalize()
         times.append(time.time() - t)
     be.timing(True)                                    # once more with HIP-event kernel timing (alone on the GPU: the event pairs bracket only this proof's kernels)
     for w, m in zip(work, master):
         w.copy_from(m)
     if native:
-        native.create_proof(work, [], np.random.default_rng(99))
+        native.create_proof(work, instances, np.random.default_rng(99))
     else:
-        z.plonk.create_proof(params, pk, work, [], np.random.default_rng(99), Blake2bWrite())
+        z.plonk.create_proof(params, pk, work, instances, np.random.default_rng(99), Blake2bWrite())
     out["kernel_ms"] = {lab: round(be.timing_get(lab)[0] or 0.0, 3) for lab in ("msm_sort", "msm_accumulate", "msm_reduce", "quotient")}
     out["msm_pairs"] = be.stat_get("msm_pairs")
     be.timing(False)

@@ -358,6 +358,11 @@ class Backend:
     def fr_interleave_dev(self, cosets, n: int, out_dev):
         self._ck(self.lib.zk_fr_interleave_dev(self.ctx, self._ptr_array(cosets), C.c_size_t(len(cosets)), C.c_size_t(n), C.c_void_p(_dptr(out_dev))))
 
+    def cosets_to_pieces_dev(self, numer, k, ek, out):
+        """numer[j] = the numerator's n values on coset j (clobbered), j < len(numer) = cs_degree - 1; out[i] receives piece i of h(X) (zk_cosets_to_pieces_dev)"""
+        assert len(numer) == len(out)
+        self._ck(self.lib.zk_cosets_to_pieces_dev(self.ctx, self._ptr_array(numer), C.c_uint32(len(numer)), C.c_uint32(k), C.c_uint32(ek), self._ptr_array(out)))
+
     def coeff_to_extended_dev(self, coeff_dev, k, ek, out_dev):
         self._ck(self.lib.zk_coeff_to_extended_dev(self.ctx, C.c_void_p(_dptr(coeff_dev)), C.c_uint32(k), C.c_uint32(ek), C.c_void_p(_dptr(out_dev))))
 

@@ -47,6 +47,7 @@ int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]);
 int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, int coset, uint64_t row_lo, uint64_t row_count);
 int domain_coeff_to_coset_batch(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek, uint32_t coset);
 int fr_interleave(zk_ctx* ctx, const void* const* h_cosets, size_t count, size_t n, void* d_out);
+int domain_cosets_to_pieces(zk_ctx* ctx, void* const* h_numer, uint32_t q, uint32_t k, uint32_t ek, void* const* h_pieces);
 }  // namespace zk
 using namespace zk;
 
@@ -113,7 +114,7 @@ static int* tune_slot(zk_ctx* ctx, const char* key) {
         {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block}, {"msm_limb29", &t.msm_limb29}, {"msm_acc_waves", &t.msm_acc_waves}, {"msm_runs", &t.msm_runs},
         {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log},
         {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}, {"lookup_force_generic_sort", &t.lookup_force_generic_sort},
-        {"ntt_quarter_input", &t.ntt_quarter_input}, {"ntt_limb29", &t.ntt_limb29}, {"ntt_waves", &t.ntt_waves}, {"ntt_ws_limit_mb", &t.ntt_ws_limit_mb}, 
+        {"ntt_quarter_input", &t.ntt_quarter_input}, {"ntt_limb29", &t.ntt_limb29}, {"ntt_waves", &t.ntt_waves}, {"quot_piece_cosets", &t.quot_piece_cosets}, {"ntt_ws_limit_mb", &t.ntt_ws_limit_mb}, 
 #ifdef ZK_NTT_PROBE
         {"ntt_debug_mode", &t.ntt_debug_mode},
 #endif
@@ -265,6 +266,7 @@ int zk_coeff_to_coset_batch_dev(zk_ctx* ctx, const void* const* coeffs, void* co
     ENTER; int rc = domain_coeff_to_coset_batch(ctx, coeffs, outs, count, k, ek, coset); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK;
 }
 int zk_fr_interleave_dev(zk_ctx* ctx, const void* const* cosets, size_t count, size_t n, void* out) { ENTER; return fr_interleave(ctx, cosets, count, n, out); }
+int zk_cosets_to_pieces_dev(zk_ctx* ctx, void* const* numer, uint32_t pieces, uint32_t k, uint32_t ek, void* const* out) { ENTER; return domain_cosets_to_pieces(ctx, numer, pieces, k, ek, out); }
 int zk_lagrange_to_coeff_dev(zk_ctx* ctx, void* a, uint32_t k) { ENTER; int rc = domain_lagrange_to_coeff(ctx, a, k); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
 int zk_coeff_to_lagrange_dev(zk_ctx* ctx, void* a, uint32_t k) { ENTER; int rc = domain_coeff_to_lagrange(ctx, a, k); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }
 int zk_coeff_to_extended_dev(zk_ctx* ctx, const void* c, uint32_t k, uint32_t ek, void* out) { ENTER; int rc = domain_coeff_to_extended(ctx, c, k, ek, out); if (rc) return rc; ZK_HIP(hipStreamSynchronize(ctx->stream)); return ZK_OK; }

@@ -43,6 +43,7 @@ struct Tune {
 #endif
     int vec_block = 256;
     int quot_threads = 128;
+    int quot_piece_cosets = 1;   // zk_plonk_pk_build on one GPU: keep cosets 0 .. cs_degree-2 of the key's columns instead of their extended forms when cs_degree - 1 < 2^(extended_k - k) (zk_cosets_to_pieces_dev)
     int quot_limb29 = 0;         // 1: quotient interpreter on carry-free 29-bit limbs (quotient29_kernel) — measured SLOWER than the 32-bit interpreter (9.9 vs 9.4 ms per proof, profiles/r03 run99): kept selectable, off
     int quot_rows = 1;           // rows per thread of the quotient interpreter (2: one micro-op decode serves two rows)
     int quot_remat_ops = 4;      // quotient compiler: a shared sub-expression of at most this many operations ...

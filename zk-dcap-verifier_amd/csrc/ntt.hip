@@ -830,6 +830,95 @@ int fr_interleave(zk_ctx* ctx, const void* const* h_cosets, size_t count, size_t
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     return ZK_OK;
 }
+// ---- h(X) from its numerator on q of the 2^(ek-k) cosets ---------------------------------------------------------------------------------------------------
+// h = N / (X^n - 1) has degree below q n, q = cs_degree - 1 pieces: h = sum_i X^(n i) h_i.  On coset j of the extended domain, X = c_j w^r with c_j = ZETA ext_omega^j, X^n is
+// the constant s_j = c_j^n, so the coset's values of h are those of G_j = sum_i s_j^i h_i, a polynomial of degree below n: an inverse size-n transform of N_j / (s_j - 1) gives
+// c_j^m G_j[m], and for every coefficient index m the q values G_j[m] determine h_0[m] .. h_{q-1}[m] through the q x q Vandermonde matrix in s_j.  So q cosets are enough —
+// the 2^(ek-k) - q others of EvaluationDomain's extended domain carry no information about h (they exist because its size is a power of two) — and the pieces come out directly:
+//   piece_i[m] = sum_j W[i][j] ZETA^-(m mod 3) ext_omega^(-j m) a_j[m],   a_j = iNTT_n(N_j),   W = V^-1 diag(1 / (s_j - 1)),  V[j][i] = s_j^i.
+// Same field elements as divide_by_vanishing_poly + extended_to_coeff on all cosets (h is unique), at q / 2^(ek-k) of the transforms and of the quotient rows.
+ZK_KERNEL void coset_combine_kernel(const void* const* a, void* const* out, const void* wz, const void* tw_lo, const void* tw_hi, uint32_t lo_bits, uint32_t ek, uint32_t q, size_t n) {
+    const uint32_t piece = blockIdx.y;
+    const uint32_t mask = (1u << ek) - 1u, lomask = (1u << lo_bits) - 1u;
+    size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; m < n; m += stride) {
+        const uint32_t z = (uint32_t)(m % 3);
+        u256 acc = Fr::zero();
+        for (uint32_t j = 0; j < q; j++) {
+            u256 v = load_u256(a[j], m);
+            const uint32_t e = (0u - j * (uint32_t)m) & mask;          // ext_omega^(-j m)
+            if (e) {
+                u256 w = load_u256(tw_lo, e & lomask);
+                const uint32_t h = e >> lo_bits;
+                if (h) w = Fr::mul(w, load_u256(tw_hi, h));
+                v = Fr::mul(v, w);
+            }
+            acc = Fr::add(acc, Fr::mul(v, load_u256(wz, (size_t)(z * q + piece) * q + j)));
+        }
+        store_u256(out[piece], m, acc);
+    }
+}
+// numer[j]: the n numerator values on coset j (device, CLOBBERED: transformed in place), j < q;  pieces[i]: n coefficients each (device, distinct from numer)
+int domain_cosets_to_pieces(zk_ctx* ctx, void* const* h_numer, uint32_t q, uint32_t k, uint32_t ek, void* const* h_pieces) {
+    if (ek > BN254_FR_S || k > ek || ek - k > 6 || !h_numer || !h_pieces || q < 1 || q > (1u << (ek - k)) || q > 8)
+        return ctx->fail(ZK_ERR_ARG, "zk_cosets_to_pieces_dev: bad k / extended_k / piece count (at most 8 pieces, at most one per coset)");
+    for (uint32_t j = 0; j < q; j++) {
+        if (!h_numer[j] || !h_pieces[j]) return ctx->fail(ZK_ERR_ARG, "zk_cosets_to_pieces_dev: null column %u", j);
+        for (uint32_t i = 0; i < q; i++) if (h_numer[j] == h_pieces[i]) return ctx->fail(ZK_ERR_ARG, "zk_cosets_to_pieces_dev: pieces must not alias the numerators");
+    }
+    int rc = domain_lagrange_to_coeff_batch(ctx, h_numer, q, k);       // a_j (the 1 / n is in there)
+    if (rc) return rc;
+    // W = V^-1 diag(1 / (s_j - 1)) by Gauss-Jordan on [V | I] (q <= 8), then its three ZETA^-z multiples
+    const uint64_t zl[4] = BN254_FR_ZETA_M;
+    const u256 zn = fr_pow2k_host(fr_const(zl), k), won = fr_pow2k_host(domain_omega(ek), k);
+    u256 V[8][16];
+    u256 s = zn, sinv[8];
+    for (uint32_t j = 0; j < q; j++) {
+        u256 pw = Fr::one();
+        for (uint32_t i = 0; i < q; i++) { V[j][i] = pw; pw = Fr::mul(pw, s); V[j][q + i] = i == j ? Fr::one() : Fr::zero(); }
+        sinv[j] = Fr::inv(Fr::sub(s, Fr::one()));                       // s_j != 1: ZETA^n has order 3, (ext_omega^n)^j a power-of-two order
+        s = Fr::mul(s, won);
+    }
+    for (uint32_t c = 0; c < q; c++) {
+        uint32_t piv = c;
+        while (piv < q && Fr::eq(V[piv][c], Fr::zero())) piv++;
+        if (piv == q) return ctx->fail(ZK_ERR_ARG, "zk_cosets_to_pieces_dev: singular Vandermonde matrix");
+        if (piv != c) for (uint32_t i = 0; i < 2 * q; i++) { const u256 t = V[c][i]; V[c][i] = V[piv][i]; V[piv][i] = t; }
+        const u256 inv = Fr::inv(V[c][c]);
+        for (uint32_t i = 0; i < 2 * q; i++) V[c][i] = Fr::mul(V[c][i], inv);
+        for (uint32_t r = 0; r < q; r++) {
+            if (r == c || Fr::eq(V[r][c], Fr::zero())) continue;
+            const u256 f = V[r][c];
+            for (uint32_t i = 0; i < 2 * q; i++) V[r][i] = Fr::sub(V[r][i], Fr::mul(f, V[c][i]));
+        }
+    }
+    std::vector<u256> wz((size_t)3 * q * q);
+    for (uint32_t z = 0; z < 3; z++)
+        for (uint32_t i = 0; i < q; i++)
+            for (uint32_t j = 0; j < q; j++) {
+                u256 w = Fr::mul(V[i][q + j], sinv[j]);
+                if (z) w = Fr::mul(w, zeta_pow(3 - z));                 // ZETA^-z = ZETA^(3 - z)
+                wz[((size_t)z * q + i) * q + j] = w;
+            }
+    const void* lo; const void* hi; uint32_t lo_bits;
+    rc = ntt_pow_tables(ctx, ek, domain_omega(ek), &lo, &hi, &lo_bits);
+    if (rc) return rc;
+    const size_t tab = wz.size() * 32, ptrs = 2 * (size_t)q * sizeof(void*);
+    ZK_HIP(ctx->ws_tmp.ensure(tab + ptrs + 64));
+    std::vector<const void*> pa(2 * q);
+    for (uint32_t j = 0; j < q; j++) { pa[j] = h_numer[j]; pa[q + j] = h_pieces[j]; }
+    ZK_HIP(hipMemcpyAsync(ctx->ws_tmp.p, wz.data(), tab, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipMemcpyAsync((char*)ctx->ws_tmp.p + tab, pa.data(), ptrs, hipMemcpyHostToDevice, ctx->stream));
+    const size_t n = (size_t)1 << k;
+    const int blk = ctx->tune.vec_block;
+    size_t grid = (n + blk - 1) / blk; if (grid > 4096) grid = 4096;
+    const void* const* d_a = (const void* const*)((char*)ctx->ws_tmp.p + tab);
+    ZK_LAUNCH(coset_combine_kernel, dim3((uint32_t)grid, q), blk, 0, ctx->stream, d_a, (void* const*)(d_a + q), (const void*)ctx->ws_tmp.p, lo, hi, lo_bits, ek, q, n);
+    ZK_CHECK_LAUNCH();
+    ZK_HIP(hipStreamSynchronize(ctx->stream));                          // wz / pa live on this frame
+    return ZK_OK;
+}
 int domain_coeff_to_lagrange(zk_ctx* ctx, void* d_a, uint32_t k) {
     if (k > BN254_FR_S) return ctx->fail(ZK_ERR_ARG, "k = %u > S", k);
     return ntt_dev(ctx, d_a, k, domain_omega(k), nullptr);

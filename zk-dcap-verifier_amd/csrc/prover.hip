@@ -402,7 +402,11 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         (L && (!pk->lookup_input_programs || !pk->lookup_table_programs || !pk->lookup_table_key)) || (pk->n_advice_queries && !pk->advice_queries) ||
         (pk->n_fixed_queries && !pk->fixed_queries) || !pk->transcript_repr)
         return ZK_ERR_ARG;
-    if (!sharded && ((pk->n_fixed && !pk->fixed_cosets) || (pk->n_perm_columns && !pk->sigma_cosets) || !pk->l0 || !pk->l_last || !pk->l_active_row)) return ZK_ERR_ARG;
+    // a single-GPU key that holds cosets 0 .. n_pieces-1 instead of the extended domain (zk_plonk_pk_build does when cs_degree - 1 is not a power of two): the quotient is
+    // evaluated on those cosets only and the pieces of h(X) come from zk_cosets_to_pieces_dev
+    const bool by_cosets = !sharded && pk->coset_l && pk->coset_l[0] && n_pieces < (1u << (ek - k)) && n_pieces <= 8;
+    if (!sharded && !by_cosets && ((pk->n_fixed && !pk->fixed_cosets) || (pk->n_perm_columns && !pk->sigma_cosets) || !pk->l0 || !pk->l_last || !pk->l_active_row)) return ZK_ERR_ARG;
+    if (by_cosets && ((pk->n_fixed && !pk->coset_fixed) || (pk->n_perm_columns && !pk->coset_sigma))) return ZK_ERR_ARG;
     if (sharded && (rank >= world || n % world || !pk->allgather || (pk->n_fixed && !pk->coset_fixed) || (pk->n_perm_columns && !pk->coset_sigma) || !pk->coset_l)) return ZK_ERR_ARG;
     // the quotient's units of this rank (see zk_plonk_pk_desc): (coset, first row, rows)
     struct Unit { uint32_t coset; uint64_t lo, rows; };
@@ -599,8 +603,9 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     lag.insert(lag.end(), lzs.begin(), lzs.end());
     for (uint32_t l = 0; l < L; l++) { lag.push_back(pin[l]); lag.push_back(ptab[l]); }
     PK(zk_lagrange_to_coeff_batch_dev(ctx, lag.data(), lag.size(), k));
-    void* h_ext = mem.get(en * 32);
-    if (!h_ext) return ZK_ERR_HIP;
+    void* h_ext = by_cosets ? nullptr : mem.get(en * 32);
+    if (!by_cosets && !h_ext) return ZK_ERR_HIP;
+    std::vector<void*> numer(by_cosets ? n_pieces : 0);
     auto quotient_args = [&](zk_quotient_args& a, void* const* ext, std::vector<const void*>& e_in, std::vector<const void*>& e_tab) {
         const size_t nA = pk->n_advice, nI = pk->n_instance;
         e_in.clear(); e_tab.clear();
@@ -611,7 +616,22 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         a.lookup_product = (const void* const*)ext + nA + nI + n_sets; a.lookup_input = e_in.data(); a.lookup_table = e_tab.data();
         a.challenges = one.v; a.beta = beta.v; a.gamma = gamma.v; a.theta = theta.v; a.y = y.v;
     };
-    if (!sharded) {
+    if (by_cosets) {
+        std::vector<void*> cols(lag.size());
+        for (auto& e : cols) { e = mem.get(col_bytes); if (!e) return ZK_ERR_HIP; }
+        for (auto& e : numer) { e = mem.get(col_bytes); if (!e) return ZK_ERR_HIP; }
+        for (uint32_t j = 0; j < n_pieces; j++) {
+            PK(zk_coeff_to_coset_batch_dev(ctx, (const void* const*)lag.data(), cols.data(), cols.size(), k, ek, j));
+            std::vector<const void*> e_in, e_tab;
+            zk_quotient_args a;
+            quotient_args(a, cols.data(), e_in, e_tab);
+            a.fixed = pk->coset_fixed + (size_t)j * pk->n_fixed; a.perm_cosets = pk->coset_sigma + (size_t)j * pk->n_perm_columns;
+            a.l0 = pk->coset_l[3 * j]; a.l_last = pk->coset_l[3 * j + 1]; a.l_active_row = pk->coset_l[3 * j + 2];
+            a.out = numer[j];
+            PK(zk_quotient_run_coset_dev(ctx, pk->program, &a, j));
+        }
+        for (auto e : cols) mem.give_back(e);
+    } else if (!sharded) {
         std::vector<void*> ext(lag.size());
         for (auto& e : ext) { e = mem.get(en * 32); if (!e) return ZK_ERR_HIP; }
         PK(zk_coeff_to_extended_batch_dev(ctx, (const void* const*)lag.data(), ext.data(), ext.size(), k, ek));
@@ -650,10 +670,16 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     }
     clk.lap(5);
     // ---- 7. divide, back to coefficients, commit the pieces ---------------------------------------------------------------------------------------------------------
-    PK(zk_divide_by_vanishing_poly_dev(ctx, h_ext, k, ek));
-    PK(zk_extended_to_coeff_dev(ctx, h_ext, k, ek));
     std::vector<void*> pieces(n_pieces);
-    for (uint32_t i = 0; i < n_pieces; i++) pieces[i] = (char*)h_ext + (size_t)i * col_bytes;
+    if (by_cosets) {
+        for (auto& e : pieces) { e = mem.get(col_bytes); if (!e) return ZK_ERR_HIP; }
+        PK(zk_cosets_to_pieces_dev(ctx, numer.data(), n_pieces, k, ek, pieces.data()));
+        for (auto e : numer) mem.give_back(e);
+    } else {
+        PK(zk_divide_by_vanishing_poly_dev(ctx, h_ext, k, ek));
+        PK(zk_extended_to_coeff_dev(ctx, h_ext, k, ek));
+        for (uint32_t i = 0; i < n_pieces; i++) pieces[i] = (char*)h_ext + (size_t)i * col_bytes;
+    }
     PK(commit(pk->srs_g, pieces));
     clk.lap(6);
     // ---- 8. x; evaluations ------------------------------------------------------------------------------------------------------------------------------------------------
@@ -942,10 +968,18 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
         for (size_t u = (size_t)host->shard_rank * slots; u < (size_t)(host->shard_rank + 1) * slots && u < n_units; u++)
             if (my_cosets.empty() || my_cosets.back() != u / parts) my_cosets.push_back((uint32_t)(u / parts));
     }
-    // coeffs -> extended cosets (single GPU: `cosets`) or this rank's cosets (`by_coset`, [coset][column])
+    // a single GPU needs h(X)'s numerator on cs_degree - 1 cosets only (zk_cosets_to_pieces_dev): when that is fewer than the 2^(ek - k) of the extended domain the key
+    // keeps cosets 0 .. cs_degree-2, n values per column, and no extended form at all (tunable "quot_piece_cosets", default on)
+    bool whole_domain = world == 1;
+    if (world == 1 && host->cs_degree - 1 < (1u << (ek - k)) && host->cs_degree - 1 <= 8) {
+        int on = 1;
+        (void)zk_tune_get(ctx, "quot_piece_cosets", &on);
+        if (on) { whole_domain = false; for (uint32_t j = 0; j + 1 < host->cs_degree; j++) my_cosets.push_back(j); }
+    }
+    // coeffs -> extended cosets (`cosets`) or the cosets this key keeps (`by_coset`, [coset][column])
     auto to_cosets = [&](std::vector<void*>& pl, std::vector<const void*>& cosets, std::vector<const void*>& by_coset) -> int {
         const size_t count = pl.size();
-        if (world == 1) {
+        if (whole_domain) {
             std::vector<void*> cs(count);
             for (auto& c : cs) { c = alloc(ext_bytes); if (!c) return ZK_ERR_HIP; }
             if (count) PK(zk_coeff_to_extended_batch_dev(ctx, (const void* const*)pl.data(), cs.data(), count, k, ek));
@@ -1000,7 +1034,7 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
         if (!rc) rc = to_cosets(tmp, ext, m->coset_l);
         for (int i = 0; i < 3; i++) (void)zk_dev_free(ctx, tmp[i]);
         if (rc) return fail(rc);
-        for (int i = 0; i < 3 && world == 1; i++) m->l[i] = (void*)ext[i];
+        for (int i = 0; i < 3 && whole_domain; i++) m->l[i] = (void*)ext[i];
     }
     rc = zk_quotient_program_load(ctx, host->evaluator_zkq1, host->evaluator_zkq1_len, &h->program);
     h->in_prog.assign(L, 0); h->tab_prog.assign(L, 0);

@@ -57,17 +57,20 @@ class ProvingKey:
     lookup_compressors: list = field(default_factory=list)   # per lookup: (input Evaluator, table Evaluator) over the 2^k rows
     coset_parts: Optional[dict] = None   # params.by_cosets(): coset j -> {"fixed", "sigma", "l"}: the 2^k values of that coset only (this rank's cosets)
     borrowed: bool = False               # shared_with(): the columns belong to another ProvingKey of the process (same GPU); only the program handles are this key's
+    pieces_from_cosets: bool = False     # one GPU, cs_degree - 1 < 2^(extended_k - k): coset_parts holds cosets 0 .. cs_degree-2 and there are NO extended forms — the prover
+                                         # evaluates h(X)'s numerator on those cosets only and takes the pieces from zk_cosets_to_pieces_dev
 
     @classmethod
     def shared_with(cls, other: "ProvingKey", backend: Backend) -> "ProvingKey":
         """The same proving key for another context on the same GPU (one context per host thread that proves concurrently): every column and every compiled
         program is SHARED with `other` — one proving key per process (≈2.3 GB at k = 19) instead of one per context, one keygen instead of N.  `other` must
         outlive the borrower's proofs; release() of a borrower returns only its program handles."""
-        assert other.coset_parts is None, "sharded keys are per rank"
+        assert other.coset_parts is None or other.pieces_from_cosets, "sharded keys are per rank"
         ev_ = ev.Evaluator.shared(other.evaluator, backend)
         comps = [(ev.Evaluator.shared(a, backend), ev.Evaluator.shared(b, backend)) for a, b in other.lookup_compressors]
         return cls(other.vk, EvaluationDomain(other.vk.cs.degree(), other.vk.k, backend=backend), backend, other.fixed_values, other.fixed_polys, other.fixed_cosets,
-                   other.sigma_values, other.sigma_polys, other.sigma_cosets, other.l0, other.l_last, other.l_active_row, ev_, other.program, comps, None, True)
+                   other.sigma_values, other.sigma_polys, other.sigma_cosets, other.l0, other.l_last, other.l_active_row, ev_, other.program, comps, other.coset_parts, True,
+                   other.pieces_from_cosets)
 
     def release(self):
         self.evaluator.release()
@@ -123,10 +126,11 @@ def _as_mont(col, n) -> np.ndarray:
     return a
 
 
-def keygen(params: ParamsKZG, cs: ConstraintSystem, fixed_columns, assembly: Optional[Assembly] = None) -> ProvingKey:
+def keygen(params: ParamsKZG, cs: ConstraintSystem, fixed_columns, assembly: Optional[Assembly] = None, piece_cosets: Optional[bool] = None) -> ProvingKey:
     """keygen_vk + keygen_pk.  fixed_columns: cs.num_fixed_columns columns of n = 2^k rows, either (n, 4) uint64
     Montgomery arrays or lists of canonical ints (selectors included, as halo2 hands them over after compression);
-    assembly: the copy constraints (None = no equality-enabled columns)."""
+    assembly: the copy constraints (None = no equality-enabled columns).  piece_cosets (default on): on one GPU, when cs_degree - 1 is not a power of two, keep the
+    key's columns on cosets 0 .. cs_degree-2 only (ProvingKey.pieces_from_cosets) — False builds the extended forms halo2's keygen_pk builds."""
     be, k, n = params.backend, params.k, params.n
     assert len(fixed_columns) == cs.num_fixed_columns
     dom = EvaluationDomain(cs.degree(), k, backend=be)
@@ -167,6 +171,12 @@ def keygen(params: ParamsKZG, cs: ConstraintSystem, fixed_columns, assembly: Opt
     # keygen_pk: polys and extended cosets (when the quotient is sharded: only this rank's cosets, 2^k values each)
     by_cosets = params.by_cosets()
     my_cosets = params.my_cosets(1 << (ek - k)) if by_cosets else []
+    n_pieces = cs.degree() - 1
+    if piece_cosets is None:
+        piece_cosets = True
+    pieces_from_cosets = bool(piece_cosets) and not by_cosets and n_pieces < (1 << (ek - k)) and n_pieces <= 8
+    if pieces_from_cosets:                                               # h(X) needs its numerator on cs_degree - 1 cosets only: keep those, build no extended form
+        by_cosets, my_cosets = True, list(range(n_pieces))
     coset_parts = {j: {} for j in my_cosets} if by_cosets else None
 
     def to_poly_and_coset(values, name=None):
@@ -208,4 +218,4 @@ def keygen(params: ParamsKZG, cs: ConstraintSystem, fixed_columns, assembly: Opt
     evaluator = ev.Evaluator(program, backend=be)
     comps = [(_compressor(cs, k, lk.input_expressions, be), _compressor(cs, k, lk.table_expressions, be)) for lk in cs.lookups]
     return ProvingKey(vk, dom, be, fixed_values, fixed_polys, fixed_cosets, sigma_values, sigma_polys, sigma_cosets,
-                      lcosets[0], lcosets[1], lcosets[2], evaluator, program, comps, coset_parts)
+                      lcosets[0], lcosets[1], lcosets[2], evaluator, program, comps, coset_parts, False, pieces_from_cosets)

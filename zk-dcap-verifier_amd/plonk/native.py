@@ -81,7 +81,7 @@ class NativeProver:
     def __init__(self, params: ParamsKZG, pk: ProvingKey, transcript: str = "blake2b", draw_schedule: int = 1, exchange=None):
         """exchange (sharded params only): the ranks' collective — an object with `all_gather(send_ptr, recv_ptr, nbytes)` and, optionally, the device
         buffers `send` / `recv` / `cap` the library should exchange through (TorchExchange above); every rank must prove with the same witness and rng stream."""
-        assert (params.world == 1) == (pk.coset_parts is None), "a sharded SRS goes with a proving key built on it (keygen(params.sharded(..)))"
+        assert (params.world == 1) == (pk.coset_parts is None or pk.pieces_from_cosets), "a sharded SRS goes with a proving key built on it (keygen(params.sharded(..)))"
         assert params.world == 1 or exchange is not None, "a sharded proof needs the ranks' all-gather"
         self.params, self.pk, self.be = params, pk, pk.backend
         cs = pk.vk.cs
@@ -120,7 +120,15 @@ class NativeProver:
         d.lookup_table_key = u32(key_ids)
         d.fixed_values, d.fixed_polys, d.fixed_cosets = ptrs(pk.fixed_values), ptrs(pk.fixed_polys), ptrs(pk.fixed_cosets)
         d.sigma_values, d.sigma_polys, d.sigma_cosets = ptrs(pk.sigma_values), ptrs(pk.sigma_polys), ptrs(pk.sigma_cosets)
-        if params.world == 1:
+        if params.world == 1 and pk.pieces_from_cosets:
+            # no extended forms: cosets 0 .. cs_degree-2 of the key's columns, the library evaluates the quotient there and calls zk_cosets_to_pieces_dev
+            d.fixed_cosets = d.sigma_cosets = None
+            mine = sorted(pk.coset_parts)
+            assert mine == list(range(cs.degree() - 1))
+            d.coset_fixed = ptrs([c for j in mine for c in pk.coset_parts[j]["fixed"]])
+            d.coset_sigma = ptrs([c for j in mine for c in pk.coset_parts[j]["sigma"]])
+            d.coset_l = ptrs([c for j in mine for c in pk.coset_parts[j]["l"]])
+        elif params.world == 1:
             d.l0, d.l_last, d.l_active_row = _dptr(pk.l0), _dptr(pk.l_last), _dptr(pk.l_active_row)
         else:
             # one proof over the ranks: this rank's table slices are behind the SRS handles already (ParamsKZG.sharded); the key's cosets come per coset

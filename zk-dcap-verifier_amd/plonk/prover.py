@@ -252,8 +252,19 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
         return dict(advice=ext[:nA], instance=ext[nA:nA + nI], perm_products=ext[nA + nI:nA + nI + nZ], lookup_product=ext[nA + nI + nZ:nA + nI + nZ + L],
                     lookup_input=ext[nA + nI + nZ + L:][0::2], lookup_table=ext[nA + nI + nZ + L:][1::2])
     scal = dict(challenges=[], beta=bt_m, gamma=gm_m, theta=th, y=fr_mont(y))
-    h_ext = dev(en * 32)
-    if pk.coset_parts is None:
+    n_pieces = dom.quotient_poly_degree
+    h_ext = dev(en * 32) if not pk.pieces_from_cosets else None
+    numer = []
+    if pk.pieces_from_cosets:
+        # cs_degree - 1 cosets determine h(X) (deg h < (cs_degree - 1) n; on a coset X^n is a constant): evaluate the numerator there only, the pieces come from zk_cosets_to_pieces_dev
+        ext = [dev(n * 32) for _ in lag]
+        numer = [dev(n * 32) for _ in range(n_pieces)]
+        for j in range(n_pieces):
+            part = pk.coset_parts[j]
+            be.coeff_to_coset_batch_dev(lag, ext, k, ek, j)
+            pk.evaluator.evaluate_h(fixed=part["fixed"], l0=part["l"][0], l_last=part["l"][1], l_active_row=part["l"][2], perm_cosets=part["sigma"],
+                                    out=numer[j], coset=j, **split(ext), **scal)
+    elif pk.coset_parts is None:
         ext = [dev(en * 32) for _ in lag]
         be.coeff_to_extended_batch_dev(lag, ext, k, ek)
         pk.evaluator.evaluate_h(fixed=pk.fixed_cosets, l0=pk.l0, l_last=pk.l_last, l_active_row=pk.l_active_row, perm_cosets=pk.sigma_cosets,
@@ -294,10 +305,14 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
         owned.remove(d)
     lap("6_ntt_evaluate_h")
     # ---- 7. vanishing::construct: divide, back to coefficients, split into d-1 pieces, commit ------------------------------------------
-    be.divide_by_vanishing_poly_dev(h_ext, k, ek)
-    be.extended_to_coeff_dev(h_ext, k, ek)
-    n_pieces = dom.quotient_poly_degree
-    pieces = [h_ext.ptr + i * n * 32 for i in range(n_pieces)]
+    if pk.pieces_from_cosets:
+        piece_bufs = [dev(n * 32) for _ in range(n_pieces)]
+        be.cosets_to_pieces_dev(numer, k, ek, piece_bufs)
+        pieces = [b.ptr for b in piece_bufs]
+    else:
+        be.divide_by_vanishing_poly_dev(h_ext, k, ek)
+        be.extended_to_coeff_dev(h_ext, k, ek)
+        pieces = [h_ext.ptr + i * n * 32 for i in range(n_pieces)]
     for pt in commit_all("g", pieces):
         transcript.write_point(pt)
 

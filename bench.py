@@ -789,6 +789,37 @@ def main(argv=None):
                 w_.pk.release()
         except Exception as e:
             extra["census_" + other + "_error"] = repr(e)
+    if args.mode == "prove" and not args.no_extras and world == 1:
+        # BASELINE configs[0]: the shape of the reference's stack-B circuit (crates/p256-ecdsa, k = 18, snark-verifier's Poseidon transcript: base.rs:200-212) — the case the
+        # reference itself runs on the CPU.  Degree 4: three h pieces, so the key holds three cosets of its columns and h(X) comes from zk_cosets_to_pieces_dev.
+        try:
+            import p256_shaped_circuit as p256
+            kb = 18 if args.k >= 18 else max(args.k - 1, 5)           # (the plumbing test runs the whole file at a tiny k)
+            cs_b, fixed_b, asm_b, advice_b, inst_b = p256.build(kb)
+            params_b = z.kzg.ParamsKZG.setup(kb, TAU, backend=be)
+            pk_b = z.plonk.keygen(params_b, cs_b, fixed_b, asm_b)
+            prover_b = z.plonk.NativeProver(params_b, pk_b, transcript="poseidon")
+            dev_b = [be.to_device(a_) for a_ in advice_b]
+            work_b = [be.alloc(a_.nbytes) for a_ in advice_b]
+            times_b, proof_b = [], None
+            for r_ in range(6):
+                for w_, m_ in zip(work_b, dev_b):
+                    w_.copy_from(m_)
+                be.sync()
+                t1 = time.time()
+                proof_b = prover_b.create_proof(work_b, inst_b, np.random.default_rng(r_))
+                times_b.append(time.time() - t1)
+            best = sorted(times_b[1:])[len(times_b[1:]) // 2]
+            extra["cfg1_p256_k18"] = {"ms_per_proof_alone": round(best * 1e3, 2), "proofs_per_hour_one_at_a_time": round(3600.0 / best, 1), "proof_bytes": len(proof_b),
+                                      "pieces_from_cosets": bool(pk_b.pieces_from_cosets), "transcript": "poseidon", "shape": f"k={kb}, 3 advice, 1 lookup, 15 instance values, degree 4 (3 h pieces)",
+                                      "what": "BASELINE configs[0] (the reference's own CPU-runnable case) through zk_plonk_create_proof; one proof at a time — at this size a proof is latency, not throughput"}
+            cfg1 = (pk_b.vk, inst_b, proof_b)
+            for d_ in dev_b + work_b:
+                d_.free()
+            pk_b.release()
+            params_b.release()
+        except Exception as e:
+            extra["cfg1_p256_k18_error"] = repr(e)
     if args.mode == "prove" and not args.no_extras:
         # latency of ONE proof with the GPU to itself (the timed region above measures throughput with several in flight)
         lat = []
@@ -858,6 +889,15 @@ def main(argv=None):
                 extra["census_" + ("reference_exact" if args.census == "chip_estimate" else "chip_estimate")]["verify_proof_accepted"] = ok2
                 if not ok2:
                     raise RuntimeError("bench: the second-census proof was REJECTED by verify_proof")
+            cfg1 = locals().get("cfg1")
+            if cfg1 is not None:
+                import importlib
+                vmod = importlib.import_module("verifier")
+                pmod = importlib.import_module("poseidon_ref")           # oracle/: the second writing of snark-verifier's Poseidon transcript (checker only)
+                ok1 = bool(vmod.verify_proof(cfg1[0], TAU, cfg1[1], cfg1[2], reader=pmod.Reader))
+                extra["cfg1_p256_k18"]["verify_proof_accepted"] = ok1
+                if not ok1:
+                    raise RuntimeError("bench: the p256-shaped k = 18 proof was REJECTED by verify_proof")
             if shim is not None and "thin_shim" in extra and isinstance(cpu, dict) and "a13_a16_cpu_port" in cpu:
                 cpu_ms = cpu["a13_a16_cpu_port"]["total_ms"]
                 tot = extra["thin_shim"]["gpu_calls_total_ms"] + cpu_ms

@@ -63,6 +63,8 @@ def test_bench_prove_mode_emits_verified_proof(built, capsys, monkeypatch):
     assert line["roofline"]["kernel"] == "msm_accumulate_kernel"
     # the PCIe-inclusive regions (witness starting in host memory) and the thin-shim replay (per-call host-buffer entry points + CPU port of a13-a16)
     assert set(line["extra"]["host_witness"]) >= {"pinned", "pageable", "bytes_per_proof"}
+    c1 = line["extra"]["cfg1_p256_k18"]                                                                # BASELINE configs[0]'s shape: Poseidon transcript, h(X) from three cosets, checked by the oracle's verifier
+    assert c1["verify_proof_accepted"] is True and c1["pieces_from_cosets"] is True and c1["proof_bytes"] == 1504, c1
     ts = line["extra"]["thin_shim"]
     assert ts["calls"] == {"zk_msm": line["extra"]["ops_per_proof"]["msm"], "zk_ntt": line["extra"]["ops_per_proof"]["intt_2^k"], "zk_evaluate_h": 1}
     assert ts["proofs_per_hour"] > 0 and line["cpu_baseline"]["a13_a16_cpu_port"]["total_ms"] > 0

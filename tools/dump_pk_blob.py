@@ -104,8 +104,9 @@ def sgx_blob(be, k=8, seed=3, census="chip_estimate", draw_schedule=1) -> bytes:
 
 def p256_blob(be, k=7, seed=18, draw_schedule=1) -> bytes:
     """the census of the reference's stack-B circuit (degree 4: three h pieces, so zk_plonk_pk_build keeps three cosets of the key's columns and no extended form)"""
+    import p256_shaped_circuit as p256
     import test_create_proof as t
-    cs, fixed, asm, advice, instances = t.p256_shaped_circuit(k)
+    cs, fixed, asm, advice, instances = p256.build(k)
     return build_blob(be, cs, fixed, asm, advice, instances, k, t.TAU, seed, draw_schedule, None)
 
 

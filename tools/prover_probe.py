@@ -25,9 +25,8 @@ def main():
     instances = []
     t = time.time()
     if census == "p256":                               # BASELINE configs[0]: the reference's stack-B circuit shape (crates/p256-ecdsa, k = 18; degree 4, 3 advice, 1 lookup, 15 instance values)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import test_create_proof as tcp
-        cs, fixed, asm, advice, instances = tcp.p256_shaped_circuit(k)
+        import p256_shaped_circuit as p256
+        cs, fixed, asm, advice, instances = p256.build(k)
     else:
         cs, fixed, asm, advice = sc.build(z, be, k, census=census)
     out["census"] = census; out["build_witness_s"] = round(time.time() - t, 3)

@@ -45,6 +45,7 @@ struct Tune {
     int quot_threads = 128;
     int quot_piece_cosets = 1;   // zk_plonk_pk_build on one GPU: keep cosets 0 .. cs_degree-2 of the key's columns instead of their extended forms when cs_degree - 1 < 2^(extended_k - k) (zk_cosets_to_pieces_dev)
     int quot_limb29 = 0;         // 1: quotient interpreter on carry-free 29-bit limbs (quotient29_kernel) — measured SLOWER than the 32-bit interpreter (9.9 vs 9.4 ms per proof, profiles/r03 run99): kept selectable, off
+    int quot_factor_horner = 1;  // quotient compiler: q * Horner([a_j], theta) for a theta-compression whose parts all carry the factor q (selector-switched lookups): m - 1 products fewer per row
     int quot_rows = 1;           // rows per thread of the quotient interpreter (2: one micro-op decode serves two rows)
     int quot_remat_ops = 4;      // quotient compiler: a shared sub-expression of at most this many operations ...
     int quot_remat_distance = 24;   // ... is recomputed when its previous copy lies further back than this many micro-ops

@@ -350,6 +350,71 @@ bool read_graph(Reader& r, Graph& g) {
     return r.ok;
 }
 
+// Common factor of a theta-compression (graph -> graph, before any code is emitted).  halo2 compresses the m expressions of a lookup argument as Horner(0, [e_0 .. e_m-1], theta),
+// each e_j evaluated on its own; lookups that are switched by a selector have e_j = q * a_j (the reference's create_bit_lookup: q * char, q * bit_j, sgx_dcap_verifier.rs:95-134), so the
+// compression is q * Horner(0, [a_j], theta): m - 1 products fewer per row, the same field element (the compression is linear in its parts).  A part that IS the factor counts as
+// factor * 1.  Applied when every part is the factor or a product with it whose only reader is this Horner; graphs whose intermediates are written more than once are left alone.
+void factor_common_horner(Graph& g) {
+    auto same = [](const VSrc& x, const VSrc& y) { return x.kind == y.kind && x.a == y.a && (x.b == y.b || x.kind == VS_INTER || x.kind == VS_CONST || x.kind >= VS_CHALLENGE); };
+    std::vector<int> writer(g.num_intermediates, -1), readers(g.num_intermediates, 0);
+    auto count = [&](const VSrc& v) { if (v.kind == VS_INTER && v.a < readers.size()) readers[v.a]++; };
+    for (size_t i = 0; i < g.calcs.size(); i++) {
+        const Calc& k = g.calcs[i];
+        if (writer[k.target] >= 0) return;                             // an intermediate written twice: not the single-assignment form add_calculation produces
+        writer[k.target] = (int)i;
+        count(k.s0);
+        if (k.op == OP_ADD || k.op == OP_SUB || k.op == OP_MUL || k.op == OP_HORNER) count(k.s1);
+        for (auto& pp : k.parts) count(pp);
+    }
+    for (size_t i = 0; i < g.calcs.size(); i++) {
+        if (g.calcs[i].op != OP_HORNER || g.calcs[i].parts.size() < 2) continue;
+        const Calc k = g.calcs[i];
+        if (!(k.s0.kind == VS_CONST && k.s0.a < g.constants.size() && Fr::is_zero(g.constants[k.s0.a]))) continue;
+        auto mul_of = [&](const VSrc& part) -> const Calc* {            // the product behind a part, if this Horner is its only reader
+            if (part.kind != VS_INTER || part.a >= writer.size() || writer[part.a] < 0 || writer[part.a] >= (int)i) return nullptr;
+            const Calc& c = g.calcs[writer[part.a]];
+            return c.op == OP_MUL && readers[part.a] == 1 ? &c : nullptr;
+        };
+        std::vector<VSrc> cands;
+        if (const Calc* c0 = mul_of(k.parts[0])) { cands.push_back(c0->s0); cands.push_back(c0->s1); }
+        cands.push_back(k.parts[0]);                                    // (the first part may be the bare factor: q * a, q * a * 2, q * a * 3, ...)
+        for (const VSrc& f : cands) {
+            std::vector<VSrc> rest;
+            size_t products = 0;
+            bool all = true;
+            for (const VSrc& part : k.parts) {
+                if (same(part, f)) { rest.push_back(VSrc{VS_CONST, 0xFFFFFFFFu, 0}); continue; }          // factor * 1 (the constant is appended below)
+                const Calc* c = mul_of(part);
+                if (c && same(c->s0, f)) { rest.push_back(c->s1); products++; }
+                else if (c && same(c->s1, f)) { rest.push_back(c->s0); products++; }
+                else { all = false; break; }
+            }
+            if (!all || products < 2) continue;                         // (one product saved at least: `products` go, one comes)
+            uint32_t one_at = 0xFFFFFFFFu;
+            for (auto& v : rest)
+                if (v.kind == VS_CONST && v.a == 0xFFFFFFFFu) {
+                    if (one_at == 0xFFFFFFFFu) {
+                        for (uint32_t c = 0; c < g.constants.size(); c++) if (Fr::eq(g.constants[c], Fr::one())) { one_at = c; break; }
+                        if (one_at == 0xFFFFFFFFu) { one_at = (uint32_t)g.constants.size(); g.constants.push_back(Fr::one()); }
+                    }
+                    v.a = one_at;
+                }
+            Calc h = k, m;
+            h.target = g.num_intermediates++;
+            h.parts = rest;
+            m.op = OP_MUL; m.target = k.target; m.s0 = VSrc{VS_INTER, h.target, 0}; m.s1 = f;
+            g.calcs[i] = h;
+            g.calcs.insert(g.calcs.begin() + i + 1, m);
+            writer.push_back((int)i);
+            readers.push_back(1);
+            for (auto& w : writer) if (w > (int)i) w++;                 // the calculations behind the insertion moved by one
+            writer[k.target] = (int)i + 1;
+            i++;
+            break;
+        }
+    }
+}
+
 // virtual-register program
 struct VIns { uint32_t op; int dst; /* -1 = ACC, else vreg */ uint32_t src[3]; int vsrc[3]; /* vreg id when kind==SLOT */ int nsrc; };
 
@@ -481,6 +546,10 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
     std::vector<Graph> lookups(P.n_lookups);
     if (!read_graph(r, custom)) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: malformed custom-gate graph");
     for (auto& g : lookups) if (!read_graph(r, g)) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: malformed lookup graph");
+    if (ctx->tune.quot_factor_horner) {
+        factor_common_horner(custom);
+        for (auto& g : lookups) factor_common_horner(g);
+    }
     if (P.n_perm_cols && P.degree < 3) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: cs_degree < 3 with a permutation");
     const uint32_t chunk_len = P.n_perm_cols ? P.degree - 2 : 1;
     P.n_sets = P.n_perm_cols ? (P.n_perm_cols + chunk_len - 1) / chunk_len : 0;
@@ -602,6 +671,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         // Horner needs interleaving (part_i must be emitted right before its step), so it keeps a
         // running value across operand visits.
         std::vector<int> horner_cur(nc, -1);
+        std::vector<int> horner_first(nc, -1);       // a zero-start Horner whose first part is a memory operand (a column, a constant): no copy, the first step reads it in place
         size_t prev_reads = 0;                       // how many operands of the graph read PreviousValue (halo2: exactly one, the start of the final Horner)
         for (size_t i = 0; i < nc; i++) for (const VSrc* o : operands_of(g.calcs[i])) if (o->kind == VS_PREV) prev_reads++;
         while (!st.empty()) {
@@ -649,22 +719,24 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
                     f.next++;
                     if (oi >= 2) {
                         // Horner(0, parts, f) — how halo2 compresses lookup expressions — starts with 0 * f + part_0: take part_0 as it is
-                        const bool zero_start = horner_cur[ci] < 0 && d[0] < 0 && k.s0.kind == VS_CONST && k.s0.a < g.constants.size() &&
+                        const bool zero_start = horner_cur[ci] < 0 && horner_first[ci] < 0 && d[0] < 0 && k.s0.kind == VS_CONST && k.s0.a < g.constants.size() &&
                                                 Fr::is_zero(g.constants[k.s0.a]);
                         // halo2's custom-gate evaluator ends in Horner(PreviousValue, gates, y): when that is the graph's result and the previous value IS the
                         // accumulator, every step is a fold of the accumulator itself (and fuses with the gate's last product, Builder::fold)
                         const bool in_acc = prev_is_acc && ci == (int)nc - 1 && d[0] < 0 && k.s0.kind == VS_PREV && d[1] < 0 && k.s1.kind == VS_Y && prev_reads == 1;
                         if (in_acc) { B.fold(opnd_at(oi)); horner_cur[ci] = -2; }
-                        else if (zero_start) horner_cur[ci] = (d[oi] >= 0 && !is_alias[d[oi]]) ? vreg[d[oi]] : B.tmp_shared(M_MOV, {opnd_at(oi)});
-                        else {
-                            Builder::Opnd curv = horner_cur[ci] >= 0 ? B.slot(horner_cur[ci]) : opnd_at(0);
+                        else if (zero_start) {
+                            if (d[oi] >= 0 && !is_alias[d[oi]]) horner_cur[ci] = vreg[d[oi]];
+                            else horner_first[ci] = (int)oi;
+                        } else {
+                            Builder::Opnd curv = horner_cur[ci] >= 0 ? B.slot(horner_cur[ci]) : horner_first[ci] >= 0 ? opnd_at((size_t)horner_first[ci]) : opnd_at(0);
                             horner_cur[ci] = B.tmp_shared(M_MULADD, {curv, opnd_at(1), opnd_at(oi)});
                         }
                     }
                     continue;
                 }
                 if (horner_cur[ci] == -2) { *result_vreg = -2; return ZK_OK; }          // the result already sits in the accumulator (only the last calculation gets here)
-                vreg[ci] = horner_cur[ci] >= 0 ? horner_cur[ci] : B.tmp(M_MOV, {opnd_at(0)});
+                vreg[ci] = horner_cur[ci] >= 0 ? horner_cur[ci] : B.tmp(M_MOV, {opnd_at(horner_first[ci] >= 0 ? (size_t)horner_first[ci] : 0)});
                 st.pop_back();
             }
             if (!ok) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: operand out of range in a calculation");

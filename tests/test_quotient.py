@@ -216,6 +216,65 @@ def test_gpu_theta_compression(gpu, orc, pyref):
     _theta_compression_case(gpu, orc, pyref, 12, 4)
 
 
+def _factored_compression_case(be, orc, pyref, k, seed):
+    """the compiler's selector factoring (quotient.hip factor_common_horner): Horner(0, [q*a_0 .. q*a_3], theta) = q * Horner(0, [a_j], theta), also with a first part that IS the
+    factor (q*a, q*a*2, q*a*3: the factor is the product q*a), and NOT applied when one part lacks the factor.  Same values with the rewrite on and off; fewer products with it."""
+    import random
+    p, rnd = pyref, random.Random(seed)
+    n, R = 1 << k, p.R
+    adv = [[rnd.randrange(R) for _ in range(n)] for _ in range(4)]
+    fix = [[rnd.randrange(R) for _ in range(n)]]
+    theta = rnd.randrange(R)
+    M = orc.fr_from_ints
+    q = lambda g, r: ev.vs(ev.FIXED, 0, r)
+
+    def shape(which):
+        g = ev.Graph()
+        zero, r0, r1 = g.add_constant(M([0])[0]), g.add_rotation(0), g.add_rotation(1)
+        if which == "products":
+            parts = [g.add_calculation(ev.MUL, q(g, r0), ev.vs(ev.ADVICE, j, r1 if j == 2 else r0)) for j in range(4)]
+            want = lambda i: fix[0][i] * sum(adv[j][(i + 1) % n if j == 2 else i] * pow(theta, 3 - j, R) for j in range(4)) % R
+        elif which == "bare":
+            base = g.add_calculation(ev.MUL, q(g, r0), ev.vs(ev.ADVICE, 0, r0))
+            cs_ = [g.add_constant(M([c])[0]) for c in (2, 3, 4)]
+            parts = [base] + [g.add_calculation(ev.MUL, base, c) for c in cs_]
+            want = lambda i: fix[0][i] * adv[0][i] * (pow(theta, 3, R) + 2 * theta * theta + 3 * theta + 4) % R
+        else:                                                            # "mixed": the last part has no factor — the chain stays as halo2 wrote it
+            parts = [g.add_calculation(ev.MUL, q(g, r0), ev.vs(ev.ADVICE, j, r0)) for j in range(3)] + [ev.vs(ev.ADVICE, 3, r0)]
+            want = lambda i: (fix[0][i] * sum(adv[j][i] * pow(theta, 3 - j, R) for j in range(3)) + adv[3][i]) % R
+        g.add_calculation(ev.HORNER, zero, parts, ev.vs(ev.THETA))
+        return ev.expression_program(k, 1, 4, 0, 0, g), want
+    d_adv, d_fix = [be.to_device(M(c)) for c in adv], [be.to_device(M(c)) for c in fix]
+    one = M([1])[0]
+    muls = {}
+    for which in ("products", "bare", "mixed"):
+        prog, want = shape(which)
+        for on in (0, 1):
+            be.tune(quot_factor_horner=on)
+            e = ev.Evaluator(prog, backend=be)
+            mix = be.quotient_program_opmix(e.handle)
+            muls[which, on] = mix["mul"] + mix["muladd"]
+            out = be.alloc(n * 32)
+            e.evaluate_h(fixed=d_fix, advice=d_adv, instance=[], l0=d_fix[0], l_last=d_fix[0], l_active_row=d_fix[0], perm_cosets=[], perm_products=[],
+                         lookup_product=[], lookup_input=[], lookup_table=[], challenges=[], beta=one, gamma=one, theta=M([theta])[0], y=one, out=out)
+            assert orc.fr_to_ints(out.download((n, 4))) == [want(i) for i in range(n)], (which, on)
+            out.free()
+            e.release()
+    be.tune(quot_factor_horner=1)
+    assert muls["products", 0] == 7 and muls["products", 1] == 4           # 4 products + 3 Horner steps  ->  3 Horner steps + 1 product
+    assert muls["bare", 0] == 7 and muls["bare", 1] == 5                   # q*a, 3 scalings, 3 steps  ->  q*a, 3 steps over constants, 1 product
+    assert muls["mixed", 0] == muls["mixed", 1] == 6
+
+
+def test_emulated_factored_theta_compression(emu, orc, pyref):
+    _factored_compression_case(emu, orc, pyref, 5, 11)
+
+
+@pytest.mark.gpu
+def test_gpu_factored_theta_compression(gpu, orc, pyref):
+    _factored_compression_case(gpu, orc, pyref, 12, 12)
+
+
 def _bench_program_case(be, orc, pyref, k):
     """The sgx-shaped program that bench.py times (24 degree-3 gates, 16 permutation columns in 6 sets, 11 lookups), at small k."""
     import sys

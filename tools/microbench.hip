@@ -226,6 +226,26 @@ __global__ void k_shr64(uint32_t* out, uint32_t seed) {         // v_lshrrev_b64
     uint64_t r = x0 ^ x1 ^ x2 ^ x3;
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
 }
+// the same shift forced (the C loop above folds into other instructions): v_lshrrev_b64 against the two 32-bit instructions that do the same (v_alignbit_b32 + v_lshrrev_b32)
+__global__ void k_shr64_asm(uint32_t* out, uint32_t seed) {
+    uint64_t a = ((uint64_t)(threadIdx.x + seed) << 40) | 0xfedcba987ull, x0 = a, x1 = a + 1, x2 = a + 2, x3 = a + 3;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile("v_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %1, 1, %1\n\tv_lshrrev_b64 %2, 1, %2\n\tv_lshrrev_b64 %3, 1, %3" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+        x0 |= a;
+    }
+    uint64_t r = x0 ^ x1 ^ x2 ^ x3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+}
+__global__ void k_shr64_pair(uint32_t* out, uint32_t seed) {
+    uint32_t l0 = threadIdx.x + seed, h0 = 0xfedcba98u, l1 = l0 + 1, h1 = h0 + 1, l2 = l0 + 2, h2 = h0 + 2, l3 = l0 + 3, h3 = h0 + 3;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile("v_alignbit_b32 %0, %1, %0, 1\n\tv_lshrrev_b32 %1, 1, %1\n\tv_alignbit_b32 %2, %3, %2, 1\n\tv_lshrrev_b32 %3, 1, %3\n\t"
+                     "v_alignbit_b32 %4, %5, %4, 1\n\tv_lshrrev_b32 %5, 1, %5\n\tv_alignbit_b32 %6, %7, %6, 1\n\tv_lshrrev_b32 %7, 1, %7"
+                     : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2), "+v"(l3), "+v"(h3));
+        h0 |= 0x80000000u;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = l0 ^ h0 ^ l1 ^ h1 ^ l2 ^ h2 ^ l3 ^ h3;
+}
 // one partial product of the FMA scheme, as it would sit in the inner loop: 2 fma + 1 f64 add + 2 integer 64-bit adds.  Round-toward-zero is set
 // once per kernel (MODE.FP_ROUND for f64 = bits 3:2).  Four independent chains; timing only (operands drift, exactness is not the point here).
 __global__ void k_fma_partial(uint32_t* out, uint32_t seed) {
@@ -318,6 +338,8 @@ int main(int argc, char** argv) {
         run("add_u64", k_addu64, 4.0 * ITER, 256, bpc);
         run("lshl_add_u64", k_lshladd64, 4.0 * ITER, 256, bpc);
         run("lshr_b64", k_shr64, 4.0 * ITER, 256, bpc);
+        run("lshrrev_b64_asm", k_shr64_asm, 4.0 * ITER, 256, bpc);
+        run("alignbit+lshr32_pair", k_shr64_pair, 4.0 * ITER, 256, bpc);
         double f = run("fma_partial52", k_fma_partial, 4.0 * ITER, 256, bpc);
         double m = run("mad_partial32", k_mad_partial, 4.0 * ITER, 256, bpc);
         printf("   bit-products/s: fma scheme %.1f T, mad+addc %.1f T  -> ratio %.2f (before carry propagation, quotient digits and limb conversion of the fma form)\n",

@@ -45,6 +45,19 @@ extern "C" {
 
 typedef struct zk_ctx zk_ctx;
 
+/* ---- ABI versioning ----------------------------------------------------------------------- *
+ * Every struct that crosses this boundary (zk_quotient_args, zk_plonk_pk_desc, zk_plonk_pk_host) starts with `uint32_t struct_size`, which the caller sets to
+ * ITS sizeof of the struct (ZK_STRUCT_INIT in C; size_of::<T>() in a Rust binding).  An entry point that receives another size than the library was built with
+ * returns ZK_ERR_ARG ("struct_size N, expected M") before it reads any other field — a binding that has fallen behind the header fails loudly at its first
+ * call instead of handing the library bytes past the end of its object.  Fields are only ever APPENDED, and each append bumps ZK_ABI_VERSION; a binding
+ * asserts at start-up that zk_abi_version() is the ZK_ABI_VERSION it was written against and that zk_abi_struct_size(name) equals its own size of every
+ * struct it declares (shim/halo2_proofs_mi355x/src/mi355x.rs does; tests/test_shim_abi.py diffs the declarations field by field). */
+#define ZK_ABI_VERSION 4u
+uint32_t zk_abi_version(void);
+/* sizeof the named struct ("zk_quotient_args", "zk_plonk_pk_desc", "zk_plonk_pk_host") in this build of the library; 0 for an unknown name */
+uint32_t zk_abi_struct_size(const char* struct_name);
+#define ZK_STRUCT_INIT(s) do { memset(&(s), 0, sizeof(s)); (s).struct_size = (uint32_t)sizeof(s); } while (0)   /* needs <string.h> */
+
 /* ---- context ------------------------------------------------------------------------------ */
 int zk_ctx_create(int device_id, zk_ctx** out);
 void zk_ctx_destroy(zk_ctx* ctx);
@@ -211,6 +224,7 @@ int zk_fr_lincomb_dev(zk_ctx* ctx, const void* const* polys_dev, const void* sca
  * once as a "ZKQ1" blob (layout in DESIGN.md / INTEGRATION.md), then run per proof on
  * device-resident extended cosets.  Column pointer arrays are HOST arrays of DEVICE pointers.     */
 typedef struct zk_quotient_args {
+    uint32_t struct_size;            /* sizeof(zk_quotient_args) of the caller (ABI versioning, above) */
     const void* const* fixed;        /* n_fixed cosets                                        */
     const void* const* advice;       /* n_advice cosets                                       */
     const void* const* instance;     /* n_instance cosets                                     */
@@ -291,10 +305,14 @@ int zk_evaluate_h(zk_ctx* ctx, uint64_t pk, const void* const* advice_polys, con
  * in tests).  Gather `bytes` bytes at send_dev of every rank into recv_dev (rank r's block at recv_dev + r * bytes) — DEVICE pointers on the context's GPU —
  * and return 0 once recv_dev is complete and send_dev may be overwritten (the library has synchronised its own stream before the call and uses the data right
  * after it).  Every rank calls it the same number of times with the same sizes: once per commitment phase (128-byte points) and once per proof for the
- * quotient's numerators. */
+ * quotient's numerators.
+ * A rank whose proof fails on its own (out of memory, a HIP error, a witness outside a lookup table) enters the NEXT exchange once more with a block whose first 32
+ * bytes are 0xFF and returns its error; the other ranks find the mark and return ZK_ERR_COMM from that same exchange, so all ranks leave the proof together.  What the
+ * library cannot cover is the collective itself hanging or a rank dying: the callback MUST enforce a timeout and return non-zero when it expires. */
 typedef int (*zk_allgather_fn)(void* user, const void* send_dev, void* recv_dev, size_t bytes);
 
 typedef struct zk_plonk_pk_desc {
+    uint32_t struct_size;                     /* sizeof(zk_plonk_pk_desc) of the caller (ABI versioning) */
     uint32_t k, extended_k, cs_degree, blinding_factors;
     uint32_t n_fixed, n_advice, n_instance, n_lookups, n_perm_columns;
     const uint32_t* perm_columns;             /* n_perm_columns x (column_type: 0 advice 1 fixed 2 instance, index) */
@@ -358,6 +376,7 @@ int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* c
  * concurrently proving host thread) a handle onto the same columns and compiled programs — pass that context's own SRS handles (zk_bases_share).
  * zk_plonk_prove = zk_plonk_create_proof on the descriptor the library built.  With values_on_device the columns are DEVICE pointers (borrowed, must outlive the key). */
 typedef struct zk_plonk_pk_host {
+    uint32_t struct_size;                     /* sizeof(zk_plonk_pk_host) of the caller (ABI versioning) */
     uint32_t k, cs_degree, blinding_factors;
     uint32_t n_fixed, n_advice, n_instance, n_lookups, n_perm_columns;
     const uint32_t* perm_columns;             /* as zk_plonk_pk_desc */

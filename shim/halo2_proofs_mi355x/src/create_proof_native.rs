@@ -14,6 +14,10 @@
 //!   * n >= 2^12.
 //! The proof comes back as bytes; `replay` feeds them through the caller's transcript (write_point / write_scalar, and a squeeze wherever create_proof squeezes),
 //! so the writer holds the same bytes AND the same hash state as after the CPU body — for any `W: Write`, without touching Blake2bWrite's private fields.
+//! `R: Send`: zk_plonk_prove calls the draw callback from a helper thread of the library (so that the draws of phase p + 1 overlap the kernels of phase p) while the
+//! calling thread blocks — the exclusive borrow travels to that thread and back, which is exactly what `Send` licenses.  OsRng (what the reference passes,
+//! sgx_dcap_verifier.rs:819) and every seedable rng are Send; create_proof's own bound becomes `R: RngCore + Send` in prover_native.patch (a ThreadRng caller
+//! wraps it or keeps the CPU prover).
 //! Witness synthesis (`WitnessCollection`, plonk/prover.rs) stays the CPU code it is.  Uncompiled in the build image (no rustc there).
 use std::any::{type_name, TypeId};
 use std::ffi::c_void;
@@ -42,7 +46,7 @@ extern "C" {
 /// `Fr::random(&mut rng)` n times, written as the 4 x u64 Montgomery limbs Fr is in memory (layout asserted by mi355x::gpu()).  The library calls this from
 /// ONE helper thread, block by block, in halo2's own order (zk_plonk_pk_desc.draw_schedule = 1: blinding rows, the Blind of every commitment, the random
 /// polynomial, the h-piece Blinds) and has made every draw when zk_plonk_prove returns: `rng` is left exactly where the CPU body would leave it.
-extern "C" fn draw<R: RngCore>(user: *mut c_void, n: usize, out_fr: *mut c_void) {
+extern "C" fn draw<R: RngCore + Send>(user: *mut c_void, n: usize, out_fr: *mut c_void) {
     let rng = unsafe { &mut *(user as *mut R) };
     let out = unsafe { std::slice::from_raw_parts_mut(out_fr as *mut Fr, n) };
     for v in out.iter_mut() {
@@ -103,7 +107,7 @@ where
     Scheme: CommitmentScheme + 'static,
     Scheme::ParamsProver: 'static,
     E: EncodedChallenge<Scheme::Curve>,
-    R: RngCore,
+    R: RngCore + Send, // the library draws through `&mut R` on ITS helper thread while this thread blocks in zk_plonk_prove: moving a `&mut R` across threads needs R: Send
     T: TranscriptWrite<Scheme::Curve, E>,
 {
     if TypeId::of::<Scheme::ParamsProver>() != TypeId::of::<ParamsKZG<Bn256>>() || instances.len() != 1 {

@@ -16,8 +16,13 @@ pub struct ZkCtx {
     _p: [u8; 0],
 }
 
+/// ZK_ABI_VERSION of the include/zkmi355.h this file was written against
+pub const ZK_ABI_VERSION: u32 = 4;
+
+/// field-for-field `zk_quotient_args`
 #[repr(C)]
 pub struct ZkQuotientArgs {
+    pub struct_size: u32, // size_of::<ZkQuotientArgs>()
     pub fixed: *const *const c_void,
     pub advice: *const *const c_void,
     pub instance: *const *const c_void,
@@ -39,6 +44,8 @@ pub struct ZkQuotientArgs {
 }
 
 extern "C" {
+    fn zk_abi_version() -> u32;
+    fn zk_abi_struct_size(struct_name: *const c_char) -> u32;
     fn zk_ctx_create(device: c_int, out: *mut *mut ZkCtx) -> c_int;
     fn zk_last_error(ctx: *mut ZkCtx) -> *const c_char;
     fn zk_bases_register(ctx: *mut ZkCtx, g1_affine: *const c_void, n: usize, handle: *mut u64) -> c_int;
@@ -91,6 +98,11 @@ pub fn gpu() -> Option<&'static Gpu> {
         assert_eq!(one, [0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f]); // R mod r
         let gen: [u64; 8] = unsafe { std::mem::transmute(G1Affine::generator()) };
         assert_eq!(&gen[..4], &[0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f]); // mont(1) in Fq
+        // ABI guards: the library this process loaded is the one these declarations describe (a mismatch is a build error of the integration, not a
+        // reason to fall back silently: refuse loudly)
+        assert_eq!(unsafe { zk_abi_version() }, ZK_ABI_VERSION, "libzkmi355.so ABI version differs from the binding's");
+        assert_eq!(unsafe { zk_abi_struct_size(b"zk_quotient_args\0".as_ptr() as *const c_char) } as usize, std::mem::size_of::<ZkQuotientArgs>());
+        assert_eq!(unsafe { zk_abi_struct_size(b"zk_plonk_pk_host\0".as_ptr() as *const c_char) } as usize, std::mem::size_of::<crate::pk_desc::ZkPlonkPkHost>());
         let dev = std::env::var("HALO2_MI355X_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
         let mut ctx = std::ptr::null_mut();
         if unsafe { zk_ctx_create(dev, &mut ctx) } != 0 {
@@ -166,6 +178,22 @@ pub fn try_msm_batch(polys: &[&[Fr]], bases: &[G1Affine]) -> Option<Vec<G1>> {
         return None;
     }
     Some(out.iter().map(|o| unsafe { std::mem::transmute_copy::<[u64; 12], G1>(o) }).collect())
+}
+
+/// `params.commit_lagrange(poly, blind)` for every column of a phase — what prover_phases.patch calls (both stacks).  Generic over the scheme as
+/// create_proof is: anything but KZG over bn256 declines.  (KZG ignores `blind`, so the batch needs none.)
+pub fn commit_lagrange_batch<P: 'static, S: 'static, Cv: 'static>(params: &P, cols: &[&[S]]) -> Option<Vec<Cv>> {
+    use crate::poly::kzg::commitment::ParamsKZG;
+    use halo2curves::bn256::Bn256;
+    if TypeId::of::<P>() != TypeId::of::<ParamsKZG<Bn256>>() || TypeId::of::<S>() != TypeId::of::<Fr>() || TypeId::of::<Cv>() != TypeId::of::<G1>() {
+        return None;
+    }
+    let params: &ParamsKZG<Bn256> = unsafe { &*(params as *const P as *const ParamsKZG<Bn256>) };
+    let n = cols.first()?.len();
+    let cols: &[&[Fr]] = unsafe { std::slice::from_raw_parts(cols.as_ptr() as *const &[Fr], cols.len()) };
+    let out = try_msm_batch(cols, &params.g_lagrange[..n])?;
+    let mut out = std::mem::ManuallyDrop::new(out);
+    Some(unsafe { Vec::from_raw_parts(out.as_mut_ptr() as *mut Cv, out.len(), out.capacity()) }) // Cv == G1 by the TypeId check
 }
 
 /// arithmetic::best_fft redirect (G = Fr only; the EC-FFT of ParamsKZG::setup stays on the CPU in this thin form)

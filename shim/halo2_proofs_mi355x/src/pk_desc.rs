@@ -21,9 +21,14 @@ use crate::mi355x::{gpu, Gpu, ZkCtx};
 use crate::plonk::{Any, ProvingKey};
 use crate::poly::kzg::commitment::ParamsKZG;
 
-/// field-for-field `zk_plonk_pk_host`
+/// the caller's collective of a proof over several GPUs (`zk_allgather_fn`); a single-GPU binding passes None
+pub type ZkAllgatherFn = extern "C" fn(user: *mut c_void, send_dev: *const c_void, recv_dev: *mut c_void, bytes: usize) -> c_int;
+
+/// field-for-field `zk_plonk_pk_host` (include/zkmi355.h) — tests/test_shim_abi.py diffs the two declarations name by name and type by type, and
+/// `mi355x::gpu()` asserts `size_of::<ZkPlonkPkHost>() == zk_abi_struct_size("zk_plonk_pk_host")` before the first call.
 #[repr(C)]
 pub struct ZkPlonkPkHost {
+    pub struct_size: u32,    // size_of::<ZkPlonkPkHost>(): the library refuses any other size than its own (ABI versioning)
     pub k: u32, pub cs_degree: u32, pub blinding_factors: u32,
     pub n_fixed: u32, pub n_advice: u32, pub n_instance: u32, pub n_lookups: u32, pub n_perm_columns: u32,
     pub perm_columns: *const u32,
@@ -39,6 +44,10 @@ pub struct ZkPlonkPkHost {
     pub transcript_repr: *const c_void,
     pub transcript: u32,     // 0 Blake2bWrite / Challenge255 (stack A)
     pub draw_schedule: u32,  // 1 = halo2's order of Fr::random draws (the only value a binding passes)
+    // one proof over several GPUs (0 / 0 / None / null: the whole proof on this process's GPU)
+    pub shard_world: u32, pub shard_rank: u32,
+    pub allgather: Option<ZkAllgatherFn>,
+    pub allgather_user: *mut c_void,
 }
 
 extern "C" {
@@ -99,6 +108,7 @@ pub fn key_for(g: &'static Gpu, params: &ParamsKZG<Bn256>, pk: &ProvingKey<G1Aff
     let repr = pk.vk.transcript_repr.to_repr(); // canonical little endian, what hash_into feeds common_scalar
 
     let host = ZkPlonkPkHost {
+        struct_size: std::mem::size_of::<ZkPlonkPkHost>() as u32,
         k, cs_degree: cs.degree() as u32, blinding_factors: cs.blinding_factors() as u32,
         n_fixed: cs.num_fixed_columns as u32, n_advice: cs.num_advice_columns as u32, n_instance: cs.num_instance_columns as u32,
         n_lookups: cs.lookups.len() as u32, n_perm_columns: (perm_columns.len() / 2) as u32,
@@ -113,6 +123,7 @@ pub fn key_for(g: &'static Gpu, params: &ParamsKZG<Bn256>, pk: &ProvingKey<G1Aff
         transcript_repr: repr.as_ref().as_ptr() as *const c_void,
         transcript: 0,
         draw_schedule: 1,
+        shard_world: 0, shard_rank: 0, allgather: None, allgather_user: std::ptr::null_mut(),
     };
     let mut handle = 0u64;
     if unsafe { zk_plonk_pk_build(g.ctx, &host, srs_g, srs_gl, &mut handle) } != 0 {

@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
     const void* transcript_repr = take(&r, 32);
 
     zk_plonk_pk_host host;
-    memset(&host, 0, sizeof host);
+    ZK_STRUCT_INIT(host);
     host.k = k; host.cs_degree = cs_degree; host.blinding_factors = bf;
     host.n_fixed = n_fixed; host.n_advice = n_advice; host.n_instance = n_instance; host.n_lookups = L; host.n_perm_columns = P;
     host.perm_columns = lists; host.advice_queries = lists + 2 * P; host.n_advice_queries = n_aq;

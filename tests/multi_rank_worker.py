@@ -118,6 +118,17 @@ def run_sharded_proof(rank: int, world: int, port: int, out_dir: str):
     except RuntimeError as e:
         ok = ok and "link down" in str(e)
     ok = ok and native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(7)) == tcp._golden()
+    # a failure of ONE rank's own (the last rank's witness leaves a lookup table: ZK_ERR_ARG from its lookup phase, after the first exchange) must not leave the
+    # others waiting in the next all-gather: the failing rank signals it in that exchange, every other rank returns ZK_ERR_COMM from it, and all of them go on
+    bad_advice = tcp.toy_circuit(k, tamper="lookup")[3]
+    calls_before = xch.calls
+    try:
+        native.create_proof([a.copy() for a in (bad_advice if rank == world - 1 else advice)], instances, np.random.default_rng(7))
+        ok = False
+    except z.ZkError as e:
+        ok = ok and e.code == (-1 if rank == world - 1 else -6) and ("signalled to the other ranks" if rank == world - 1 else "reported a failure of its own") in str(e)
+    ok = ok and xch.calls - calls_before == 2                          # the advice commitments, then the exchange that carried the mark
+    ok = ok and native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(7)) == tcp._golden()
     np.save(os.path.join(out_dir, f"proof_rank{rank}.npy"), np.array([int(ok)]))
     dist.barrier()
     dist.destroy_process_group()

@@ -26,8 +26,12 @@ class ZkError(RuntimeError):
         self.code = code
 
 
+ABI_VERSION = 4          # ZK_ABI_VERSION of include/zkmi355.h this binding follows
+
+
 class QuotientArgs(C.Structure):
-    _fields_ = [("fixed", C.c_void_p), ("advice", C.c_void_p), ("instance", C.c_void_p),
+    _fields_ = [("struct_size", C.c_uint32),
+                ("fixed", C.c_void_p), ("advice", C.c_void_p), ("instance", C.c_void_p),
                 ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
                 ("perm_cosets", C.c_void_p), ("perm_products", C.c_void_p), ("n_sets", C.c_uint32),
                 ("lookup_product", C.c_void_p), ("lookup_input", C.c_void_p), ("lookup_table", C.c_void_p),
@@ -44,6 +48,13 @@ def _load(path: str):
     lib.zk_last_error.restype = C.c_char_p
     lib.zk_version.restype = C.c_char_p
     lib.zk_timing_get.restype = C.c_double
+    lib.zk_abi_version.restype = C.c_uint32
+    lib.zk_abi_struct_size.restype = C.c_uint32
+    # the binding's own structs against the library it loaded (include/zkmi355.h, ABI versioning): a stale .so or a stale binding stops here
+    if lib.zk_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {lib.zk_abi_version()}, this binding is written against {ABI_VERSION} (rebuild: __graft_entry__.build())")
+    if lib.zk_abi_struct_size(b"zk_quotient_args") != C.sizeof(QuotientArgs):
+        raise RuntimeError(f"{path}: sizeof(zk_quotient_args) = {lib.zk_abi_struct_size(b'zk_quotient_args')}, the binding's QuotientArgs has {C.sizeof(QuotientArgs)}")
     return lib
 
 
@@ -494,7 +505,7 @@ class Backend:
 
         ch = np.ascontiguousarray(np.asarray(challenges, dtype=np.uint64).reshape(-1, 4)) if len(challenges) else np.zeros((1, 4), np.uint64)
         sc = [self._fe(v) for v in (beta, gamma, theta, y)]
-        a = QuotientArgs(parr(fixed), parr(advice), parr(instance), _dptr(l0), _dptr(l_last), _dptr(l_active_row),
+        a = QuotientArgs(C.sizeof(QuotientArgs), parr(fixed), parr(advice), parr(instance), _dptr(l0), _dptr(l_last), _dptr(l_active_row),
                          parr(perm_cosets), parr(perm_products), len(perm_products),
                          parr(lookup_product), parr(lookup_input), parr(lookup_table),
                          ch.ctypes.data, sc[0].ctypes.data, sc[1].ctypes.data, sc[2].ctypes.data, sc[3].ctypes.data, _dptr(out))

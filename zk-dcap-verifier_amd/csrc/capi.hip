@@ -52,6 +52,8 @@ int domain_cosets_to_pieces(zk_ctx* ctx, void* const* h_numer, uint32_t q, uint3
 using namespace zk;
 
 void zk_internal_plonk_ctx_destroyed(zk_ctx* ctx);   // prover.hip
+// prover.hip is a client of the public ABI and does not see zk_ctx's members: its own argument errors reach zk_last_error through this
+int zk_internal_fail(zk_ctx* ctx, int code, const char* msg) { return ctx ? ctx->fail(code, "%s", msg) : code; }
 #define LOCK std::lock_guard<std::mutex> lk__(ctx->mu)
 #define NEED_CTX if (!ctx) return ZK_ERR_ARG
 
@@ -63,6 +65,15 @@ const char* zk_version(void) {
 #else
     return "zkmi355 0.1 gfx950";
 #endif
+}
+
+uint32_t zk_abi_version(void) { return ZK_ABI_VERSION; }
+uint32_t zk_abi_struct_size(const char* name) {
+    if (!name) return 0;
+    if (!strcmp(name, "zk_quotient_args")) return (uint32_t)sizeof(zk_quotient_args);
+    if (!strcmp(name, "zk_plonk_pk_desc")) return (uint32_t)sizeof(zk_plonk_pk_desc);
+    if (!strcmp(name, "zk_plonk_pk_host")) return (uint32_t)sizeof(zk_plonk_pk_host);
+    return 0;
 }
 
 int zk_ctx_create(int device_id, zk_ctx** out) {
@@ -354,14 +365,19 @@ int zk_quotient_program_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_prog, u
     if (!ctx || !owner || !prog) return ZK_ERR_ARG;
     return quotient_program_share(ctx, owner, owner_prog, prog);
 }
-int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; return quotient_run(ctx, prog, args, -1, 0, 0); }
+// ABI versioning (zkmi355.h): the caller's sizeof of a boundary struct must be this build's before any other field is read
+#define ARGS_SIZE(fn) do { if (!args) return ctx->fail(ZK_ERR_ARG, fn ": null args"); \
+        if (args->struct_size != sizeof(zk_quotient_args)) return ctx->fail(ZK_ERR_ARG, fn ": zk_quotient_args.struct_size %u, expected %zu (ABI version %u)", args->struct_size, sizeof(zk_quotient_args), ZK_ABI_VERSION); } while (0)
+int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; ARGS_SIZE("zk_quotient_run_dev"); return quotient_run(ctx, prog, args, -1, 0, 0); }
 int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset) {
     ENTER;
+    ARGS_SIZE("zk_quotient_run_coset_dev");
     if (coset >= (1u << 16)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_dev: coset %u out of range", coset);
     return quotient_run(ctx, prog, args, (int)coset, 0, 0);
 }
 int zk_quotient_run_coset_rows_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset, uint64_t row_lo, uint64_t row_count) {
     ENTER;
+    ARGS_SIZE("zk_quotient_run_coset_rows_dev");
     if (coset >= (1u << 16)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_rows_dev: coset %u out of range", coset);
     if (!row_count) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_rows_dev: row_count = 0");
     return quotient_run(ctx, prog, args, (int)coset, row_lo, row_count);

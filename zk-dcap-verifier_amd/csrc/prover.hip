@@ -5,6 +5,8 @@
 // stays on the host in the reference — Fiat-Shamir hashing (Blake2b, src/transcript.rs), point encoding, rotation-set bookkeeping and the O(#points^2)
 // interpolations of SHPLONK.  zk-dcap-verifier_amd/plonk/prover.py + shplonk.py are the Python twin (phase by phase, draw by draw): both must emit the
 // bytes of the independent CPU prover's goldens (tests/test_native_prover.py).  Single circuit instance, no user challenges, Blake2b transcript (stack A).
+#include <stdarg.h>
+#include <stdio.h>
 #include <string.h>
 #include <algorithm>
 #include <atomic>
@@ -13,6 +15,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 #include "field.cuh"
@@ -20,7 +23,17 @@
 
 using namespace zk;
 
+int zk_internal_fail(zk_ctx* ctx, int code, const char* msg);   // capi.hip: sets zk_last_error(ctx)
+
 namespace {
+int pk_fail(zk_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[384];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return zk_internal_fail(ctx, code, buf);
+}
 
 // ---- Blake2b-512 with personalisation (RFC 7693), incremental, copyable ------------------------------------------------------------------------------
 struct Blake2b {
@@ -385,9 +398,41 @@ struct PhaseClock {
 
 }  // namespace
 
+// One proof over several ranks: the ranks run in lockstep from collective to collective, so a rank that fails on its own (out of memory, a HIP error, its witness
+// outside a lookup table, an rng callback error) must not simply return — the others would wait in the next all-gather for ever.  It enters that NEXT exchange once more
+// with a poisoned block (first 32 bytes 0xFF: no field element and no point coordinate has that value) and returns its error; every other rank finds the mark in
+// the gathered blocks and returns ZK_ERR_COMM from the same exchange.  Not covered: a failing collective itself, and a rank that cannot even allocate its exchange
+// buffers — the callback must enforce a timeout for those (include/zkmi355.h, zk_allgather_fn).
+struct ShardSignal {
+    std::vector<size_t> sizes;                                         // bytes of every exchange of this proof, in order (the same list on every rank)
+    size_t next = 0;                                                   // the exchange every healthy rank enters next
+    void* xsend = nullptr; void* xrecv = nullptr;
+    bool armed = false;
+};
+static const uint64_t POISON[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+
+static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
+                             const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len, ShardSignal& sig);
+
 extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
                                      const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len) {
-    if (!ctx || !pk || !rng || !proof_len || (pk->n_advice && !advice)) return ZK_ERR_ARG;
+    ShardSignal sig;
+    const int rc = create_proof_body(ctx, pk, advice, advice_on_device, instances, instance_lens, rng, rng_user, proof_out, proof_cap, proof_len, sig);
+    if (rc != ZK_OK && rc != ZK_ERR_COMM && sig.armed && sig.next < sig.sizes.size()) {
+        std::string why = zk_last_error(ctx) ? zk_last_error(ctx) : "";
+        if (zk_dev_upload(ctx, sig.xsend, POISON, 32) == ZK_OK && zk_dev_sync(ctx) == ZK_OK)
+            (void)pk->allgather(pk->allgather_user, sig.xsend, sig.xrecv, sig.sizes[sig.next]);
+        pk_fail(ctx, rc, "%s [rank %u of a sharded proof: failure signalled to the other ranks in exchange %zu]", why.c_str(), pk->shard_rank, sig.next);
+    }
+    return rc;
+}
+
+static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
+                             const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len, ShardSignal& sig) {
+    if (!ctx || !pk) return ZK_ERR_ARG;
+    if (pk->struct_size != sizeof(zk_plonk_pk_desc))
+        return pk_fail(ctx, ZK_ERR_ARG, "zk_plonk_create_proof: zk_plonk_pk_desc.struct_size %u, expected %zu (ABI version %u)", pk->struct_size, sizeof(zk_plonk_pk_desc), ZK_ABI_VERSION);
+    if (!rng || !proof_len || (pk->n_advice && !advice)) return ZK_ERR_ARG;
     const uint32_t k = pk->k, ek = pk->extended_k, bf = pk->blinding_factors, L = pk->n_lookups;
     const size_t n = (size_t)1 << k, en = (size_t)1 << ek, col_bytes = n * 32;
     if (k < 1 || ek < k || ek > 27 || bf + 2 >= n || pk->cs_degree < 3) return ZK_ERR_ARG;
@@ -435,6 +480,37 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
     for (uint32_t i = 0; i < pk->n_advice; i++) if (!advice[i]) return ZK_ERR_ARG;
     Arena mem(ctx);
     if (pk->transcript > 2) return ZK_ERR_ARG;
+    // exchange buffers of a sharded proof: the caller's (e.g. two torch tensors, so that its callback can hand RCCL tensors) or the proof's own.  First thing of all:
+    // from here on this rank can tell the others about a failure of its own (ShardSignal)
+    void* xsend = nullptr; void* xrecv = nullptr;
+    if (sharded) {
+        const size_t most_cols = std::max<size_t>({pk->n_advice, 2 * (size_t)L, (size_t)n_sets + L, n_pieces, 1});
+        const size_t need = std::max(slots * unit_rows * 32, most_cols * 128);
+        if (pk->xchg_send && pk->xchg_recv) { if (pk->xchg_cap < need) return ZK_ERR_LIMIT; xsend = pk->xchg_send; xrecv = pk->xchg_recv; }
+        else { xsend = mem.get(need); xrecv = mem.get(need * world); if (!xsend || !xrecv) return ZK_ERR_HIP; }
+        for (size_t cols : {(size_t)pk->n_advice, 2 * (size_t)L, (size_t)n_sets + L, (size_t)1}) if (cols) sig.sizes.push_back(cols * 128);   // advice, permuted pairs, grand products, random poly
+        sig.sizes.push_back(slots * unit_rows * 32);                                                                                       // the quotient's numerators
+        for (size_t cols : {(size_t)n_pieces, (size_t)1, (size_t)1}) sig.sizes.push_back(cols * 128);                                        // h pieces, SHPLONK h(X) and quotient
+        sig.xsend = xsend; sig.xrecv = xrecv; sig.armed = true;
+    }
+    // one exchange: the caller's collective (the library's stream is idle when it runs), then the other ranks' failure marks — the first 32 bytes of every rank's block,
+    // read from `gathered_host` when the caller has downloaded the blocks anyway
+    auto exchange = [&](size_t bytes, uint64_t* gathered_host) -> int {
+        if (sig.next >= sig.sizes.size() || sig.sizes[sig.next] != bytes) return pk_fail(ctx, ZK_ERR_ARG, "zk_plonk_create_proof: exchange %zu of %zu bytes is not in the proof's schedule", sig.next, bytes);
+        PK(zk_dev_sync(ctx));
+        const size_t ex = sig.next;
+        sig.next = sig.sizes.size();                                   // (no signalling after a failure in here: the collective itself is in doubt)
+        if (pk->allgather(pk->allgather_user, xsend, xrecv, bytes)) return pk_fail(ctx, ZK_ERR_COMM, "zk_plonk_create_proof: the caller's all-gather failed in exchange %zu", ex);
+        if (gathered_host) PK(zk_dev_download(ctx, gathered_host, xrecv, bytes * world));
+        for (uint32_t r = 0; r < world; r++) {
+            uint64_t head[4];
+            if (gathered_host) memcpy(head, gathered_host + (size_t)r * bytes / 8, 32);
+            else PK(zk_dev_download(ctx, head, (const char*)xrecv + (size_t)r * bytes, 32));
+            if (!memcmp(head, POISON, 32)) return pk_fail(ctx, ZK_ERR_COMM, "zk_plonk_create_proof: rank %u reported a failure of its own in exchange %zu", r, ex);
+        }
+        sig.next = ex + 1;
+        return ZK_OK;
+    };
     Transcript tr((int)pk->transcript);
     Draws draws;
     for (double& v : g_phase_ms) v = 0;
@@ -493,14 +569,6 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         for (uint32_t i = 0; i < pk->n_advice; i++) { bdst[i] = (char*)adv[i] + usable * 32; bsrc[i] = draws.take(i); }
         if (pk->n_advice) PK(zk_dev_upload_batch(ctx, bdst.data(), bsrc.data(), pk->n_advice, (n - usable) * 32));
     }
-    // exchange buffers of a sharded proof: the caller's (e.g. two torch tensors, so that its callback can hand RCCL tensors) or the proof's own
-    void* xsend = nullptr; void* xrecv = nullptr;
-    if (sharded) {
-        const size_t most_cols = std::max<size_t>({pk->n_advice, 2 * (size_t)L, (size_t)n_sets + L, n_pieces, 1});
-        const size_t need = std::max(slots * unit_rows * 32, most_cols * 128);
-        if (pk->xchg_send && pk->xchg_recv) { if (pk->xchg_cap < need) return ZK_ERR_LIMIT; xsend = pk->xchg_send; xrecv = pk->xchg_recv; }
-        else { xsend = mem.get(need); xrecv = mem.get(need * world); if (!xsend || !xrecv) return ZK_ERR_HIP; }
-    }
     auto commit = [&](uint64_t table, const std::vector<void*>& cols) -> int {
         if (cols.empty()) return ZK_OK;
         std::vector<uint64_t> out(cols.size() * 12);
@@ -513,8 +581,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
             std::vector<uint64_t> part(cols.size() * 16), all((size_t)world * cols.size() * 16);
             PK(zk_msm_batch_partial_dev(ctx, table, slice.data(), cols.size(), n_loc, part.data()));
             PK(zk_dev_upload(ctx, xsend, part.data(), bytes));
-            if (pk->allgather(pk->allgather_user, xsend, xrecv, bytes)) return ZK_ERR_COMM;
-            PK(zk_dev_download(ctx, all.data(), xrecv, bytes * world));
+            PK(exchange(bytes, all.data()));
             PK(zk_g1_sum_xyzz_batch(all.data(), world, cols.size(), out.data()));
         }
         for (size_t i = 0; i < cols.size(); i++) tr.write_point(&out[12 * i]);
@@ -533,7 +600,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
             *out = mem.get(col_bytes);
             if (!*out) return ZK_ERR_HIP;
             zk_quotient_args a;
-            memset(&a, 0, sizeof a);
+            ZK_STRUCT_INIT(a);
             a.fixed = pk->fixed_values; a.advice = (const void* const*)adv.data(); a.instance = (const void* const*)inst_values.data();
             a.l0 = a.l_last = a.l_active_row = anycol;
             a.beta = a.gamma = a.y = one.v; a.theta = theta.v; a.challenges = one.v;
@@ -610,7 +677,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         const size_t nA = pk->n_advice, nI = pk->n_instance;
         e_in.clear(); e_tab.clear();
         for (uint32_t l = 0; l < L; l++) { e_in.push_back(ext[nA + nI + n_sets + L + 2 * l]); e_tab.push_back(ext[nA + nI + n_sets + L + 2 * l + 1]); }
-        memset(&a, 0, sizeof a);
+        ZK_STRUCT_INIT(a);
         a.advice = (const void* const*)ext; a.instance = (const void* const*)ext + nA;
         a.perm_products = (const void* const*)ext + nA + nI; a.n_sets = n_sets;
         a.lookup_product = (const void* const*)ext + nA + nI + n_sets; a.lookup_input = e_in.data(); a.lookup_table = e_tab.data();
@@ -661,8 +728,8 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
             if (parts == 1) PK(zk_quotient_run_coset_dev(ctx, pk->program, &a, u.coset));
             else PK(zk_quotient_run_coset_rows_dev(ctx, pk->program, &a, u.coset, u.lo, u.rows));
         }
-        PK(zk_dev_sync(ctx));
-        if (pk->allgather(pk->allgather_user, xsend, xrecv, slots * unit_rows * 32)) return ZK_ERR_COMM;
+        if (units.empty()) PK(zk_dev_zero(ctx, xsend, 32));          // (more ranks than units: nothing of this rank's travels, but its block's head is read as a status)
+        PK(exchange(slots * unit_rows * 32, nullptr));
         std::vector<const void*> srcs(n_cosets);
         for (uint32_t j = 0; j < n_cosets; j++) srcs[j] = (const char*)xrecv + (size_t)j * col_bytes;
         PK(zk_fr_interleave_dev(ctx, srcs.data(), n_cosets, n, h_ext));
@@ -905,6 +972,8 @@ struct PkHandle {
     zk_plonk_pk_desc desc;
     uint64_t program = 0;
     std::vector<uint64_t> in_prog, tab_prog;
+    int in_use = 0;              // zk_plonk_prove calls running on this handle (g_pk_mu)
+    bool released = false;       // zk_plonk_pk_release / zk_ctx_destroy arrived meanwhile: the last of those calls drops the handle
 };
 std::mutex g_pk_mu;
 std::map<std::pair<zk_ctx*, uint64_t>, PkHandle*> g_pk_handles;
@@ -937,6 +1006,8 @@ void pk_drop(zk_ctx* ctx, PkHandle* h) {                              // g_pk_mu
 
 extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk) {
     if (!ctx || !host || !pk) return ZK_ERR_ARG;
+    if (host->struct_size != sizeof(zk_plonk_pk_host))
+        return pk_fail(ctx, ZK_ERR_ARG, "zk_plonk_pk_build: zk_plonk_pk_host.struct_size %u, expected %zu (ABI version %u)", host->struct_size, sizeof(zk_plonk_pk_host), ZK_ABI_VERSION);
     const uint32_t k = host->k, L = host->n_lookups;
     if (k < 1 || k > 27 || host->cs_degree < 3 || host->transcript > 2 || host->draw_schedule > 1 || !host->transcript_repr || !host->evaluator_zkq1) return ZK_ERR_ARG;
     if ((host->n_fixed && !host->fixed_values) || (host->n_perm_columns && (!host->sigma_values || !host->perm_columns)) || (host->n_advice_queries && !host->advice_queries) ||
@@ -1052,7 +1123,7 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
     for (auto* v : {&m->fixed_values, &m->fixed_polys, &m->fixed_cosets, &m->sigma_values, &m->sigma_polys, &m->sigma_cosets, &m->coset_fixed, &m->coset_sigma, &m->coset_l}) v->push_back(nullptr);
     memcpy(m->transcript_repr, host->transcript_repr, 32);
     zk_plonk_pk_desc shape;
-    memset(&shape, 0, sizeof shape);
+    ZK_STRUCT_INIT(shape);
     shape.k = k; shape.extended_k = ek; shape.cs_degree = host->cs_degree; shape.blinding_factors = host->blinding_factors;
     shape.n_fixed = host->n_fixed; shape.n_advice = host->n_advice; shape.n_instance = host->n_instance; shape.n_lookups = L; shape.n_perm_columns = host->n_perm_columns;
     shape.n_advice_queries = host->n_advice_queries; shape.n_fixed_queries = host->n_fixed_queries;
@@ -1093,7 +1164,8 @@ extern "C" int zk_plonk_pk_release(zk_ctx* ctx, uint64_t pk) {
     std::lock_guard<std::mutex> lk(g_pk_mu);
     auto it = g_pk_handles.find({ctx, pk});
     if (it == g_pk_handles.end()) return ZK_ERR_ARG;
-    pk_drop(ctx, it->second);
+    if (it->second->in_use) it->second->released = true;             // a proof is running through this handle on another thread: it drops the handle when it returns
+    else pk_drop(ctx, it->second);
     g_pk_handles.erase(it);
     return ZK_OK;
 }
@@ -1109,17 +1181,28 @@ extern "C" int zk_plonk_pk_descriptor(zk_ctx* ctx, uint64_t pk, const zk_plonk_p
 
 extern "C" int zk_plonk_prove(zk_ctx* ctx, uint64_t pk, const void* const* advice, int advice_on_device, const void* const* instances, const uint32_t* instance_lens,
                               zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len) {
-    const zk_plonk_pk_desc* d = nullptr;
-    int rc = zk_plonk_pk_descriptor(ctx, pk, &d);
-    if (rc) return rc;
-    return zk_plonk_create_proof(ctx, d, advice, advice_on_device, instances, instance_lens, rng, rng_user, proof_out, proof_cap, proof_len);
+    if (!ctx) return ZK_ERR_ARG;
+    PkHandle* h = nullptr;
+    {   // the handle (descriptor, programs, its share of the columns) stays alive for the whole proof whatever other threads release meanwhile
+        std::lock_guard<std::mutex> lk(g_pk_mu);
+        auto it = g_pk_handles.find({ctx, pk});
+        if (it == g_pk_handles.end()) return pk_fail(ctx, ZK_ERR_ARG, "zk_plonk_prove: unknown key %llu", (unsigned long long)pk);
+        h = it->second;
+        h->in_use++;
+    }
+    int rc = zk_plonk_create_proof(ctx, &h->desc, advice, advice_on_device, instances, instance_lens, rng, rng_user, proof_out, proof_cap, proof_len);
+    {
+        std::lock_guard<std::mutex> lk(g_pk_mu);
+        if (--h->in_use == 0 && h->released) pk_drop(ctx, h);
+    }
+    return rc;
 }
 
 // zk_ctx_destroy (capi.hip): the keys this context still holds go with it (before its programs are released)
 void zk_internal_plonk_ctx_destroyed(zk_ctx* ctx) {
     std::lock_guard<std::mutex> lk(g_pk_mu);
     for (auto it = g_pk_handles.begin(); it != g_pk_handles.end();) {
-        if (it->first.first == ctx) { pk_drop(ctx, it->second); it = g_pk_handles.erase(it); }
+        if (it->first.first == ctx) { if (it->second->in_use) it->second->released = true; else pk_drop(ctx, it->second); it = g_pk_handles.erase(it); }
         else ++it;
     }
 }

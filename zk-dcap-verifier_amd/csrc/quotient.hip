@@ -332,7 +332,9 @@ bool read_graph(Reader& r, Graph& g) {
     for (uint32_t i = 0; i < nr; i++) g.rotations.push_back((int32_t)r.get());
     g.num_intermediates = r.get();
     uint32_t ncalc = r.get();
-    if (!r.ok || ncalc > (1u << 22)) return false;
+    // every intermediate is the target of some calculation, so more intermediates than calculations is malformed (and would size the compiler's tables from an
+    // unchecked 32-bit word of the blob)
+    if (!r.ok || ncalc > (1u << 22) || g.num_intermediates > ncalc) return false;
     for (uint32_t i = 0; i < ncalc; i++) {
         Calc c;
         c.op = r.get(); c.target = r.get(); c.s0 = r.vs();
@@ -1207,7 +1209,7 @@ int evaluate_h_host(zk_ctx* ctx, uint64_t pkh, const void* const* advice, const 
         if (rc) return rc;
     }
     zk_quotient_args qa;
-    memset(&qa, 0, sizeof qa);
+    ZK_STRUCT_INIT(qa);
     void* const* dyn = pk->dyn_ext.data();
     qa.fixed = pk->fixed.data(); qa.advice = dyn; qa.instance = dyn + P.n_advice;
     qa.l0 = pk->l[0]; qa.l_last = pk->l[1]; qa.l_active_row = pk->l[2];

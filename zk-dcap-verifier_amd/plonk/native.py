@@ -57,7 +57,8 @@ class TorchExchange:
 
 
 class PkDesc(C.Structure):
-    _fields_ = [("k", C.c_uint32), ("extended_k", C.c_uint32), ("cs_degree", C.c_uint32), ("blinding_factors", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32),
+                ("k", C.c_uint32), ("extended_k", C.c_uint32), ("cs_degree", C.c_uint32), ("blinding_factors", C.c_uint32),
                 ("n_fixed", C.c_uint32), ("n_advice", C.c_uint32), ("n_instance", C.c_uint32), ("n_lookups", C.c_uint32), ("n_perm_columns", C.c_uint32),
                 ("perm_columns", C.c_void_p),
                 ("advice_queries", C.c_void_p), ("n_advice_queries", C.c_uint32),
@@ -107,6 +108,8 @@ class NativeProver:
         repr_bytes = np.frombuffer(int(pk.vk.transcript_repr).to_bytes(32, "little"), dtype=np.uint8).copy()
         self._keep.append(repr_bytes)
         d = PkDesc()
+        d.struct_size = C.sizeof(PkDesc)
+        assert self.be.lib.zk_abi_struct_size(b"zk_plonk_pk_desc") == C.sizeof(PkDesc), "PkDesc has fallen behind include/zkmi355.h"
         d.k, d.extended_k, d.cs_degree, d.blinding_factors = params.k, pk.domain.extended_k, cs.degree(), cs.blinding_factors()
         d.n_fixed, d.n_advice, d.n_instance = cs.num_fixed_columns, cs.num_advice_columns, cs.num_instance_columns
         d.n_lookups, d.n_perm_columns = len(cs.lookups), len(cs.permutation_columns)

@@ -376,25 +376,30 @@ def cpu_baseline(cfg, threads, program_for=None, verify=None, ntt_checks=(), shi
     n = 1 << k
     sc = rand_fr(n, 1)
     bases = orc.gen_bases_arith(5, 3, n, threads=threads)
-    t = time.time(); orc.best_multiexp(sc, bases, threads=threads); t_msm = time.time() - t
+
+    def median3(f):                                                   # one call of a primitive is noisy on a shared 256-thread host: the median of three
+        ts = []
+        for _ in range(3):
+            t = time.time(); f(); ts.append(time.time() - t)
+        return sorted(ts)[1]
+    t_msm = median3(lambda: orc.best_multiexp(sc, bases, threads=threads))
     w = orc.Domain(cfg["d"], k)
-    t = time.time(); w.lagrange_to_coeff(sc, threads=threads); t_intt = time.time() - t
-    t = time.time(); w.coeff_to_extended(sc, threads=threads); t_ext = time.time() - t
-    # quotient on 2^14 rows of the same program shape, scaled by rows
+    t_intt = median3(lambda: w.lagrange_to_coeff(sc, threads=threads))
+    t_ext = median3(lambda: w.coeff_to_extended(sc, threads=threads))
+    # quotient on 2^17 rows of the same program shape, scaled by rows
     import zk_dcap_verifier_amd as z
-    ks = 12
+    ks = min(k, 17 - (ek - k))
     prog = program_for(ks, ks + (ek - k)) if program_for else sgx_shaped_program(z, ks, ks + (ek - k), cfg["A"], cfg["F"], cfg["L"], cfg["n_perm"], cfg["d"])
     size = 1 << (ks + ek - k)
     col = rand_fr(size, 3)
     P = (cfg["n_perm"] + cfg["d"] - 3) // (cfg["d"] - 2)
-    t = time.time()
-    orc.evaluate_h(prog.to_blob(), [col] * cfg["F"], [col] * cfg["A"], [], col, col, col, [col] * cfg["n_perm"], [col] * P, [col] * cfg["L"], [col] * cfg["L"],
-                   [col] * cfg["L"], [], col[0], col[1], col[2], col[3], size, threads=threads)
-    t_q = (time.time() - t) * ((1 << ek) / size)
+    blob = prog.to_blob()
+    t_q = median3(lambda: orc.evaluate_h(blob, [col] * cfg["F"], [col] * cfg["A"], [], col, col, col, [col] * cfg["n_perm"], [col] * P, [col] * cfg["L"], [col] * cfg["L"],
+                                         [col] * cfg["L"], [], col[0], col[1], col[2], col[3], size, threads=threads)) * ((1 << ek) / size)
     total = cfg["n_msm"] * t_msm + cfg["n_intt"] * t_intt + (cfg["n_ext"] + 1) * t_ext + t_q
     out = {"value": round(3600.0 / total, 3), "unit": "proofs/hour", "cores": threads, "kind": "port",
-           "sample": f"1 best_multiexp(2^{k}) {t_msm:.2f}s x{cfg['n_msm']}, 1 lagrange_to_coeff {t_intt:.3f}s x{cfg['n_intt']}, "
-                     f"1 coeff_to_extended(2^{ek}) {t_ext:.3f}s x{cfg['n_ext'] + 1}, evaluate_h on 2^{ks + ek - k} rows scaled to 2^{ek} = {t_q:.2f}s "
+           "sample": f"median of 3: best_multiexp(2^{k}) {t_msm:.2f}s x{cfg['n_msm']}, lagrange_to_coeff {t_intt:.3f}s x{cfg['n_intt']}, "
+                     f"coeff_to_extended(2^{ek}) {t_ext:.3f}s x{cfg['n_ext'] + 1}, evaluate_h on 2^{ks + ek - k} rows scaled to 2^{ek} = {t_q:.2f}s "
                      "(grand products, lookup permutation, evaluations and SHPLONK of the CPU prover are NOT counted: the baseline is optimistic); "
                      "C restatement of halo2 CPU algorithms (pthreads), not the Rust binary"}
     if shim is not None:
@@ -661,7 +666,11 @@ def main(argv=None):
     sort_ms, _ = tsum("msm_sort")
     red_ms, _ = tsum("msm_reduce")
     q_ms, q_n = tsum("quotient")
-    be_stats = {"msm_columns": sum(b.stat_get("msm_columns") for b in bes), "msm_pairs": sum(b.stat_get("msm_pairs") for b in bes)}
+    ntt_s_ms, ntt_s_n = tsum("ntt_strided_pass")
+    ntt_f_ms, ntt_f_n = tsum("ntt_final_pass")
+    be_stats = {"msm_columns": sum(b.stat_get("msm_columns") for b in bes), "msm_pairs": sum(b.stat_get("msm_pairs") for b in bes),
+                "ntt_points": sum(b.stat_get("ntt_points") for b in bes), "ntt_pass_points": sum(b.stat_get("ntt_pass_points") for b in bes),
+                "quotient_alg_bytes": sum(b.stat_get("quotient_alg_bytes") for b in bes)}
     for b in bes:
         b.timing(False)
     if dist is not None:
@@ -686,12 +695,22 @@ def main(argv=None):
     achieved = 96.0 * wl.n * msm_columns / acc_s / 1e9
     # HBM bytes per launch from the PMC counters: they cannot be collected inside this run (separate rocprofv3 --pmc passes, MI355X_MICROARCH.md), so the
     # figure is the one of the last profiling session (tools/collect_profiles.sh + tools/summarize_profiles.py), cited with its source
-    traffic, traffic_source = None, None
+    # Two readings of the same counters are given, because the guide's x2 on FETCH_SIZE is calibrated for wide coalesced streaming reads only and this kernel's reads
+    # are 64-byte gathers (one table point per pair): `raw` = (FETCH_SIZE + WRITE_SIZE) KB x 1024 as counted, `doubled_fetch` = (2 FETCH_SIZE + WRITE_SIZE) x 1024; the
+    # kernel's own design traffic (`expected_gather_bytes`: 64 B per pair + its 4-byte reference) lies next to `raw`, which is the reading that applies to gathers
+    # (tools/microbench `gather64` under --pmc FETCH_SIZE calibrates it: DESIGN.md 5).
+    traffic, traffic_source, tjd = None, None, {}
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         try:
             tjd = json.load(open(tj))
-            traffic, traffic_source = tjd.get("msm_accumulate_bytes_per_launch"), tjd.get("source", "").split(" (")[0]
+            traffic_source = tjd.get("source", "").split(" (")[0]
+            kern = tjd.get("kernels", {}).get("msm_accumulate_kernel")
+            if kern:
+                traffic = {"raw": round(kern["fetch_bytes_per_launch"] + kern["write_bytes_per_launch"]),
+                           "doubled_fetch": round(2 * kern["fetch_bytes_per_launch"] + kern["write_bytes_per_launch"])}
+            elif tjd.get("msm_accumulate_bytes_per_launch"):           # (a traffic.json of rounds 1-3: only the doubled reading was kept)
+                traffic = {"raw": None, "doubled_fetch": tjd.get("msm_accumulate_bytes_per_launch")}
         except Exception:
             traffic = None
     # The bucket step in the kernel that ran: on carry-free 29-bit limbs (msm_limb29, the default since round 3: 1467 v_mad_u64_u32, no addc, ~650 other VALU instructions per
@@ -730,6 +749,28 @@ def main(argv=None):
                 # the other throughput-bound kernels, same counters (profiles/traffic.json): NTT passes and the quotient interpreter
                 "other_kernels_pmc": {k_: {c_: valu[k_].get(c_) for c_ in ("ms_per_launch", "valu_busy", "active_valu_per_wave_cycle", "wait_inst_per_wave_cycle", "eff_clock_ghz", "int64_share", "issue_model")}
                                       for k_ in ("ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "quotient_kernel") if k_ in valu} or None}
+    if isinstance(traffic, dict):
+        alg = roofline["algorithmic_bytes_per_launch"]
+        pairs_per_launch = msm_pairs / max(acc_n, 1)
+        traffic["expected_gather_bytes"] = round(pairs_per_launch * 68)    # one 64-byte table point + its 4-byte sorted reference per point addition: the kernel's design traffic
+        traffic["ratio_to_algorithmic"] = {"raw": round(traffic["raw"] / alg, 2) if traffic.get("raw") and alg else None,
+                                           "doubled_fetch": round(traffic["doubled_fetch"] / alg, 2) if traffic.get("doubled_fetch") and alg else None}
+        traffic["applies"] = "raw (64-byte gathers; the x2 of MI355X_MICROARCH.md is for wide coalesced streaming reads)"
+    # Every throughput-bound kernel class with its own line: algorithmic bytes of SURVEY 8d over the kernel's HIP-event time INSIDE the timed
+    # region (event pairs on the library's streams; with several proofs in flight a pair also spans cycles given to other streams' kernels, so these are lower bounds —
+    # `alone` repeats them with one proof in flight when the extras run).
+    def kline(name, alg_bytes, ms, launches, **more):
+        ach = alg_bytes / max(ms * 1e-3, 1e-9) / 1e9 if ms else None
+        return dict({"kernel": name, "bound": "hbm", "algorithmic_bytes": round(alg_bytes), "ms": round(ms, 3) if ms else None, "launches": launches,
+                     "achieved": round(ach, 2) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None}, **more)
+    ntt_ms = (ntt_s_ms or 0.0) + (ntt_f_ms or 0.0)
+    passes = be_stats["ntt_pass_points"] / be_stats["ntt_points"] if be_stats["ntt_points"] else None
+    roofline["kernels"] = [
+        kline("msm_accumulate_kernel", 96.0 * wl.n * msm_columns, acc_ms, acc_n, per_unit="96 B per (scalar, base) pair", int_alu_frac=roofline["int_alu"]["issue_bound_frac"]),
+        kline("ntt_strided_pass29_kernel + ntt_final_pass_kernel", 64.0 * be_stats["ntt_points"], ntt_ms, ntt_s_n + ntt_f_n, per_unit="64 B per point per transform",
+              passes=round(passes, 2) if passes else None, hbm_bytes_moved_estimate=round(64.0 * be_stats["ntt_pass_points"]),
+              strided_ms=round(ntt_s_ms or 0.0, 3), final_ms=round(ntt_f_ms or 0.0, 3)),
+        kline("quotient_kernel", be_stats["quotient_alg_bytes"], q_ms or 0.0, q_n, per_unit="(columns + 1) x 32 B per evaluated row")]
 
     if args.mode == "prove":
         # The same K steps once more with the witness starting in HOST memory (what the Rust boundary hands over: create_proof receives host-owned
@@ -835,9 +876,19 @@ def main(argv=None):
         # (unlike event_span_ms_per_proof_pipelined above) are kernel times
         be.timing(True)
         wl.step()
-        alone = {lab: be.timing_get(lab) for lab in ("msm_sort", "msm_accumulate", "msm_reduce", "quotient")}
+        alone = {lab: be.timing_get(lab) for lab in ("msm_sort", "msm_accumulate", "msm_reduce", "quotient", "ntt_strided_pass", "ntt_final_pass")}
         pairs_alone = be.stat_get("msm_pairs")
+        alone_stats = {lab: be.stat_get(lab) for lab in ("ntt_points", "ntt_pass_points", "quotient_alg_bytes")}
         be.timing(False)
+        # ... and the NTT / quotient lines of roofline.kernels with the GPU to this one proof
+        n_ms = (alone["ntt_strided_pass"][0] or 0.0) + (alone["ntt_final_pass"][0] or 0.0)
+        for kl in roofline["kernels"]:
+            if kl["kernel"].startswith("ntt") and n_ms:
+                kl["alone"] = {"ms": round(n_ms, 3), "achieved": round(64.0 * alone_stats["ntt_points"] / (n_ms * 1e-3) / 1e9, 2),
+                               "frac": round(64.0 * alone_stats["ntt_points"] / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            if kl["kernel"] == "quotient_kernel" and alone["quotient"][0]:
+                kl["alone"] = {"ms": round(alone["quotient"][0], 3), "achieved": round(alone_stats["quotient_alg_bytes"] / (alone["quotient"][0] * 1e-3) / 1e9, 2),
+                               "frac": round(alone_stats["quotient_alg_bytes"] / (alone["quotient"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
         extra["single_proof"]["kernel_ms"] = {lab: round(v[0], 3) for lab, v in alone.items() if v[0] is not None}
         if alone["msm_accumulate"][0]:
             extra["single_proof"]["int_alu_frac_alone"] = round(pairs_alone / (alone["msm_accumulate"][0] * 1e-3) / XYZZ_MADD_PEAK, 4)
@@ -847,6 +898,7 @@ def main(argv=None):
             ach = 96.0 * wl.n * wl.n_msm / (a_ms * 1e-3) / 1e9
             roofline["alone"] = {"avg_launch_ms": round(a_ms / max(a_n, 1), 4), "launches": a_n, "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5),
                                  "what": "one proof with the GPU to itself (extra.single_proof): the kernel's own duration"}
+            roofline["kernels"][0]["alone"] = {"ms": round(a_ms, 3), "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
     cfg = {"k": args.k, "ek": wl.ek, "A": wl.A, "F": wl.F, "L": wl.L, "n_perm": wl.n_perm, "d": wl.d,
            "n_msm": wl.n_msm, "n_intt": wl.n_intt, "n_ext": wl.n_ext}
     cpu = None
@@ -855,6 +907,7 @@ def main(argv=None):
     if rank == 0 and not args.no_extras and world == 1:
         try:
             extra["msm_2^20"] = msm_microbench(be, 20, 20241008, verify=True)
+            extra["msm_2^21"] = msm_microbench(be, 21, 20241012, verify=True)      # the size of BASELINE configs[4]: the N = 1 point of extra.msm_sharded_2^21's curve
             extra["msm_2^24"] = msm_microbench(be, 24, 20241010, reps=2, verify=True)
         except Exception as e:
             extra["msm_microbench_error"] = str(e)

@@ -263,6 +263,21 @@ int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args
  * coset's complete n values (rotations reach outside the slice); args->out receives row_count values.  This is the unit when a proof's quotient is split over
  * MORE ranks than there are cosets (8 GPUs at extended_k = k + 2): ranks that share a coset each evaluate a part of its rows. */
 int zk_quotient_run_coset_rows_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset, uint64_t row_lo, uint64_t row_count);
+/* Degree split of the numerator.  h's numerator is sum_i y^(N-1-i) id_i over the identities halo2 folds with y (gates, permutation, lookups); an identity of
+ * degree d in the columns contributes a share of h(X) of degree below (d - 1) n, which d - 1 cosets of the size-n domain determine.  A program whose constraint system has
+ * degree >= 4 is therefore compiled a second and third time: its HIGH part (identities of degree > 3) is evaluated on every row as before, its LOW part (degree <= 3: halo2-lib's
+ * gates, the boundary / ordering identities of every lookup and permutation set — about half of the arithmetic of the sgx-shaped program) only on the rows of cosets 0 and 1, and
+ * joins through zk_cosets_to_pieces_dev(.., pieces = 2, ..): h = (pieces of the high part) + (the two pieces of the low part).  Same field elements as the unsplit evaluation
+ * whenever the witness satisfies the circuit (every identity then vanishes on the domain, so both shares are polynomials); for a witness that violates it the (invalid) proofs
+ * differ — tune "quot_degree_split" = 0 before zk_quotient_program_load / zk_plonk_pk_build keeps halo2's bytes there too.
+ * zk_quotient_program_split: *low_cosets = 2 when `prog` carries the two parts, 0 when it does not (then only zk_quotient_run*_dev above apply).
+ * zk_quotient_run_high_dev: as zk_quotient_run_dev, high part only.  zk_quotient_run_low_dev: columns of the whole extended domain as for zk_quotient_run_dev, low part on the
+ * rows of cosets 0 .. low_cosets-1; args->out receives low_cosets x n values, coset-major.  zk_quotient_run_coset_part_dev: as zk_quotient_run_coset_dev, part 1 = high, 2 = low. */
+int zk_quotient_program_split(zk_ctx* ctx, uint64_t prog, uint32_t* low_cosets, uint32_t* n_instr_high, uint32_t* n_instr_low);
+int zk_quotient_program_part_opmix(zk_ctx* ctx, uint64_t prog, uint32_t part, uint32_t counts[9]);   /* zk_quotient_program_opmix of part 1 = high / 2 = low */
+int zk_quotient_run_high_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args);
+int zk_quotient_run_low_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t low_cosets);
+int zk_quotient_run_coset_part_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset, uint32_t part);
 int zk_coeff_to_coset_batch_dev(zk_ctx* ctx, const void* const* coeffs_dev, void* const* outs_dev, size_t count, uint32_t k, uint32_t extended_k, uint32_t coset);
 int zk_fr_interleave_dev(zk_ctx* ctx, const void* const* cosets_dev, size_t count, size_t n, void* out_dev);   /* out[i * count + j] = cosets[j][i] */
 /* The pieces of h(X) straight from the numerator's values on cosets 0 .. pieces-1 (vanishing::Argument::construct: divide_by_vanishing_poly + extended_to_coeff + the split
@@ -330,7 +345,7 @@ typedef struct zk_plonk_pk_desc {
     uint32_t transcript;                      /* 0: Blake2bWrite + Challenge255, y-parity flag in bit 255 (stack A, sgx_dcap_verifier.rs:813);
                                                * 1: snark-verifier PoseidonTranscript<NativeLoader> (T = 3, RATE = 2, R_F = 8, R_P = 57), flag in bit 254 (stack B gen_proof, base.rs:200-212);
                                                * 2: snark-verifier EvmTranscript (Keccak-256, 32-byte big-endian words, uncompressed points; gen_evm_proof_shplonk, base.rs:193-199) */
-    uint32_t draw_schedule;                   /* order in which the caller's rng is consumed (see zk_rng_fn): 1 = halo2's (bindings set this), 0 = this library's rounds 1-2 */
+    uint32_t draw_schedule;                   /* order in which the caller's rng is consumed (see zk_rng_fn): 1 = halo2_proofs v2023_01_20 (PSE; stack A). The only schedule: any other value is ZK_ERR_ARG */
     /* ---- one proof over shard_world GPUs, one process / context per GPU; shard_world <= 1 = single GPU and everything below is ignored ---------------------- *
      * MSM: srs_g / srs_g_lagrange are tables of n / shard_world points holding bases [shard_rank * n / shard_world, ...) of params.g / params.g_lagrange; every
      *   commitment phase is one partial MSM batch per rank on its slice of the scalars + ONE all-gather of 128-byte XYZZ points, summed on every rank.
@@ -359,7 +374,9 @@ typedef struct zk_plonk_pk_desc {
  *   lookup/prover.rs           per lookup product: blinding_factors rows, one Blind
  *   vanishing/prover.rs        commit: the n coefficients of the random polynomial, one Blind;  construct: one Blind per h(X) piece
  * so a proof consumes exactly the draws the CPU create_proof would and leaves the caller's rng in the same state (all draws are complete when the call returns ZK_OK).
- * draw_schedule 0 is the order of this library's first two rounds (no Blind draws; every lookup's input rows before any table rows), kept for its golden proofs. */
+ * Stack B's prover (halo2-axiom 0.4.2) is NOT claimed draw for draw: that fork commits with Blind::default() and is believed not to draw the Blinds ([3P-MEM], source
+ * absent here), so under transcripts 1 / 2 the proofs verify and are deterministic in the rng stream, but byte parity with the axiom CPU prover is out of scope until its
+ * schedule is pinned by shim/p256_k18_driver's dump.  Multi-phase advice and the Challenge API are not modelled either (zk_plonk_pk_build's caller must not pass such circuits). */
 typedef void (*zk_rng_fn)(void* user, size_t n, void* out_fr);
 /* advice: n_advice columns of 2^k x 32 B (HOST, or DEVICE when advice_on_device — then consumed: they hold coefficients afterwards); instances: HOST,
  * instance_lens[c] canonical 32-byte values per instance column.  The proof (32 bytes per commitment and per evaluation; 64 per commitment under transcript 2) is written to proof_out;

@@ -262,18 +262,15 @@ def _permute_expression_pair(inp, tab, usable, blind_in, blind_tab):
     return a + list(blind_in), s + list(blind_tab)
 
 
-def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.Generator, require_satisfied: bool = True, draw_schedule: int = 1) -> bytes:
+def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.Generator, require_satisfied: bool = True) -> bytes:
     """advice: cs.num_advice_columns lists of n canonical ints (rows past the usable ones are overwritten with blinding); instances: lists of
     canonical ints.  Returns the proof bytes (Blake2b transcript).  require_satisfied = False: behave as halo2 does on a witness that violates a gate —
     no check, extended_to_coeff silently truncates h(X) to (d-1) n coefficients (poly/domain.rs) — instead of stopping (differential tests on random circuits).
-    draw_schedule: 1 = every Fr::random of halo2's provers in place, including the Blind each commitment draws (`blind()` below: drawn and dropped, as KZG does);
-    0 = the order of this repo's rounds 1-2 (no Blind draws, the lookups' input rows all before their table rows) — kept for the first set of golden proofs."""
-    assert draw_schedule in (0, 1)
+    Every Fr::random of halo2's provers is drawn in place, including the Blind each commitment draws (`blind()` below: drawn and dropped, as KZG does)."""
 
     def blind(times=1):                                              # `Blind(Scheme::Scalar::random(&mut rng))`: the stream advances, the value is unused under KZG
-        if draw_schedule == 1:
-            for _ in range(times):
-                rand_fr(rng, 1)
+        for _ in range(times):
+            rand_fr(rng, 1)
     cs, k, n = keys.cs, params.k, params.n
     w = p.omega(k)
     ek = _extended_k(cs, k)
@@ -315,17 +312,12 @@ def create_proof(params: Params, keys: Keys, advice, instances, rng: np.random.G
             out.append(acc)
         return out
     compressed = [(compress(lk.input_expressions), compress(lk.table_expressions)) for lk in cs.lookups]
-    if draw_schedule == 1:                                           # lookup/prover.rs commit_permuted, lookup by lookup: permute_expression_pair extends the input
-        permuted = []                                                # then the table with random rows, commit_values draws one Blind per commitment
-        for cin_, ctab_ in compressed:
-            bi_ = rand_fr(rng, bf + 1)
-            bt_ = rand_fr(rng, bf + 1)
-            permuted.append(_permute_expression_pair(cin_, ctab_, usable, bi_, bt_))
-            blind(2)
-    else:
-        bi = [rand_fr(rng, bf + 1) for _ in range(L)]
-        bt = [rand_fr(rng, bf + 1) for _ in range(L)]
-        permuted = [_permute_expression_pair(c[0], c[1], usable, bi[j], bt[j]) for j, c in enumerate(compressed)]
+    permuted = []                                                    # lookup/prover.rs commit_permuted, lookup by lookup: permute_expression_pair extends the input
+    for cin_, ctab_ in compressed:                                   # then the table with random rows, commit_values draws one Blind per commitment
+        bi_ = rand_fr(rng, bf + 1)
+        bt_ = rand_fr(rng, bf + 1)
+        permuted.append(_permute_expression_pair(cin_, ctab_, usable, bi_, bt_))
+        blind(2)
     for a_, s_ in permuted:
         tr.write_point(params.commit_lagrange(a_))
         tr.write_point(params.commit_lagrange(s_))

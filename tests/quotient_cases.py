@@ -116,6 +116,12 @@ def run_case(be, orc, pyref, pc_mod, prog, seed=5, check_cosets=True):
                       lookup_input=cdev["lookup_input"], lookup_table=cdev["lookup_table"], challenges=chal, beta=beta, gamma=gamma, theta=theta, y=y)
             e.evaluate_h(out=co, coset=j, **kw)
             assert (co.download((n, 4)) == want[j::nc]).all(), ("coset", j)
+            if be.quotient_program_split(e.handle)["low_cosets"]:      # the two parts on coset-layout columns (zk_quotient_run_coset_part_dev) add up to the coset's numerator
+                p1, p2 = be.alloc(n * 32), be.alloc(n * 32)
+                e.evaluate_h(out=p1, coset=j, part=1, **kw)
+                e.evaluate_h(out=p2, coset=j, part=2, **kw)
+                assert (orc.fr_add(p1.download((n, 4)), p2.download((n, 4))) == want[j::nc]).all(), ("split, coset layout", j)
+                p1.free(); p2.free()
             parts = 4 if n >= 4 else 1
             rows = n // parts
             for p_ in range(parts):
@@ -128,6 +134,22 @@ def run_case(be, orc, pyref, pc_mod, prog, seed=5, check_cosets=True):
                     d.free()
             for d in cl + [co]:
                 d.free()
+    # the degree split (include/zkmi355.h): on every row the numerator is the sum of its high and low parts — for ANY column values, the split is pure algebra
+    # (a sum of y-weighted identities regrouped) — with the low part evaluated on the rows of cosets 0 and 1 only, coset-major
+    sp = be.quotient_program_split(e.handle)
+    if sp["low_cosets"]:
+        n, nc, lc = 1 << prog.k, 1 << e_bits, sp["low_cosets"]
+        assert lc == 2 and sp["instructions_high"] and sp["instructions_low"]
+        kw = dict(fixed=dev["fixed"], advice=dev["advice"], instance=dev["instance"], l0=d_l0, l_last=d_ll, l_active_row=d_la, perm_cosets=dev["perm_cosets"],
+                  perm_products=dev["perm_products"], lookup_product=dev["lookup_product"], lookup_input=dev["lookup_input"], lookup_table=dev["lookup_table"],
+                  challenges=chal, beta=beta, gamma=gamma, theta=theta, y=y)
+        hi, lo = be.alloc(size * 32), be.alloc(lc * n * 32)
+        e.evaluate_h(out=hi, part=1, **kw)
+        e.evaluate_h(out=lo, part=2, low_cosets=lc, **kw)
+        h_hi, h_lo = hi.download((size, 4)), lo.download((lc * n, 4))
+        for j in range(lc):
+            assert (orc.fr_add(np.ascontiguousarray(h_hi[j::nc]), np.ascontiguousarray(h_lo[j * n:(j + 1) * n])) == want[j::nc]).all(), ("split, extended layout, coset", j)
+        hi.free(); lo.free()
     e.release()
     for v in dev.values():
         for d in v:

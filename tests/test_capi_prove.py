@@ -20,11 +20,11 @@ def _run(exe, path, tune=None, world=None):
     return subprocess.run([os.path.join(ROOT, "tests", "csrc", exe), str(path)] + ([str(world)] if world else []), capture_output=True, text=True, timeout=900, env=env)
 
 
-@pytest.mark.parametrize("which,sched", [("toy", 1), ("toy", 0), ("sgx", 1), ("p256", 1)])
-def test_plain_c_prover_reproduces_the_goldens_emulated(emu, orc, tmp_path, which, sched):
+@pytest.mark.parametrize("which", ["toy", "sgx", "p256"])
+def test_plain_c_prover_reproduces_the_goldens_emulated(emu, orc, tmp_path, which):
     """("p256": a degree-4 circuit — zk_plonk_pk_build keeps three cosets of the key instead of its extended forms and the prover takes h(X) from them: tests/test_piece_cosets.py)"""
     import dump_pk_blob as dp
-    blob = dp.toy_blob(emu, 6, 7, sched) if which == "toy" else dp.p256_blob(emu, 7, 18, sched) if which == "p256" else dp.sgx_blob(emu, 8, 3, "chip_estimate", sched)
+    blob = dp.toy_blob(emu, 6, 7) if which == "toy" else dp.p256_blob(emu, 7, 18) if which == "p256" else dp.sgx_blob(emu, 8, 3, "chip_estimate")
     path = tmp_path / "pk.zkpk"
     path.write_bytes(blob)
     r = _run("capi_prove_emu", path, EMU_TUNE)
@@ -37,7 +37,7 @@ def test_plain_c_prover_sharded_over_ranks_emulated(emu, orc, tmp_path, world):
     each, 8 ranks half a coset; the zk_allgather_fn is a barrier + device copies.  Every rank must emit the golden proof."""
     import dump_pk_blob as dp
     path = tmp_path / "pk.zkpk"
-    path.write_bytes(dp.toy_blob(emu, 6, 7, 1))
+    path.write_bytes(dp.toy_blob(emu, 6, 7))
     r = _run("capi_prove_emu", path, EMU_TUNE, world)
     assert r.returncode == 0 and f"{world} ranks" in r.stdout and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
 

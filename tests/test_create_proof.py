@@ -21,11 +21,6 @@ GOLDEN_SGX = "sgx_shaped_k8_seed3.bin"       # the same for the sgx_dcap_verifie
 GOLDEN_REF_EXACT = "reference_exact_k9_seed3.bin"   # ... and for census B (the reference's base64 sub-circuit built exactly) at k = 9
 
 
-def sched0(name):
-    """the same golden under draw schedule 0 (this repo's rounds 1-2; tests/golden/README.md)"""
-    return name.replace(".bin", "_sched0.bin")
-
-
 def _golden(name=GOLDEN_PROOF):
     import os
     from conftest import ROOT
@@ -90,7 +85,7 @@ def test_mock_prover_mirrors_the_first_step_of_the_reference_test():
         assert needle in str(e.value), (what, str(e.value))
 
 
-def prove(be, k, seed=1, draw_schedule=1, **kw):
+def prove(be, k, seed=1, **kw):
     """the reference test's sequence (sgx_dcap_verifier.rs:790-823): MockProver, gen_srs, keygen_vk/pk, create_proof"""
     cs, fixed, asm, advice, instances = toy_circuit(k, **kw)
     if k <= 10 and not kw.get("tamper"):
@@ -98,7 +93,7 @@ def prove(be, k, seed=1, draw_schedule=1, **kw):
     params = z.kzg.ParamsKZG.setup(k, TAU, backend=be)
     pk = plonk.keygen(params, cs, fixed, asm)
     tr = Blake2bWrite()
-    info = plonk.create_proof(params, pk, advice, instances, np.random.default_rng(seed), tr, draw_schedule=draw_schedule)
+    info = plonk.create_proof(params, pk, advice, instances, np.random.default_rng(seed), tr)
     proof = tr.finalize()
     vk = pk.vk
     pk.release()
@@ -247,8 +242,7 @@ def test_cpu_prover_reproduces_the_committed_goldens(orc):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_golden_proof as gg
     for name, (t_, cs, instances, (keys, proof)) in ((GOLDEN_PROOF, gg.toy()), (GOLDEN_SGX, gg.sgx_shaped()),
-                                                     (GOLDEN_REF_EXACT, gg.sgx_shaped(9, 3, "reference_exact")),
-                                                     (sched0(GOLDEN_PROOF), gg.toy(draw_schedule=0)), (sched0(GOLDEN_SGX), gg.sgx_shaped(draw_schedule=0))):
+                                                     (GOLDEN_REF_EXACT, gg.sgx_shaped(9, 3, "reference_exact"))):
         assert proof == _golden(name), name
         assert verifier.verify_proof(keys, TAU, instances, proof) is True
 
@@ -263,7 +257,6 @@ def test_golden_proof_is_accepted_and_reproduced_on_the_emulator(emu, orc):
     vk, instances, proof, _ = prove(emu, 6, seed=7)
     assert proof == _golden()
     assert verifier.verify_proof(vk, TAU, instances, _golden()) is True
-    assert prove(emu, 6, seed=7, draw_schedule=0)[2] == _golden(sched0(GOLDEN_PROOF)) != proof
 
 
 @pytest.mark.gpu
@@ -272,7 +265,6 @@ def test_gpu_emits_the_golden_proof_bytes(gpu, orc):
     (oracle/prover.py) emitted (every MSM / NTT / quotient / sort result is a canonical value): the north star's bit-exactness claim, end to end.
     The sgx-shaped golden is compared in test_sgx_shaped_circuit_proof_verifies_gpu[8]."""
     assert prove(gpu, 6, seed=7)[2] == _golden()
-    assert prove(gpu, 6, seed=7, draw_schedule=0)[2] == _golden(sched0(GOLDEN_PROOF))
 
 
 def p256_shaped_circuit(k):

@@ -184,21 +184,15 @@ def test_emulated_run_length_msm(emu, orc, pyref):
     _check_run_length_msm(emu, orc, pyref, 2500)
 
 
-@pytest.mark.parametrize("mode", [0, 2])
-def test_ntt_and_domain_on_the_other_limb_forms(emu, orc, pyref, mode):
-    """ntt_limb29 = 1 (the default: strided passes on 29-bit limbs, final pass 32-bit) is what every other test runs; 0 = all passes 32-bit (round 2), 2 = all passes on
-    29-bit limbs (the final pass then ends with the quotient-estimate reduction) stay selectable and must give the same values, two-level twiddles included"""
-    emu.tune(ntt_limb29=mode)
+def test_ntt_with_two_level_inter_pass_twiddles(emu, orc, pyref):
+    """ntt_full_twiddle_max_log = 0: the strided passes take their inter-pass twiddles from the two-level power tables (what transforms above 2^24 do) instead of a full table"""
+    emu.tune(ntt_full_twiddle_max_log=0)
     try:
-        for log_n in (1, 2, 5, 9, 12):
-            pc.check_ntt(emu, orc, pyref, log_n, seed=40 + log_n)
-        pc.check_domain(emu, orc, pyref, 4, 5)
+        for log_n in (5, 9, 12):
+            pc.check_ntt(emu, orc, pyref, log_n, seed=7 + log_n)
         pc.check_domain(emu, orc, pyref, 9, 3)
-        pc.check_domain_batch(emu, orc, pyref, 4, 5, 3)
-        emu.tune(ntt_full_twiddle_max_log=0)
-        pc.check_ntt(emu, orc, pyref, 9, seed=7)
     finally:
-        emu.tune(ntt_limb29=1, ntt_full_twiddle_max_log=24)
+        emu.tune(ntt_full_twiddle_max_log=24)
 
 
 def test_msm_on_the_32_bit_bucket_chain(emu, orc, pyref):

@@ -192,19 +192,15 @@ def test_run_length_msm_gpu(gpu, orc, pyref):
     _check_run_length_msm(gpu, orc, pyref, 40000)
 
 
-@pytest.mark.parametrize("mode", [0, 2])
-def test_ntt_and_domain_on_the_other_limb_forms(gpu, orc, pyref, mode):
-    """ntt_limb29 0 (all passes 32-bit) and 2 (all passes on 29-bit limbs) against the oracle; 1 — strided passes 29-bit, final pass 32-bit — is the default everywhere else"""
-    gpu.tune(ntt_limb29=mode)
+def test_ntt_with_two_level_inter_pass_twiddles(gpu, orc, pyref):
+    """ntt_full_twiddle_max_log = 0: inter-pass twiddles from the two-level power tables (the path of transforms above 2^24)"""
+    gpu.tune(ntt_full_twiddle_max_log=0)
     try:
-        for log_n in (4, 10, 14, 17):
-            pc.check_ntt(gpu, orc, pyref, log_n, seed=40 + log_n)
+        for log_n in (10, 14, 17):
+            pc.check_ntt(gpu, orc, pyref, log_n, seed=7 + log_n)
         pc.check_domain(gpu, orc, pyref, 5, 12)
-        pc.check_domain_batch(gpu, orc, pyref, 4, 6, 3)
-        gpu.tune(ntt_full_twiddle_max_log=0)
-        pc.check_ntt(gpu, orc, pyref, 14, seed=7)
     finally:
-        gpu.tune(ntt_limb29=1, ntt_full_twiddle_max_log=24)
+        gpu.tune(ntt_full_twiddle_max_log=24)
 
 
 def test_msm_on_the_32_bit_bucket_chain(gpu, orc, pyref):

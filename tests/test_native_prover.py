@@ -11,15 +11,15 @@ from zk_dcap_verifier_amd.transcript import Blake2bWrite
 import test_create_proof as tcp
 
 
-def _toy(be, k, seed, draw_schedule=1):
+def _toy(be, k, seed):
     import verifier
     cs, fixed, asm, advice, instances = tcp.toy_circuit(k)
     params = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
     pk = plonk.keygen(params, cs, fixed, asm)
-    native = plonk.NativeProver(params, pk, draw_schedule=draw_schedule)
+    native = plonk.NativeProver(params, pk)
     proof = native.create_proof([a.copy() for a in advice], instances, np.random.default_rng(seed))
     tr = Blake2bWrite()
-    plonk.create_proof(params, pk, [a.copy() for a in advice], instances, np.random.default_rng(seed), tr, draw_schedule=draw_schedule)
+    plonk.create_proof(params, pk, [a.copy() for a in advice], instances, np.random.default_rng(seed), tr)
     assert proof == tr.finalize()
     assert verifier.verify_proof(pk.vk, tcp.TAU, instances, proof) is True
     # device-resident witness: same bytes
@@ -30,7 +30,7 @@ def _toy(be, k, seed, draw_schedule=1):
     return proof
 
 
-def _sgx(be, k, census, golden=None, draw_schedule=1):
+def _sgx(be, k, census, golden=None):
     import os, sys
     import verifier
     from conftest import ROOT
@@ -39,7 +39,7 @@ def _sgx(be, k, census, golden=None, draw_schedule=1):
     cs, fixed, asm, advice = sc.build(z, be, k, census=census)
     params = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
     pk = plonk.keygen(params, cs, fixed, asm)
-    proof = plonk.NativeProver(params, pk, draw_schedule=draw_schedule).create_proof(advice, [], np.random.default_rng(3))
+    proof = plonk.NativeProver(params, pk).create_proof(advice, [], np.random.default_rng(3))
     if golden:
         assert proof == tcp._golden(golden)
     assert verifier.verify_proof(pk.vk, tcp.TAU, [], proof) is True
@@ -56,14 +56,44 @@ def test_native_prover_emits_the_sgx_shaped_goldens_emulated(emu, orc):
     _sgx(emu, 9, "reference_exact", tcp.GOLDEN_REF_EXACT)
 
 
-def test_native_prover_draw_schedule_0_goldens_emulated(emu, orc):
-    """the order of Fr::random draws of this repo's rounds 1-2 (no Blind draws, lookup input rows before table rows) still gives the first set of goldens"""
-    assert _toy(emu, 6, 7, draw_schedule=0) == tcp._golden(tcp.sched0(tcp.GOLDEN_PROOF))
-    _sgx(emu, 8, "chip_estimate", tcp.sched0(tcp.GOLDEN_SGX), draw_schedule=0)
+def _split_on_off(be, k, census):
+    """the degree split of the quotient (low-degree identities on two cosets, include/zkmi355.h) changes no byte of a valid proof: same circuit, witness and draws with the
+    split compiled in (the default: asserted through zk_quotient_program_split) and without it"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sgx_shaped_circuit as sc
+    proofs = []
+    for split in (1, 0):
+        be.tune(quot_degree_split=split)
+        try:
+            cs, fixed, asm, advice = sc.build(z, be, k, census=census)
+            params = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
+            pk = plonk.keygen(params, cs, fixed, asm)
+            sp = be.quotient_program_split(pk.evaluator.handle)
+            assert (sp["low_cosets"] == 2 and sp["instructions_high"] > 0 and sp["instructions_low"] > 0) if split else sp["low_cosets"] == 0, sp
+            proofs.append(plonk.NativeProver(params, pk).create_proof(advice, [], np.random.default_rng(3)))
+            pk.release()
+            params.release()
+        finally:
+            be.tune(quot_degree_split=1)
+    assert proofs[0] == proofs[1]
+    return proofs[0]
+
+
+def test_degree_split_changes_no_proof_byte_emulated(emu, orc):
+    assert _split_on_off(emu, 8, "chip_estimate") == tcp._golden(tcp.GOLDEN_SGX)
+
+
+@pytest.mark.gpu
+def test_degree_split_changes_no_proof_byte_gpu(gpu, orc):
+    assert _split_on_off(gpu, 8, "chip_estimate") == tcp._golden(tcp.GOLDEN_SGX)
+    assert _split_on_off(gpu, 9, "reference_exact") == tcp._golden(tcp.GOLDEN_REF_EXACT)
+    _split_on_off(gpu, 13, "chip_estimate")
 
 
 def test_draw_schedule_leaves_the_callers_rng_where_halo2_would(emu, orc):
-    """Under schedule 1 a proof consumes exactly draw_plan's draws — blinding rows, random polynomial AND the Blind(Fr::random) of every commitment (advice,
+    """A proof consumes exactly draw_plan's draws — blinding rows, random polynomial AND the Blind(Fr::random) of every commitment (advice,
     permuted pairs, grand products, random polynomial, h pieces) — and all of them are made before zk_plonk_create_proof returns, so a caller that proves twice
     with one seeded rng (the shape of a Rust caller's `&mut rng`) gets the same two proofs from the native prover and from the Python twin; the running
     totals per challenge are what shim/sgx_k19_driver's counting RNG dumps (tests/test_rust_vectors.py kind 5)."""
@@ -85,11 +115,10 @@ def test_draw_schedule_leaves_the_callers_rng_where_halo2_would(emu, orc):
     bf, n = cs.blinding_factors(), 1 << 6
     chunk = cs.permutation_chunk_len()
     n_sets = -(-len(cs.permutation_columns) // chunk)
-    plan = draw_plan(cs.num_advice_columns, len(cs.lookups), n_sets, cs.degree() - 1, n, bf, 1)
+    plan = draw_plan(cs.num_advice_columns, len(cs.lookups), n_sets, cs.degree() - 1, n, bf)
     total = sum(c for _, _, c, _ in plan)
     A, L = cs.num_advice_columns, len(cs.lookups)
     assert total == A * (bf + 1) + A + L * (2 * (bf + 1) + 2) + n_sets * (bf + 1) + L * (bf + 1) + n + 1 + (cs.degree() - 1)
-    assert sum(c for _, _, c, _ in draw_plan(A, L, n_sets, cs.degree() - 1, n, bf, 0)) == A * (bf + 1) + L * 2 * (bf + 1) + (n_sets + L) * bf + n
     pk.release()
     params.release()
 
@@ -195,10 +224,6 @@ def test_native_prover_goldens_gpu(gpu, orc):
     assert _toy(gpu, 6, 7) == tcp._golden(tcp.GOLDEN_PROOF)
     _sgx(gpu, 8, "chip_estimate", tcp.GOLDEN_SGX)
     _sgx(gpu, 9, "reference_exact", tcp.GOLDEN_REF_EXACT)
-    # ... and the first set (draw schedule 0)
-    assert _toy(gpu, 6, 7, draw_schedule=0) == tcp._golden(tcp.sched0(tcp.GOLDEN_PROOF))
-    _sgx(gpu, 8, "chip_estimate", tcp.sched0(tcp.GOLDEN_SGX), draw_schedule=0)
-    _sgx(gpu, 9, "reference_exact", tcp.sched0(tcp.GOLDEN_REF_EXACT), draw_schedule=0)
 
 
 @pytest.mark.gpu

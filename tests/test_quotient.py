@@ -296,55 +296,15 @@ def test_gpu_bench_program(gpu, orc, pyref):
 
 
 
-@pytest.mark.parametrize("seed,shape", SHAPES[:2])
-def test_emulated_quotient_two_rows_per_thread(emu, orc, pyref, seed, shape):
-    """quot_rows = 2: one micro-op decode serves two rows of the extended domain; same values."""
-    emu.tune(quot_rows=2, quot_threads=4)
-    try:
-        qc.run_case(emu, orc, pyref, pc, qc.build_program(orc, pyref, seed=seed, **shape), seed=seed)
-    finally:
-        emu.tune(quot_rows=1, quot_threads=32)
+DENSE = dict(k=4, cs_degree=5, n_fixed=4, n_advice=6, n_instance=1, n_challenges=1, n_perm=7, n_lookups=3)
+
+
+def test_emulated_quotient_dense_program(emu, orc, pyref):
+    """60 gate operations over 6 advice columns, 7 permutation columns, 3 lookups: many live intermediates (LDS slots beyond the register slot)"""
+    qc.run_case(emu, orc, pyref, pc, qc.build_program(orc, pyref, seed=5, gate_ops=60, **DENSE), seed=5)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,shape", [SHAPES[0], (5, dict(k=10, cs_degree=5, n_fixed=4, n_advice=6, n_instance=1, n_challenges=1, n_perm=7, n_lookups=3))])
-def test_gpu_quotient_two_rows_per_thread(gpu, orc, pyref, seed, shape):
-    gpu.tune(quot_rows=2)
-    try:
-        qc.run_case(gpu, orc, pyref, pc, qc.build_program(orc, pyref, seed=seed, gate_ops=60 if shape["k"] >= 10 else 24, **shape), seed=seed)
-    finally:
-        gpu.tune(quot_rows=1)
-
-
-def _both_interpreters(be, orc, pyref, seed, shape, **kw):
-    """the same program on the 32-bit interpreter (the default) and on the 29-bit-limb one (tune quot_limb29 = 1: statically bounded values, no modular corrections;
-    measured slower on the GPU, kept selectable): both equal the oracle; the launch counter shows which one ran"""
-    prog = qc.build_program(orc, pyref, seed=seed, **shape, **kw)
-    be.timing(True)
-    qc.run_case(be, orc, pyref, pc, prog, seed=seed)
-    assert not be.stat_get("quotient29_launches")
-    be.timing(False)
-    be.tune(quot_limb29=1)
-    try:
-        be.timing(True)
-        qc.run_case(be, orc, pyref, pc, prog, seed=seed)
-        ran29 = be.stat_get("quotient29_launches")
-        be.timing(False)
-        assert ran29 and ran29 > 0, "the 29-bit interpreter did not run (bound analysis refused the program?)"
-    finally:
-        be.tune(quot_limb29=0)
-
-
-@pytest.mark.parametrize("seed,shape", [SHAPES[0], SHAPES[3]])
-def test_emulated_quotient_on_both_interpreters(emu, orc, pyref, seed, shape):
-    _both_interpreters(emu, orc, pyref, seed, shape)
-
-
-def test_emulated_quotient_dense_program_on_both_interpreters(emu, orc, pyref):
-    _both_interpreters(emu, orc, pyref, 5, dict(k=4, cs_degree=5, n_fixed=4, n_advice=6, n_instance=1, n_challenges=1, n_perm=7, n_lookups=3), gate_ops=60)
-
-
-@pytest.mark.gpu
-def test_gpu_quotient_on_both_interpreters(gpu, orc, pyref):
-    _both_interpreters(gpu, orc, pyref, 5, dict(k=10, cs_degree=5, n_fixed=4, n_advice=6, n_instance=1, n_challenges=1, n_perm=7, n_lookups=3), gate_ops=60)
-    _both_interpreters(gpu, orc, pyref, 4, SHAPES[3][1])
+def test_gpu_quotient_dense_program(gpu, orc, pyref):
+    qc.run_case(gpu, orc, pyref, pc, qc.build_program(orc, pyref, seed=5, gate_ops=60, **dict(DENSE, k=10)), seed=5)
+    qc.run_case(gpu, orc, pyref, pc, qc.build_program(orc, pyref, seed=4, **SHAPES[3][1]), seed=4)

@@ -17,7 +17,17 @@ def _check(be, k, seed, twin=True):
     cs, fixed, asm, advice, instances = rc.random_circuit(k, seed)
     want = rc.oracle_proof(k, tcp.TAU, cs, fixed, asm, advice, instances, seed)
     params = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
-    pk = plonk.keygen(params, cs, fixed, asm, piece_cosets=False)   # these witnesses do NOT satisfy their gates: h(X) is not a polynomial, and only the extended route is halo2's on such input (tests/test_piece_cosets.py)
+    # these witnesses do NOT satisfy their gates: h(X) is not a polynomial, and only the extended route with every identity on every row is halo2's on such input
+    # (tests/test_piece_cosets.py; the degree split of the quotient program, include/zkmi355.h)
+    be.tune(quot_degree_split=0)
+    try:
+        return _check_unsplit(be, k, seed, twin, cs, fixed, asm, advice, instances, want, params)
+    finally:
+        be.tune(quot_degree_split=1)
+
+
+def _check_unsplit(be, k, seed, twin, cs, fixed, asm, advice, instances, want, params):
+    pk = plonk.keygen(params, cs, fixed, asm, piece_cosets=False)
     shape = dict(seed=seed, degree=cs.degree(), e=pk.domain.extended_k - k, advice=cs.num_advice_columns, fixed=cs.num_fixed_columns, instance=cs.num_instance_columns,
                  lookups=len(cs.lookups), perm=len(cs.permutation_columns), gates=len(cs.gates), bf=cs.blinding_factors())
     got = plonk.NativeProver(params, pk).create_proof([a.copy() for a in advice], instances, np.random.default_rng(seed))

@@ -109,14 +109,14 @@ def test_format_round_trip_with_oracle_written_vectors(orc, pyref, tmp_path):
     assert read_zkv(tmp_path / "p.zkv") == {"kind": "proof", "proof": b"hello", "first_draws": list(range(8))}
 
 
-def expected_squeeze_record(census: dict, schedule: int):
-    """What the Rust driver's kind-5 record must read for a circuit with this census (vk_cs.json keys) if halo2 draws in `schedule`'s order: per squeeze
+def expected_squeeze_record(census: dict, blinds: bool = True):
+    """What the Rust driver's kind-5 record must read for a circuit with this census (vk_cs.json keys) if halo2 draws in draw_plan's order (blinds = False: the same plan without the Blind(Fr::random) of the commitments — the alternative a dump could point at): per squeeze
     (Fr::random draws so far, points written, scalars written) — theta, beta, gamma, y, x, then SHPLONK's y, v, u — and the total number of draws."""
     from zk_dcap_verifier_amd.plonk.prover import draw_plan
     A, L, P, d, bf, k = (census[key] for key in ("num_advice_columns", "lookups", "permutation_columns", "degree", "blinding_factors", "k"))
     chunk = d - 2
     n_sets = -(-P // chunk) if P else 0
-    plan = draw_plan(A, L, n_sets, d - 1, 1 << k, bf, schedule)
+    plan = [it for it in draw_plan(A, L, n_sets, d - 1, 1 << k, bf) if blinds or it[0] != "blind"]
     upto = lambda names: sum(c for _, _, c, sq in plan if sq in names)
     n_evals = census["advice_queries"] + census["fixed_queries"] + 1 + P + (3 * n_sets - 1 if n_sets else 0) + 5 * L
     pts = [A, A + 2 * L, A + 2 * L, A + 2 * L + n_sets + L + 1, A + 2 * L + n_sets + L + 1 + (d - 1)]
@@ -128,10 +128,10 @@ def expected_squeeze_record(census: dict, schedule: int):
 
 
 def test_draw_record_round_trip_and_expected_counts(tmp_path):
-    """the kind-5 loader on a record written here from draw_plan — and the two schedules must be told apart by it (else the Rust dump could not settle anything)"""
+    """the kind-5 loader on a record written here from draw_plan — and the plan with and without the Blind draws must be told apart by it (else the Rust dump could not settle anything)"""
     census = {"k": 8, "num_advice_columns": 25, "lookups": 11, "permutation_columns": 16, "degree": 5, "blinding_factors": 5, "advice_queries": 60, "fixed_queries": 30}
-    rows1, total1 = expected_squeeze_record(census, 1)
-    rows0, total0 = expected_squeeze_record(census, 0)
+    rows1, total1 = expected_squeeze_record(census)
+    rows0, total0 = expected_squeeze_record(census, blinds=False)
     assert total1 - total0 == 25 + 2 * 11 + 6 + 11 + 1 + 4 and rows1[0][0] == 25 * 6 + 25 and rows0[0][0] == 25 * 6        # one Blind per commitment of phases 2-7
     assert [r[0] for r in rows1] != [r[0] for r in rows0]
     flat = [v * 8 if i % 3 == 0 else v for r in rows1 for i, v in enumerate(r)]
@@ -143,15 +143,15 @@ def test_draw_record_round_trip_and_expected_counts(tmp_path):
 
 @pytest.mark.skipif(not (_vectors(5) and os.path.exists(os.path.join(DIR, "vk_cs.json"))), reason="no Rust draw-count record under tests/golden/rust")
 def test_draw_schedule_equals_rust_create_proof():
-    """THE check of DESIGN.md 1's top open parity risk: halo2's create_proof, run under a counting rng, must have consumed exactly draw_plan(schedule 1)'s
-    draws before each squeeze; the message says which schedule (if any) the record matches."""
+    """THE check of DESIGN.md 1's top open parity risk: halo2's create_proof, run under a counting rng, must have consumed exactly draw_plan's
+    draws before each squeeze; the message says when the record matches the plan WITHOUT the Blind draws instead."""
     census = json.load(open(os.path.join(DIR, "vk_cs.json")))
     for p in _vectors(5):
         v = read_zkv(p)
         got = [[r[0] / v["per_fr"], r[1], r[2]] for r in v["at_squeeze"]]
-        want1, total1 = expected_squeeze_record(census, 1)
-        want0, _ = expected_squeeze_record(census, 0)
-        assert got == want1 and v["total"] == total1 * v["per_fr"], (p, "matches schedule 0" if got == want0 else "matches neither schedule", got, want1)
+        want1, total1 = expected_squeeze_record(census)
+        want0, _ = expected_squeeze_record(census, blinds=False)
+        assert got == want1 and v["total"] == total1 * v["per_fr"], (p, "matches the plan without Blind draws" if got == want0 else "matches neither plan", got, want1)
 
 
 def replay_events(v):

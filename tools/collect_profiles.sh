@@ -12,6 +12,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o s -- python
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $O/lds -o l -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
+# FETCH_SIZE on this repo's own access patterns with KNOWN byte counts (MI355X_MICROARCH.md: other widths than wide streaming reads are uncalibrated): a 64-byte gather per lane
+# (msm_accumulate's table reads) and a 32-byte-per-lane stream (NTT passes, quotient columns)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cal_gather -o c -- ./tools/microbench --gather64 > $O/${TAG}_fetch_size_calibration.txt 2>> $O/bench.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cal_stream -o c -- ./tools/microbench --stream32 >> $O/${TAG}_fetch_size_calibration.txt 2>> $O/bench.err
 # VALU side of the integer roofline: issue / stall split + the chip's effective clock (GRBM_GUI_ACTIVE / 8 / duration), then the instruction mix
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/valu -o v -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/mix -o m -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err

@@ -34,7 +34,7 @@ def _pad8(b: bytes) -> bytes:
     return b + bytes(-len(b) % 8)
 
 
-def build_blob(be, cs, fixed, asm, advice, instances, k, tau, seed, draw_schedule=1, expected=None) -> bytes:
+def build_blob(be, cs, fixed, asm, advice, instances, k, tau, seed, expected=None) -> bytes:
     import zk_dcap_verifier_amd as z
     from zk_dcap_verifier_amd import plonk
     from zk_dcap_verifier_amd.fields import rand_fr_array
@@ -50,7 +50,7 @@ def build_blob(be, cs, fixed, asm, advice, instances, k, tau, seed, draw_schedul
     u32 = lambda vals: np.asarray(vals, dtype=np.int64).astype(np.uint32).tobytes()
     out = [b"ZKPK", struct.pack("<I", 1),
            struct.pack("<12I", k, cs.degree(), cs.blinding_factors(), cs.num_fixed_columns, cs.num_advice_columns, cs.num_instance_columns, len(cs.lookups),
-                       len(cs.permutation_columns), len(aq), len(fq), 0, draw_schedule),
+                       len(cs.permutation_columns), len(aq), len(fq), 0, 1),
            _pad8(u32([v for t, i in cs.permutation_columns for v in (t, i)]) + u32([v for c, r in aq for v in (c, r)]) + u32([v for c, r in fq for v in (c, r)]) + u32(key_ids)),
            int(pk.vk.transcript_repr).to_bytes(32, "little")]
     blob = pk.program.to_blob()
@@ -68,12 +68,12 @@ def build_blob(be, cs, fixed, asm, advice, instances, k, tau, seed, draw_schedul
     chunk = cs.permutation_chunk_len()
     n_sets = -(-len(cs.permutation_columns) // chunk) if cs.permutation_columns else 0
     rng = np.random.default_rng(seed)
-    draws = [rand_fr_array(rng, cnt) for _, _, cnt, _ in draw_plan(cs.num_advice_columns, len(cs.lookups), n_sets, cs.degree() - 1, n, cs.blinding_factors(), draw_schedule)]
+    draws = [rand_fr_array(rng, cnt) for _, _, cnt, _ in draw_plan(cs.num_advice_columns, len(cs.lookups), n_sets, cs.degree() - 1, n, cs.blinding_factors())]
     stream = np.concatenate(draws) if draws else np.zeros((0, 4), np.uint64)
     out += [struct.pack("<Q", stream.shape[0]), stream.tobytes()]
     if expected is None:                                             # no golden for this circuit: the Python twin's bytes (same kernels) are the reference
         tr = Blake2bWrite()
-        plonk.create_proof(params, pk, [a.copy() for a in host_advice], instances, np.random.default_rng(seed), tr, draw_schedule=draw_schedule)
+        plonk.create_proof(params, pk, [a.copy() for a in host_advice], instances, np.random.default_rng(seed), tr)
         expected = tr.finalize()
     out += [struct.pack("<Q", len(expected)), _pad8(expected)]
     pk.release()
@@ -81,33 +81,33 @@ def build_blob(be, cs, fixed, asm, advice, instances, k, tau, seed, draw_schedul
     return b"".join(out)
 
 
-def toy_blob(be, k=6, seed=7, draw_schedule=1) -> bytes:
+def toy_blob(be, k=6, seed=7) -> bytes:
     import test_create_proof as t
     cs, fixed, asm, advice, instances = t.toy_circuit(k)
     golden = None
     if (k, seed) == (6, 7):
-        golden = t._golden(t.GOLDEN_PROOF if draw_schedule == 1 else t.sched0(t.GOLDEN_PROOF))
-    return build_blob(be, cs, fixed, asm, advice, instances, k, t.TAU, seed, draw_schedule, golden)
+        golden = t._golden(t.GOLDEN_PROOF)
+    return build_blob(be, cs, fixed, asm, advice, instances, k, t.TAU, seed, golden)
 
 
-def sgx_blob(be, k=8, seed=3, census="chip_estimate", draw_schedule=1) -> bytes:
+def sgx_blob(be, k=8, seed=3, census="chip_estimate") -> bytes:
     import sgx_shaped_circuit as sc
     import test_create_proof as t
     import zk_dcap_verifier_amd as z
     cs, fixed, asm, advice = sc.build(z, be, k, census=census)
     golden = None
-    if (k, seed, census, draw_schedule) == (8, 3, "chip_estimate", 1):
+    if (k, seed, census) == (8, 3, "chip_estimate"):
         golden = t._golden(t.GOLDEN_SGX)
     adv = [a.download((1 << k, 4)) if not isinstance(a, np.ndarray) else a for a in advice]
-    return build_blob(be, cs, fixed, asm, adv, [], k, t.TAU, seed, draw_schedule, golden)
+    return build_blob(be, cs, fixed, asm, adv, [], k, t.TAU, seed, golden)
 
 
-def p256_blob(be, k=7, seed=18, draw_schedule=1) -> bytes:
+def p256_blob(be, k=7, seed=18) -> bytes:
     """the census of the reference's stack-B circuit (degree 4: three h pieces, so zk_plonk_pk_build keeps three cosets of the key's columns and no extended form)"""
     import p256_shaped_circuit as p256
     import test_create_proof as t
     cs, fixed, asm, advice, instances = p256.build(k)
-    return build_blob(be, cs, fixed, asm, advice, instances, k, t.TAU, seed, draw_schedule, None)
+    return build_blob(be, cs, fixed, asm, advice, instances, k, t.TAU, seed, None)
 
 
 def main():

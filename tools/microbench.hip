@@ -313,7 +313,52 @@ static double run(const char* name, K kern, double ops_per_thread, int block, in
     return rate;
 }
 
+// ---- FETCH_SIZE calibration on this repo's own access patterns (MI355X_MICROARCH.md, HBM: "other access widths are uncalibrated: calibrate on a known byte count in your own
+// access pattern").  `microbench --gather64` / `--stream32` run ONE kernel each with a known byte count, to be read next to `rocprofv3 --pmc FETCH_SIZE`:
+//   gather64: every lane reads ONE 64-byte table point (4 x 16 B, as msm_accumulate_kernel gathers its affine points) at a pseudo-random index of a 512 MiB table;
+//   stream32: every lane reads 32 consecutive bytes of a 1 GiB stream (2 x 16 B per lane: how the NTT passes and the quotient read their columns).
+__global__ void k_gather64(const uint4* table, uint32_t mask, uint32_t per_lane, uint32_t* out) {
+    uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u, acc = 0;
+    for (uint32_t i = 0; i < per_lane; i++) {
+        x = x * 1664525u + 1013904223u;
+        const uint4* p = table + (size_t)((x >> 4) & mask) * 4;
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        acc ^= a.x ^ b.y ^ c.z ^ d.w;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+__global__ void k_stream32(const uint4* src, size_t n32, uint32_t* out) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 a = src[2 * i], b = src[2 * i + 1];
+        acc ^= a.x ^ b.w;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+static int calibrate(const char* which) {
+    const int block = 256, grid = 256 * 8;
+    uint32_t* out; CK(hipMalloc(&out, (size_t)grid * block * 4));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    if (!strcmp(which, "--gather64")) {
+        const size_t points = (size_t)1 << 23;                                       // 2^23 x 64 B = 512 MiB: the window-expanded table of one SRS at k = 19
+        uint4* t; CK(hipMalloc(&t, points * 64)); CK(hipMemset(t, 1, points * 64));
+        const uint32_t per_lane = 64;
+        CK(hipEventRecord(a)); hipLaunchKernelGGL(k_gather64, dim3(grid), dim3(block), 0, 0, (const uint4*)t, (uint32_t)(points - 1), per_lane, out); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        const double bytes = (double)grid * block * per_lane * 64;
+        printf("k_gather64: %.0f gathers of 64 B = %.0f bytes requested (random over a 512 MiB table: at most 512 MiB of them can be first touches), %.3f ms, %.1f GB/s\n", bytes / 64, bytes, ms, bytes / ms / 1e6);
+    } else {
+        const size_t bytes = (size_t)1 << 30;
+        uint4* sbuf; CK(hipMalloc(&sbuf, bytes)); CK(hipMemset(sbuf, 1, bytes));
+        CK(hipEventRecord(a)); hipLaunchKernelGGL(k_stream32, dim3(grid), dim3(block), 0, 0, (const uint4*)sbuf, bytes / 32, out); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        printf("k_stream32: %zu bytes read once (32 B per lane, consecutive), %.3f ms, %.1f GB/s\n", bytes, ms, (double)bytes / ms / 1e6);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && (!strcmp(argv[1], "--gather64") || !strcmp(argv[1], "--stream32"))) return calibrate(argv[1]);
     {
         const int st = mont29_selftest();
         printf("mont29 host self-test (9 x 29-bit limbs vs Fq::mul): %s\n", st ? "FAILED" : "ok");

@@ -139,22 +139,26 @@ def main():
     fe, wr = agg(f"{O}/fetch/f_counter_collection.csv", "FETCH_SIZE"), agg(f"{O}/write/w_counter_collection.csv", "WRITE_SIZE")
     keep = ["msm_accumulate_kernel", "quotient_kernel", "ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "ntt_final_pass29_kernel", "msm_hist_kernel", "msm_scatter_kernel", "lpb_scatter_kernel",
             "lpb_hist_kernel", "msm_merge_kernel", "msm_rowcol_kernel", "pe_eval_partial_kernel", "pe_lincomb_kernel", "gp_batch_divide_kernel"]
-    traffic = {}
+    traffic, raw = {}, {}
     with open(f"{P}/{tag}_rocprofv3_pmc_hbm_traffic.csv", "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras  (one real proof + setup/keygen)\n")
-        f.write("# bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024: the gfx950 correction of MI355X_MICROARCH.md (HBM section); launches include keygen launches of the same kernel\n")
-        f.write("kernel,launches,FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,hbm_bytes_per_launch\n")
+        f.write("# two readings per kernel: raw = (FETCH_SIZE + WRITE_SIZE) KB * 1024 as counted; doubled = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024, the gfx950 correction of MI355X_MICROARCH.md (HBM section),\n")
+        f.write("# which is calibrated for wide coalesced streaming reads (the NTT passes, the quotient's column reads) and NOT for 64-byte gathers (msm_accumulate: tools/microbench gather64 under the same counter);\n")
+        f.write("# launches include keygen launches of the same kernel\n")
+        f.write("kernel,launches,FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum,raw_bytes_per_launch,doubled_fetch_bytes_per_launch\n")
         for k in keep:
             if k in fe:
                 n = fe[k][0]
                 by = (2 * fe[k][1] + wr.get(k, [0, 0])[1]) * 1024 / n
                 traffic[k] = by
-                f.write(f"{k},{n},{fe[k][1]:.1f},{wr.get(k, [0, 0])[1]:.1f},{by:.0f}\n")
+                raw[k] = {"launches": n, "fetch_bytes_per_launch": round(fe[k][1] * 1024 / n), "write_bytes_per_launch": round(wr.get(k, [0, 0])[1] * 1024 / n)}
+                f.write(f"{k},{n},{fe[k][1]:.1f},{wr.get(k, [0, 0])[1]:.1f},{(fe[k][1] + wr.get(k, [0, 0])[1]) * 1024 / n:.0f},{by:.0f}\n")
     tj = {"source": f"profiles/{rnd}/{tag}_rocprofv3_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 --inflight 1 --no-extras; "
                     "bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 per the gfx950 correction of MI355X_MICROARCH.md HBM section)",
           "msm_accumulate_bytes_per_launch": round(traffic["msm_accumulate_kernel"]), "quotient_bytes_per_launch": round(traffic["quotient_kernel"]),
           "ntt_strided_pass_bytes_per_launch": round(traffic.get("ntt_strided_pass29_kernel") or traffic["ntt_strided_pass_kernel"]),      # (the 29-bit-limb kernel when the plan uses it)
-          "ntt_final_pass_bytes_per_launch": round(traffic.get("ntt_final_pass_kernel") or traffic["ntt_final_pass29_kernel"])}
+          "ntt_final_pass_bytes_per_launch": round(traffic.get("ntt_final_pass_kernel") or traffic["ntt_final_pass29_kernel"]),
+          "kernels": raw}                                              # FETCH_SIZE / WRITE_SIZE as counted, per launch: bench.py reports raw and doubled readings side by side
     json.dump(tj, open(os.path.join(os.path.dirname(P), "traffic.json"), "w"), indent=1)
     d = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
@@ -176,8 +180,35 @@ def main():
                 f.write(f"{k},{cnt[k]},{v['SQ_INSTS_LDS']:.0f},{v['SQ_LDS_IDX_ACTIVE']:.0f},{v['SQ_LDS_BANK_CONFLICT']:.0f},{v['SQ_LDS_BANK_CONFLICT'] / act:.4f},"
                         f"{v['SQ_LDS_IDX_ACTIVE'] / (v['SQ_WAVE_CYCLES'] or 1):.4f}\n")
     valu_section(O, P, tag, rnd)
+    calibration_section(O, P, tag)
     for name in (f"{tag}_bench_default.json", f"{tag}_bench_under_rocprofv3.json"):
         open(f"{P}/{name}", "w").write(json.dumps(last_json_line(f"{O}/{name}")) + "\n")
+
+
+def calibration_section(O, P, tag):
+    """FETCH_SIZE of tools/microbench --gather64 / --stream32 (known byte counts) next to what the kernels requested: settles which reading of the counter applies to
+    64-byte gathers (msm_accumulate) and to 32-byte-per-lane streams (NTT passes, quotient): profiles/<round>/<tag>_fetch_size_calibration.txt"""
+    src = f"{O}/{tag}_fetch_size_calibration.txt"
+    if not os.path.exists(src):
+        return
+    lines = [l.rstrip("\n") for l in open(src) if l.startswith("k_")]
+    counted = {}
+    for d, kern in (("cal_gather", "k_gather64"), ("cal_stream", "k_stream32")):
+        for root, _, files in os.walk(f"{O}/{d}"):
+            for fn in files:
+                if fn.endswith("counter_collection.csv"):
+                    for r in csv.DictReader(open(os.path.join(root, fn))):
+                        if r["Counter_Name"] == "FETCH_SIZE" and kern in r["Kernel_Name"]:
+                            counted[kern] = counted.get(kern, 0.0) + float(r["Counter_Value"]) * 1024
+    with open(f"{P}/{tag}_fetch_size_calibration.txt", "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE --output-format csv -- ./tools/microbench --gather64 | --stream32   (one kernel each, known byte count)\n")
+        for l in lines:
+            f.write(l + "\n")
+            kern = l.split(":")[0]
+            req = float(l.split(" bytes")[0].split()[-1]) if kern == "k_stream32" else float(l.split("= ")[1].split(" bytes")[0])
+            if kern in counted:
+                f.write(f"    FETCH_SIZE as counted: {counted[kern]:.0f} bytes = {counted[kern] / req:.3f} of the bytes requested  (x2: {2 * counted[kern] / req:.3f})\n")
+    print(open(f"{P}/{tag}_fetch_size_calibration.txt").read())
 
 
 if __name__ == "__main__":

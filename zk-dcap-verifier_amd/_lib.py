@@ -485,17 +485,26 @@ class Backend:
         self._ck(self.lib.zk_quotient_program_info(self.ctx, C.c_uint64(prog), C.byref(a), C.byref(b), C.byref(c)))
         return {"instructions": a.value, "slots": b.value, "columns": c.value}
 
-    def quotient_program_opmix(self, prog: int) -> dict:
+    def quotient_program_opmix(self, prog: int, part: int = 0) -> dict:
+        """opcode census of the compiled program; part 1 / 2 = its high / low part when it has a degree split (quotient_program_split)"""
         c = (C.c_uint32 * 9)()
-        self._ck(self.lib.zk_quotient_program_opmix(self.ctx, C.c_uint64(prog), c))
+        self._ck(self.lib.zk_quotient_program_part_opmix(self.ctx, C.c_uint64(prog), C.c_uint32(part), c) if part else self.lib.zk_quotient_program_opmix(self.ctx, C.c_uint64(prog), c))
         return dict(zip(("add", "sub", "mul", "sqr", "dbl", "neg", "mov", "muladd", "memory_operands"), [int(x) for x in c]))
+
+    def quotient_program_split(self, prog: int) -> dict:
+        """the degree split of a compiled program: cosets the low part runs on (0 = no split) and the instruction counts of the two parts"""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self.lib.zk_quotient_program_split(self.ctx, C.c_uint64(prog), C.byref(a), C.byref(b), C.byref(c)))
+        return {"low_cosets": a.value, "instructions_high": b.value, "instructions_low": c.value}
 
     def quotient_program_release(self, prog: int):
         self._ck(self.lib.zk_quotient_program_release(self.ctx, C.c_uint64(prog)))
 
     def quotient_run_dev(self, prog: int, *, fixed, advice, instance, l0, l_last, l_active_row, perm_cosets, perm_products,
                          lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out, coset: int | None = None,
-                         rows: tuple | None = None):
+                         rows: tuple | None = None, part: int = 0, low_cosets: int = 0):
+        """part 1 / 2: the high / low part of a program with a degree split (zk_quotient_run_high_dev / _low_dev / _coset_part_dev); low_cosets: the low part on the rows of
+        that many cosets of extended-layout columns, `out` coset-major"""
         keep = []
 
         def parr(cols):
@@ -509,7 +518,15 @@ class Backend:
                          parr(perm_cosets), parr(perm_products), len(perm_products),
                          parr(lookup_product), parr(lookup_input), parr(lookup_table),
                          ch.ctypes.data, sc[0].ctypes.data, sc[1].ctypes.data, sc[2].ctypes.data, sc[3].ctypes.data, _dptr(out))
-        if coset is None:
+        if part:
+            assert rows is None
+            if coset is not None:
+                self._ck(self.lib.zk_quotient_run_coset_part_dev(self.ctx, C.c_uint64(prog), C.byref(a), C.c_uint32(coset), C.c_uint32(part)))
+            elif part == 1:
+                self._ck(self.lib.zk_quotient_run_high_dev(self.ctx, C.c_uint64(prog), C.byref(a)))
+            else:
+                self._ck(self.lib.zk_quotient_run_low_dev(self.ctx, C.c_uint64(prog), C.byref(a), C.c_uint32(low_cosets)))
+        elif coset is None:
             self._ck(self.lib.zk_quotient_run_dev(self.ctx, C.c_uint64(prog), C.byref(a)))
         elif rows is None:
             self._ck(self.lib.zk_quotient_run_coset_dev(self.ctx, C.c_uint64(prog), C.byref(a), C.c_uint32(coset)))

@@ -43,8 +43,9 @@ int g1_ntt(zk_ctx* ctx, const void* d_affine_in, uint32_t log_n, const void* ome
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
-int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]);
-int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, int coset, uint64_t row_lo, uint64_t row_count);
+int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t part, uint32_t counts[9]);
+int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, int coset, uint64_t row_lo, uint64_t row_count, int part, uint32_t low_cosets);
+int quotient_program_split(zk_ctx* ctx, uint64_t prog, uint32_t* low_cosets, uint32_t* n_instr_high, uint32_t* n_instr_low);
 int domain_coeff_to_coset_batch(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek, uint32_t coset);
 int fr_interleave(zk_ctx* ctx, const void* const* h_cosets, size_t count, size_t n, void* d_out);
 int domain_cosets_to_pieces(zk_ctx* ctx, void* const* h_numer, uint32_t q, uint32_t k, uint32_t ek, void* const* h_pieces);
@@ -125,11 +126,8 @@ static int* tune_slot(zk_ctx* ctx, const char* key) {
         {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block}, {"msm_limb29", &t.msm_limb29}, {"msm_acc_waves", &t.msm_acc_waves}, {"msm_runs", &t.msm_runs},
         {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log},
         {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}, {"lookup_force_generic_sort", &t.lookup_force_generic_sort},
-        {"ntt_quarter_input", &t.ntt_quarter_input}, {"ntt_limb29", &t.ntt_limb29}, {"ntt_waves", &t.ntt_waves}, {"quot_piece_cosets", &t.quot_piece_cosets}, {"quot_factor_horner", &t.quot_factor_horner}, {"ntt_ws_limit_mb", &t.ntt_ws_limit_mb}, 
-#ifdef ZK_NTT_PROBE
-        {"ntt_debug_mode", &t.ntt_debug_mode},
-#endif
-        {"quot_rows", &t.quot_rows}, {"quot_limb29", &t.quot_limb29}, {"quot_remat_ops", &t.quot_remat_ops}, {"quot_remat_distance", &t.quot_remat_distance}};
+        {"ntt_quarter_input", &t.ntt_quarter_input}, {"quot_piece_cosets", &t.quot_piece_cosets}, {"quot_factor_horner", &t.quot_factor_horner}, {"quot_degree_split", &t.quot_degree_split}, {"ntt_ws_limit_mb", &t.ntt_ws_limit_mb}, 
+        {"quot_remat_ops", &t.quot_remat_ops}, {"quot_remat_distance", &t.quot_remat_distance}};
     for (auto& e : tab) if (!strcmp(e.k, key)) return e.v;
     return nullptr;
 }
@@ -148,10 +146,16 @@ int zk_tune_get(zk_ctx* ctx, const char* key, int* value) {
     *value = *s;
     return ZK_OK;
 }
-int zk_timing_enable(zk_ctx* ctx, int on) { NEED_CTX; LOCK; ctx->timing = on != 0; ctx->last_ms.clear(); return ZK_OK; }
+int zk_timing_enable(zk_ctx* ctx, int on) {
+    NEED_CTX; LOCK;
+    if (on) { resolve_pending_timers(ctx); ctx->last_ms.clear(); }   // (switching the timing OFF keeps what was measured: zk_timing_get reads it afterwards)
+    ctx->timing = on != 0;
+    return ZK_OK;
+}
 double zk_timing_get(zk_ctx* ctx, const char* label) {
     if (!ctx || !label) return -1.0;
     LOCK;
+    resolve_pending_timers(ctx);
     auto it = ctx->last_ms.find(label);
     return it == ctx->last_ms.end() ? -1.0 : it->second;
 }
@@ -359,7 +363,8 @@ int zk_fr_lincomb_dev(zk_ctx* ctx, const void* const* polys_dev, const void* sca
 // ---- quotient -----------------------------------------------------------------------------------
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog) { ENTER; return quotient_program_load(ctx, blob, len, prog); }
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* ni, uint32_t* ns, uint32_t* nc) { ENTER; return quotient_program_info(ctx, prog, ni, ns, nc); }
-int zk_quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]) { ENTER; return quotient_program_opmix(ctx, prog, counts); }
+int zk_quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]) { ENTER; return quotient_program_opmix(ctx, prog, 0, counts); }
+int zk_quotient_program_part_opmix(zk_ctx* ctx, uint64_t prog, uint32_t part, uint32_t counts[9]) { ENTER; return quotient_program_opmix(ctx, prog, part, counts); }
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog) { ENTER; return quotient_program_release(ctx, prog); }
 int zk_quotient_program_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_prog, uint64_t* prog) {
     if (!ctx || !owner || !prog) return ZK_ERR_ARG;
@@ -368,19 +373,31 @@ int zk_quotient_program_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_prog, u
 // ABI versioning (zkmi355.h): the caller's sizeof of a boundary struct must be this build's before any other field is read
 #define ARGS_SIZE(fn) do { if (!args) return ctx->fail(ZK_ERR_ARG, fn ": null args"); \
         if (args->struct_size != sizeof(zk_quotient_args)) return ctx->fail(ZK_ERR_ARG, fn ": zk_quotient_args.struct_size %u, expected %zu (ABI version %u)", args->struct_size, sizeof(zk_quotient_args), ZK_ABI_VERSION); } while (0)
-int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; ARGS_SIZE("zk_quotient_run_dev"); return quotient_run(ctx, prog, args, -1, 0, 0); }
+int zk_quotient_run_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; ARGS_SIZE("zk_quotient_run_dev"); return quotient_run(ctx, prog, args, -1, 0, 0, 0, 0); }
 int zk_quotient_run_coset_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset) {
     ENTER;
     ARGS_SIZE("zk_quotient_run_coset_dev");
     if (coset >= (1u << 16)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_dev: coset %u out of range", coset);
-    return quotient_run(ctx, prog, args, (int)coset, 0, 0);
+    return quotient_run(ctx, prog, args, (int)coset, 0, 0, 0, 0);
 }
 int zk_quotient_run_coset_rows_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset, uint64_t row_lo, uint64_t row_count) {
     ENTER;
     ARGS_SIZE("zk_quotient_run_coset_rows_dev");
     if (coset >= (1u << 16)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_rows_dev: coset %u out of range", coset);
     if (!row_count) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_rows_dev: row_count = 0");
-    return quotient_run(ctx, prog, args, (int)coset, row_lo, row_count);
+    return quotient_run(ctx, prog, args, (int)coset, row_lo, row_count, 0, 0);
+}
+int zk_quotient_program_split(zk_ctx* ctx, uint64_t prog, uint32_t* low_cosets, uint32_t* n_instr_high, uint32_t* n_instr_low) { ENTER; return quotient_program_split(ctx, prog, low_cosets, n_instr_high, n_instr_low); }
+int zk_quotient_run_high_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args) { ENTER; ARGS_SIZE("zk_quotient_run_high_dev"); return quotient_run(ctx, prog, args, -1, 0, 0, 1, 0); }
+int zk_quotient_run_low_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t low_cosets) {
+    ENTER; ARGS_SIZE("zk_quotient_run_low_dev");
+    if (!low_cosets) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_low_dev: low_cosets = 0");
+    return quotient_run(ctx, prog, args, -1, 0, 0, 2, low_cosets);
+}
+int zk_quotient_run_coset_part_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, uint32_t coset, uint32_t part) {
+    ENTER; ARGS_SIZE("zk_quotient_run_coset_part_dev");
+    if (coset >= (1u << 16) || part < 1 || part > 2) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_part_dev: coset %u / part %u out of range", coset, part);
+    return quotient_run(ctx, prog, args, (int)coset, 0, 0, (int)part, 0);
 }
 
 int zk_pk_load(zk_ctx* ctx, uint64_t prog, const void* const* fixed, const void* const* sigma, const void* l0, const void* l_last, const void* l_active,

@@ -35,18 +35,13 @@ struct Tune {
     int ntt_max_radix_log = 8;
     int ntt_full_twiddle_max_log = 24;   // up to this size inter-pass twiddles come from full HBM tables (32 B/element/pass)
     int ntt_ws_limit_mb = 24576; // a batched transform's out-of-place workspace (columns x N x 32 B) is capped here: larger batches run in slices of columns (k >= 22)
-    int ntt_limb29 = 1;          // NTT passes on carry-free 29-bit limbs (field29.cuh): 1 = the strided passes (-5 % there; the final pass measured +3 % and stays 32-bit), 2 = every pass, 0 = none
-    int ntt_waves = 4;           // waves per SIMD the 29-bit passes are compiled for (2: 256 VGPRs, 3: 168, 4: 128 with spills)
     int ntt_quarter_input = 1;   // coeff_to_extended: skip the arithmetic of the first two stages when 3/4 of the input is the zero padding
-#ifdef ZK_NTT_PROBE
-    int ntt_debug_mode = 0;      // `make probe` only (tools/ntt_probe.py; WRONG results): 1 = passes without their butterfly stages, 2 = without global loads / stores
-#endif
     int vec_block = 256;
     int quot_threads = 128;
     int quot_piece_cosets = 1;   // zk_plonk_pk_build on one GPU: keep cosets 0 .. cs_degree-2 of the key's columns instead of their extended forms when cs_degree - 1 < 2^(extended_k - k) (zk_cosets_to_pieces_dev)
-    int quot_limb29 = 0;         // 1: quotient interpreter on carry-free 29-bit limbs (quotient29_kernel) — measured SLOWER than the 32-bit interpreter (9.9 vs 9.4 ms per proof, profiles/r03 run99): kept selectable, off
+    int quot_degree_split = 1;   // quotient compiler + zk_plonk_create_proof: identities of degree <= 3 are evaluated on two cosets of the extended domain only and join h(X) through
+                                 // zk_cosets_to_pieces_dev; 0 = every identity on every row, halo2's bytes also for a witness that violates its circuit
     int quot_factor_horner = 1;  // quotient compiler: q * Horner([a_j], theta) for a theta-compression whose parts all carry the factor q (selector-switched lookups): m - 1 products fewer per row
-    int quot_rows = 1;           // rows per thread of the quotient interpreter (2: one micro-op decode serves two rows)
     int quot_remat_ops = 4;      // quotient compiler: a shared sub-expression of at most this many operations ...
     int quot_remat_distance = 24;   // ... is recomputed when its previous copy lies further back than this many micro-ops
     int lookup_force_generic_sort = 0;   // tests: take the every-digit sort of permute_expression_pair even when the 64-bit window sort is exact
@@ -94,7 +89,6 @@ struct TwiddleSet {           // per (omega, log_n)
     void* d_full[3] = {nullptr, nullptr, nullptr};   // per non-final pass: inter-pass twiddles in store order
     uint32_t radix_log[3] = {0, 0, 0};
     int passes = 0;
-    int r261 = 0;             // a 29-bit-limb plan (tune ntt_limb29; 1 = strided passes, 2 = all): the tables of those passes hold w * 2^261 mod p instead of w * 2^256
 };
 
 struct QuotProgram;  // quotient.hip
@@ -117,6 +111,8 @@ struct zk_ctx {
     // last-call kernel timing (ms), filled when timing is enabled
     bool timing = false;
     std::map<std::string, double> last_ms;
+    struct PendingTimer { const char* label; hipEvent_t a, b; };
+    std::vector<PendingTimer> pending_timers;   // event pairs of asynchronous entry points, read by zk_timing_get
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -151,7 +147,18 @@ struct EvTimer {
         ctx->last_ms[label] += ms; ctx->last_ms[std::string(label) + "#n"] += 1.0;
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     }
+    // for entry points that return without waiting for their kernels (the NTT passes): the event pair is read at the next zk_timing_get
+    void defer() { if (on) { ctx->pending_timers.push_back({label, a, b}); on = false; } }
 };
+inline void resolve_pending_timers(zk_ctx* ctx) {
+    for (auto& t : ctx->pending_timers) {
+        (void)hipEventSynchronize(t.b);
+        float ms = 0; (void)hipEventElapsedTime(&ms, t.a, t.b);
+        ctx->last_ms[t.label] += ms; ctx->last_ms[std::string(t.label) + "#n"] += 1.0;
+        (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
+    }
+    ctx->pending_timers.clear();
+}
 
 // implemented in the respective translation units
 int msm_register(zk_ctx* ctx, const void* pts, size_t n, bool on_device, uint64_t* handle);

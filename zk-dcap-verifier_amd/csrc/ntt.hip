@@ -59,14 +59,9 @@ ZK_HD u256 zeta_pow(uint32_t k) {  // ZETA^k, k in {1, 2}
     for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)((k == 1 ? z1[i >> 1] : z2[i >> 1]) >> (32 * (i & 1)));
     return o;
 }
-// PROBE is a measurement-only template parameter: the product library instantiates 0 alone; `make probe` (-DZK_NTT_PROBE, tools/ntt_probe.py) also builds 1 = a pass
-// without its butterfly stages (its memory time) and 2 = without global loads / stores (its arithmetic time) — both give WRONG results by construction.
-template <int PROBE>
 ZK_HD u256 ntt_load_input(const NttPassArgs& a, size_t idx) {
     if (a.n_valid && idx >= a.n_valid) return Fr::zero();
-    u256 v;
-    if (PROBE == 2) { for (int i = 0; i < 8; i++) v.v[i] = (uint32_t)idx * 0x9e3779b9u + i; v.v[7] &= 0x0fffffffu; }
-    else v = load_u256(a.src, idx);
+    u256 v = load_u256(a.src, idx);
     if (a.pre_zeta) {
         uint32_t m = (uint32_t)idx % 3u;
         if (m) v = Fr::mul(v, zeta_pow(m));
@@ -307,25 +302,13 @@ ZK_HD u261 ntt_load_input29(const NttPassArgs& a, size_t idx) {
     }
     return v;
 }
-// last store of a transform: the tile value (below 32 p) leaves canonical — through the product of a fused scaling, or the quotient-estimate reduction
-ZK_HD u256 ntt_post29(const NttPassArgs& a, u261 v, size_t out_idx) {
-    bool below2p = false;
-    if (a.post_scale) { v = Fr29::mul(v, Fr29::from32<0>(a.scale29)); below2p = true; }
-    if (a.post_zeta_inv) {
-        const uint32_t m = (uint32_t)out_idx % 3u;
-        if (m) { v = Fr29::mul(v, Fr29::from32<0>(m == 1 ? a.zeta29[1] : a.zeta29[0])); below2p = true; }   // ZETA^-m = ZETA^(3-m)
-    }
-    if (!below2p) v = Fr29::reduce_small(v);                          // below 3 p
-    return Fr::normalize(Fr29::to32(v));                              // [0, 4p) -> canonical
-}
 ZK_HD Tile29 tile29_at(uint4* base, uint32_t count) {                 // planes of `count` elements: 16 B | 16 B | 4 B
     Tile29 t;
     t.lo = base; t.hi = base + count; t.top = reinterpret_cast<uint32_t*>(base + 2 * count);
     return t;
 }
 
-template <int WPE>
-ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(WPE) ntt_strided_pass29_kernel(NttPassArgs a) {
+ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) ntt_strided_pass29_kernel(NttPassArgs a) {
     ZK_DYN_SHARED(uint4, smem);
     if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
     const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
@@ -365,80 +348,8 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(WPE) ntt_strided_pass29_ker
     }
 }
 
-template <int WPE>
-ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(WPE) ntt_final_pass29_kernel(NttPassArgs a) {
-    ZK_DYN_SHARED(uint4, smem);
-    if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
-    const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
-    const Tile29 t = tile29_at(smem, tile);
-    const uint32_t half = R >> 1 ? R >> 1 : 1;
-    const Tile29 tw = tile29_at(smem + (tile * 36 + 15) / 16, half);
-    for (uint32_t e = threadIdx.x; e < half; e += blockDim.x) lds_put29(tw, e, Fr29::from32<0>(load_u256(a.stage_tw, e)));
-    const uint32_t tb = blockIdx.x;
-    const uint32_t jm = tb & ((1u << a.p_log) - 1);
-    const uint32_t j10 = (tb >> a.p_log) << a.c_log;
-    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
-        const uint32_t row = e & (R - 1), col = e >> a.r;
-        const size_t o = ((size_t)(j10 + col) << a.p_log) + jm;
-        lds_put29(t, tile_at(bitrev(row, a.r), col, a.r, a.c_log), ntt_load_input29(a, (o << a.r) + row));
-    }
-    __syncthreads();
-    ntt_tile_stages29(t, a.r, a.c_log, tw, a.quarter_input != 0);
-    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
-        const uint32_t col = e & (C - 1), row = e >> a.c_log;
-        const size_t out_idx = (size_t)(j10 + col) + (((size_t)jm + ((size_t)row << a.p_log)) << a.q_log);
-        store_u256(a.dst, out_idx, ntt_post29(a, lds_get29(t, tile_at(row, col, a.r, a.c_log)), out_idx));
-    }
-}
-
-// non-final pass: rows are `cols` apart inside a sub-transform of size 2^blk_log; in/out share
-// the same addresses; the output row j of column m is multiplied by omega_blk^(m*j).
-template <int PROBE>
-ZK_KERNEL void ntt_strided_pass_kernel(NttPassArgs a) {
-    ZK_DYN_SHARED(uint4, smem);
-    if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
-    const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
-    uint4* lo = smem;
-    uint4* hi = smem + tile;
-    uint4* twl = smem + 2 * tile;                                   // R/2 stage twiddles, 2 x uint4 each
-    for (uint32_t e = threadIdx.x; e < R; e += blockDim.x) twl[e] = reinterpret_cast<const uint4*>(a.stage_tw)[e];
-    const uint32_t cols_log = a.blk_log - a.r;
-    const uint32_t tiles_per_blk_log = cols_log - a.c_log;
-    const uint32_t t = blockIdx.x;
-    const size_t o = t >> tiles_per_blk_log;
-    const uint32_t m0 = (t & ((1u << tiles_per_blk_log) - 1)) << a.c_log;
-    const size_t base = (o << a.blk_log) + m0;
-    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
-        const uint32_t col = e & (C - 1), row = e >> a.c_log;
-        const size_t idx = base + ((size_t)row << cols_log) + col;
-        lds_put(lo, hi, tile_at(bitrev(row, a.r), col, a.r, a.c_log), ntt_load_input<PROBE>(a, idx));
-    }
-    __syncthreads();
-    if (PROBE != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, twl, a.quarter_input != 0);
-    const uint32_t sh = a.log_n - a.blk_log;
-    const uint32_t lomask = (1u << a.lo_bits) - 1;
-    for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
-        const uint32_t col = e & (C - 1), row = e >> a.c_log;
-        u256 v = lds_get(lo, hi, tile_at(row, col, a.r, a.c_log));
-        const uint32_t ex = ((m0 + col) * row) << sh;  // < 2^log_n
-        if (ex) {
-            // (the tile holds values in [0, 4p); the product with a canonical twiddle is stored in [0, 2p), an untouched value as it is: the next pass takes [0, 4p))
-            if (a.tw_full) {   // one coalesced 32-byte read in exactly the order this pass stores
-                v = Fr::mul_lazy(v, load_u256(a.tw_full, ((size_t)row << cols_log) + m0 + col));
-            } else {
-                u256 tw = load_u256(a.tw_lo, ex & lomask);
-                const uint32_t h = ex >> a.lo_bits;
-                if (h) tw = Fr::mul(tw, load_u256(a.tw_hi, h));
-                v = Fr::mul_lazy(v, tw);
-            }
-        }
-        if (PROBE != 2 || v.v[3] == 0x12345u) store_u256(a.dst, base + ((size_t)row << cols_log) + col, v);
-    }
-}
-
 // final pass: the sub-transform is contiguous (size R); outer index o = j1 * P + jm; the result
 // row goes to out[j1 + Q * (jm + P * row)] — the digit reversal that restores natural order.
-template <int PROBE>
 ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
     ZK_DYN_SHARED(uint4, smem);
     if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
@@ -453,15 +364,14 @@ ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
         const uint32_t row = e & (R - 1), col = e >> a.r;
         const size_t o = ((size_t)(j10 + col) << a.p_log) + jm;
-        lds_put(lo, hi, tile_at(bitrev(row, a.r), col, a.r, a.c_log), ntt_load_input<PROBE>(a, (o << a.r) + row));
+        lds_put(lo, hi, tile_at(bitrev(row, a.r), col, a.r, a.c_log), ntt_load_input(a, (o << a.r) + row));
     }
     __syncthreads();
-    if (PROBE != 1) ntt_tile_stages(lo, hi, a.r, a.c_log, twl, a.quarter_input != 0);
+    ntt_tile_stages(lo, hi, a.r, a.c_log, twl, a.quarter_input != 0);
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
         const uint32_t col = e & (C - 1), row = e >> a.c_log;
         const size_t out_idx = (size_t)(j10 + col) + (((size_t)jm + ((size_t)row << a.p_log)) << a.q_log);
-        const u256 v = ntt_post(a, lds_get(lo, hi, tile_at(row, col, a.r, a.c_log)), out_idx);
-        if (PROBE != 2 || v.v[3] == 0x12345u) store_u256(a.dst, out_idx, v);
+        store_u256(a.dst, out_idx, ntt_post(a, lds_get(lo, hi, tile_at(row, col, a.r, a.c_log)), out_idx));
     }
 }
 
@@ -542,13 +452,12 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleS
     int passes;
     plan_passes(log_n, ctx->tune, rl, &passes);
     for (auto& t : ctx->twiddles)
-        if (t.log_n == log_n && Fr::eq(t.omega, omega) && t.passes == passes && t.radix_log[0] == rl[0] && t.radix_log[1] == rl[1] && t.r261 == ctx->tune.ntt_limb29 &&
+        if (t.log_n == log_n && Fr::eq(t.omega, omega) && t.passes == passes && t.radix_log[0] == rl[0] && t.radix_log[1] == rl[1] &&
             t.radix_log[2] == rl[2] && (t.d_full[0] != nullptr) == (passes > 1 && (int)log_n <= ctx->tune.ntt_full_twiddle_max_log)) { *out = &t; return ZK_OK; }
     TwiddleSet ts;
     ts.log_n = log_n; ts.omega = omega; ts.passes = passes;
-    ts.r261 = ctx->tune.ntt_limb29;           // 1: the strided passes only (measured: the final pass gains nothing, profiles/r03), 2: every pass
-    // a 29-bit plan multiplies with twiddles in the form w * 2^261: its stage and inter-pass tables hold 32 * (w * 2^256) mod p, canonical (the two-level power
-    // tables stay in the library's form: the quotient kernel reads them too)
+    // the strided passes run on 29-bit limbs and multiply with twiddles in the form w * 2^261: their stage and inter-pass tables hold 32 * (w * 2^256) mod p, canonical
+    // (the final pass stays on the 32-bit form — measured, profiles/r03 — and the two-level power tables in the library's form: the quotient kernel reads them too)
     u256 c32 = Fr::zero();
     c32.v[0] = 32;
     c32 = Fr::to_mont(c32);
@@ -567,7 +476,7 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleS
         ZK_HIP(hipMalloc(&ts.d_stage[i], (size_t)half * 32));
         ZK_LAUNCH(fr_pow_table_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, fr_pow2k_host(omega, log_n - rl[i]), half, ts.d_stage[i]);
         ZK_CHECK_LAUNCH();
-        if (ts.r261 == 2 || (ts.r261 == 1 && i + 1 < passes)) {
+        if (i + 1 < passes) {
             ZK_LAUNCH(fr_vec_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, 3, (const void*)ts.d_stage[i], (const void*)ts.d_stage[i], ts.d_stage[i], (size_t)half, c32);
             ZK_CHECK_LAUNCH();
         }
@@ -581,10 +490,8 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleS
             ZK_LAUNCH(ntt_full_twiddle_kernel, (uint32_t)((cnt + blk - 1) / blk), blk, 0, ctx->stream, (const void*)ts.d_lo, (const void*)ts.d_hi, ts.lo_bits,
                       cols_log, rl[i], log_n - blk_log, ts.d_full[i]);
             ZK_CHECK_LAUNCH();
-            if (ts.r261) {
-                ZK_LAUNCH(fr_vec_kernel, 1024, blk, 0, ctx->stream, 3, (const void*)ts.d_full[i], (const void*)ts.d_full[i], ts.d_full[i], cnt, c32);
-                ZK_CHECK_LAUNCH();
-            }
+            ZK_LAUNCH(fr_vec_kernel, 1024, blk, 0, ctx->stream, 3, (const void*)ts.d_full[i], (const void*)ts.d_full[i], ts.d_full[i], cnt, c32);
+            ZK_CHECK_LAUNCH();
             blk_log -= rl[i];
         }
     }
@@ -605,20 +512,8 @@ void release_twiddles(zk_ctx* ctx) {
 
 int ntt_set_lds_attr() {
 #ifndef ZK_EMU
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass29_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass29_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass29_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass29_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass29_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass29_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#ifdef ZK_NTT_PROBE
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#endif
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_final_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_strided_pass29_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
     return 0;
 }
@@ -701,8 +596,7 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
         if (first && nf.cs_stride) { a.cs_lo = nf.cs_lo; a.cs_hi = nf.cs_hi; a.cs_lo_bits = nf.cs_lo_bits; a.cs_stride = nf.cs_stride; a.cs_log = nf.cs_log; }
         if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; a.quarter_input = tn.ntt_quarter_input && nf.n_valid && (size_t)nf.n_valid * 4 <= N && a.r >= 2; }
         if (last) { a.post_scale = nf.post_scale; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
-        const bool l29 = ts->r261 == 2 || (ts->r261 == 1 && !last);
-        if (l29) {
+        if (!last) {                                                  // strided pass: 29-bit limbs, the constants of its fused operations as x * 2^261
             u256 c32 = Fr::zero();
             c32.v[0] = 32;
             c32 = Fr::to_mont(c32);
@@ -711,23 +605,14 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             a.zeta29[1] = Fr::mul(zeta_pow(2), c32);
         }
         const uint32_t room = tl > a.r ? tl - a.r : 0;
+        EvTimer t_pass(ctx, last ? "ntt_final_pass" : "ntt_strided_pass");   // (event pairs only while zk_timing_enable is on; read at the next zk_timing_get)
         if (!last) {
             const uint32_t cols_log = blk_log - a.r;
             a.c_log = room < cols_log ? room : cols_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
-            const size_t lds = l29 ? ((((size_t)36 << (a.r + a.c_log)) + 15) & ~(size_t)15) + ((size_t)18 << a.r) + 64     // 36-byte elements: tile + R/2 stage twiddles
-                                   : ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
-            if (l29 && tn.ntt_threads > 256) return ctx->fail(ZK_ERR_ARG, "ntt_threads: the 29-bit passes take at most 256 threads per workgroup");
-            if (l29 && tn.ntt_waves == 3) { ZK_LAUNCH(ntt_strided_pass29_kernel<3>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
-            else if (l29 && tn.ntt_waves == 4) { ZK_LAUNCH(ntt_strided_pass29_kernel<4>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
-            else if (l29) { ZK_LAUNCH(ntt_strided_pass29_kernel<2>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
-            else
-#ifdef ZK_NTT_PROBE
-            if (tn.ntt_debug_mode == 1) { ZK_LAUNCH(ntt_strided_pass_kernel<1>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
-            else if (tn.ntt_debug_mode == 2) { ZK_LAUNCH(ntt_strided_pass_kernel<2>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
-            else
-#endif
-            ZK_LAUNCH(ntt_strided_pass_kernel<0>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
+            const size_t lds = ((((size_t)36 << (a.r + a.c_log)) + 15) & ~(size_t)15) + ((size_t)18 << a.r) + 64;     // 36-byte elements: tile + R/2 stage twiddles
+            if (tn.ntt_threads > 256) return ctx->fail(ZK_ERR_ARG, "ntt_threads: the strided passes take at most 256 threads per workgroup");
+            ZK_LAUNCH(ntt_strided_pass29_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();
         } else {
             // o = j1 * Pm + jm with j1 the digit of pass 0 (Q = R_0) and jm the digit of pass 1 (if 3 passes)
@@ -735,26 +620,18 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             a.p_log = P == 3 ? ts->radix_log[1] : 0;
             a.c_log = room < a.q_log ? room : a.q_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
-            const size_t lds = l29 ? ((((size_t)36 << (a.r + a.c_log)) + 15) & ~(size_t)15) + ((size_t)18 << a.r) + 64
-                                   : ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
-            if (l29 && tn.ntt_threads > 256) return ctx->fail(ZK_ERR_ARG, "ntt_threads: the 29-bit passes take at most 256 threads per workgroup");
-            if (l29 && tn.ntt_waves == 3) { ZK_LAUNCH(ntt_final_pass29_kernel<3>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
-            else if (l29 && tn.ntt_waves == 4) { ZK_LAUNCH(ntt_final_pass29_kernel<4>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
-            else if (l29) { ZK_LAUNCH(ntt_final_pass29_kernel<2>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
-            else
-#ifdef ZK_NTT_PROBE
-            if (tn.ntt_debug_mode == 1) { ZK_LAUNCH(ntt_final_pass_kernel<1>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
-            else if (tn.ntt_debug_mode == 2) { ZK_LAUNCH(ntt_final_pass_kernel<2>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a); }
-            else
-#endif
-            ZK_LAUNCH(ntt_final_pass_kernel<0>, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
+            const size_t lds = ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
+            ZK_LAUNCH(ntt_final_pass_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();
             if (via_tmp)
                 for (size_t i = 0; i < count; i++)
                     ZK_HIP(hipMemcpyAsync(h_cols[i], tmp_base + i * N * 32, N * 32, hipMemcpyDeviceToDevice, ctx->stream));
         }
+        t_pass.stop();
+        t_pass.defer();
         blk_log -= a.r;
     }
+    if (ctx->timing) { ctx->last_ms["ntt_points"] += (double)count * (double)N; ctx->last_ms["ntt_pass_points"] += (double)count * (double)N * P; }
     return ZK_OK;
 }
 int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const NttFuse* fuse) {

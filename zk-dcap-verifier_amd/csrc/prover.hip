@@ -515,22 +515,20 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
     Draws draws;
     for (double& v : g_phase_ms) v = 0;
     PhaseClock clk;
-    // The caller's `&mut rng` is consumed in halo2's order (plonk/prover.rs and the argument provers it calls; [3P-MEM]).  draw_schedule 1 (upstream, the default of
-    // every binding): the blinding rows of every advice column, then one Blind(Fr::random) per advice column (KZG ignores the value, the stream advances); per lookup, in order:
+    // The caller's `&mut rng` is consumed in halo2's order (plonk/prover.rs and the argument provers it calls; [3P-MEM]).  draw_schedule 1 (the only one:
+    // every binding sets it): the blinding rows of every advice column, then one Blind(Fr::random) per advice column (KZG ignores the value, the stream advances); per lookup, in order:
     // permute_expression_pair's input rows then table rows, then commit_values' two Blinds; per permutation set its rows + one Blind; per lookup product its rows + one Blind; the
-    // vanishing argument's n coefficients + one Blind; one Blind per h(X) piece.  draw_schedule 0 (rounds 1-2 of this repo): no Blind draws, all lookups' input rows before all table rows.
-    if (pk->draw_schedule > 1) return ZK_ERR_ARG;
-    const bool upstream = pk->draw_schedule == 1;
+    // vanishing argument's n coefficients + one Blind; one Blind per h(X) piece.
+    if (pk->draw_schedule != 1) return pk_fail(ctx, ZK_ERR_ARG, "zk_plonk_create_proof: draw_schedule %u (1 = halo2_proofs v2023_01_20, the only schedule this build knows)", pk->draw_schedule);
     auto plan = [&](size_t count) { draws.counts.push_back(count); return draws.counts.size() - 1; };
     std::vector<size_t> d_bi(L), d_bt(L), d_pb(n_sets), d_lb(L);
     for (uint32_t i = 0; i < pk->n_advice; i++) plan(n - usable);                                  // items [0, n_advice)
-    if (upstream) for (uint32_t i = 0; i < pk->n_advice; i++) plan(1);
-    if (upstream) for (uint32_t l = 0; l < L; l++) { d_bi[l] = plan(bf + 1); d_bt[l] = plan(bf + 1); plan(1); plan(1); }
-    else { for (uint32_t l = 0; l < L; l++) d_bi[l] = plan(bf + 1); for (uint32_t l = 0; l < L; l++) d_bt[l] = plan(bf + 1); }
-    for (uint32_t s = 0; s < n_sets; s++) { d_pb[s] = plan(bf); if (upstream) plan(1); }
-    for (uint32_t l = 0; l < L; l++) { d_lb[l] = plan(bf); if (upstream) plan(1); }
+    for (uint32_t i = 0; i < pk->n_advice; i++) plan(1);
+    for (uint32_t l = 0; l < L; l++) { d_bi[l] = plan(bf + 1); d_bt[l] = plan(bf + 1); plan(1); plan(1); }
+    for (uint32_t s = 0; s < n_sets; s++) { d_pb[s] = plan(bf); plan(1); }
+    for (uint32_t l = 0; l < L; l++) { d_lb[l] = plan(bf); plan(1); }
     const size_t d_rp = plan(n);
-    if (upstream) for (uint32_t i = 0; i < 1 + n_pieces; i++) plan(1);
+    for (uint32_t i = 0; i < 1 + n_pieces; i++) plan(1);
     draws.start(rng, rng_user, mem.pool);
 
     // ---- 1. vk, instances ----------------------------------------------------------------------------------------------------------------------------
@@ -683,6 +681,20 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
         a.lookup_product = (const void* const*)ext + nA + nI + n_sets; a.lookup_input = e_in.data(); a.lookup_table = e_tab.data();
         a.challenges = one.v; a.beta = beta.v; a.gamma = gamma.v; a.theta = theta.v; a.y = y.v;
     };
+    // Degree split (zkmi355.h, zk_quotient_program_split): the identities of degree <= 3 — about half of the sgx-shaped program's arithmetic — are evaluated on
+    // low_cosets = 2 cosets only; their share of h(X) has degree below 2 n and is added to the first two pieces.  Single-GPU proofs only (a sharded proof keeps the whole program).
+    uint32_t low_cosets = 0;
+    {
+        int want = 0;
+        if (!sharded && zk_tune_get(ctx, "quot_degree_split", &want) == ZK_OK && want) PK(zk_quotient_program_split(ctx, pk->program, &low_cosets, nullptr, nullptr));
+        if (low_cosets >= n_pieces || low_cosets > n_cosets) low_cosets = 0;
+    }
+    std::vector<void*> numer_low(low_cosets);
+    if (low_cosets) {
+        void* blk = mem.get(low_cosets * col_bytes);                  // (one block: zk_quotient_run_low_dev writes the cosets back to back)
+        if (!blk) return ZK_ERR_HIP;
+        for (uint32_t j = 0; j < low_cosets; j++) numer_low[j] = (char*)blk + (size_t)j * col_bytes;
+    }
     if (by_cosets) {
         std::vector<void*> cols(lag.size());
         for (auto& e : cols) { e = mem.get(col_bytes); if (!e) return ZK_ERR_HIP; }
@@ -695,7 +707,11 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
             a.fixed = pk->coset_fixed + (size_t)j * pk->n_fixed; a.perm_cosets = pk->coset_sigma + (size_t)j * pk->n_perm_columns;
             a.l0 = pk->coset_l[3 * j]; a.l_last = pk->coset_l[3 * j + 1]; a.l_active_row = pk->coset_l[3 * j + 2];
             a.out = numer[j];
-            PK(zk_quotient_run_coset_dev(ctx, pk->program, &a, j));
+            if (!low_cosets) PK(zk_quotient_run_coset_dev(ctx, pk->program, &a, j));
+            else {
+                PK(zk_quotient_run_coset_part_dev(ctx, pk->program, &a, j, 1));
+                if (j < low_cosets) { a.out = numer_low[j]; PK(zk_quotient_run_coset_part_dev(ctx, pk->program, &a, j, 2)); }
+            }
         }
         for (auto e : cols) mem.give_back(e);
     } else if (!sharded) {
@@ -706,7 +722,12 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
         zk_quotient_args a;
         quotient_args(a, ext.data(), e_in, e_tab);
         a.fixed = pk->fixed_cosets; a.l0 = pk->l0; a.l_last = pk->l_last; a.l_active_row = pk->l_active_row; a.perm_cosets = pk->sigma_cosets; a.out = h_ext;
-        PK(zk_quotient_run_dev(ctx, pk->program, &a));
+        if (!low_cosets) PK(zk_quotient_run_dev(ctx, pk->program, &a));
+        else {
+            PK(zk_quotient_run_high_dev(ctx, pk->program, &a));
+            a.out = numer_low[0];
+            PK(zk_quotient_run_low_dev(ctx, pk->program, &a, low_cosets));
+        }
         for (auto e : ext) mem.give_back(e);
     } else {
         // this rank brings the columns to ITS cosets only (size-n NTTs), evaluates the numerator on its units straight into the send buffer; one all-gather
@@ -746,6 +767,18 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
         PK(zk_divide_by_vanishing_poly_dev(ctx, h_ext, k, ek));
         PK(zk_extended_to_coeff_dev(ctx, h_ext, k, ek));
         for (uint32_t i = 0; i < n_pieces; i++) pieces[i] = (char*)h_ext + (size_t)i * col_bytes;
+    }
+    if (low_cosets) {                                                 // h = (the high part's pieces) + (the low part's two pieces)
+        std::vector<void*> lowp(low_cosets);
+        for (auto& e : lowp) { e = mem.get(col_bytes); if (!e) return ZK_ERR_HIP; }
+        PK(zk_cosets_to_pieces_dev(ctx, numer_low.data(), low_cosets, k, ek, lowp.data()));
+        const Fe ones[2] = {one, one};
+        for (uint32_t i = 0; i < low_cosets; i++) {
+            const void* two[2] = {pieces[i], lowp[i]};
+            PK(zk_fr_lincomb_dev(ctx, two, ones, 2, n, pieces[i]));
+        }
+        for (auto e : lowp) mem.give_back(e);
+        mem.give_back(numer_low[0]);
     }
     PK(commit(pk->srs_g, pieces));
     clk.lap(6);
@@ -1009,7 +1042,7 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
     if (host->struct_size != sizeof(zk_plonk_pk_host))
         return pk_fail(ctx, ZK_ERR_ARG, "zk_plonk_pk_build: zk_plonk_pk_host.struct_size %u, expected %zu (ABI version %u)", host->struct_size, sizeof(zk_plonk_pk_host), ZK_ABI_VERSION);
     const uint32_t k = host->k, L = host->n_lookups;
-    if (k < 1 || k > 27 || host->cs_degree < 3 || host->transcript > 2 || host->draw_schedule > 1 || !host->transcript_repr || !host->evaluator_zkq1) return ZK_ERR_ARG;
+    if (k < 1 || k > 27 || host->cs_degree < 3 || host->transcript > 2 || host->draw_schedule != 1 || !host->transcript_repr || !host->evaluator_zkq1) return ZK_ERR_ARG;
     if ((host->n_fixed && !host->fixed_values) || (host->n_perm_columns && (!host->sigma_values || !host->perm_columns)) || (host->n_advice_queries && !host->advice_queries) ||
         (host->n_fixed_queries && !host->fixed_queries) ||
         (L && (!host->lookup_input_zkq1 || !host->lookup_input_zkq1_len || !host->lookup_table_zkq1 || !host->lookup_table_zkq1_len || !host->lookup_table_key)))

@@ -34,20 +34,26 @@ struct QuotProgram {
     uint32_t n_perm_cols = 0, n_sets = 0, n_lookups = 0;
     std::vector<uint32_t> perm_cols;      // pairs (type, index)
     std::vector<uint4> code;
-    std::vector<uint4> code29;            // the same micro-program annotated for the 29-bit-limb interpreter (bias class / reduce flags from the bound analysis); empty = not available
     std::vector<u256> graph_consts;       // constants that come with the program
     std::vector<int32_t> rotations;       // distinct rotations (rows)
     uint32_t n_slots = 0, n_cols = 0;
     // constant table layout (indices)
-    uint32_t c_zero = 0, c_one = 0, c_chal = 0, c_beta = 0, c_gamma = 0, c_theta = 0, c_y = 0, c_delta = 0, n_consts = 0;
+    uint32_t c_zero = 0, c_one = 0, c_chal = 0, c_beta = 0, c_gamma = 0, c_theta = 0, c_y = 0, c_delta = 0, c_ypow = 0, n_consts = 0;
+    // Degree split (compile_program, `mode`): h's numerator is sum_i y^(N-1-i) id_i over the N identities halo2 folds with y; an identity of degree d (in the columns)
+    // contributes a share of h(X) of degree below (d - 1) n, which (d - 1) cosets of the size-n domain determine.  part_hi / part_lo are the SAME program restricted to the
+    // identities of degree above / up to SPLIT_LOW_DEGREE (a skipped identity leaves a power of y on the next fold: ypow_exps, constants of the run at c_ypow): the low part
+    // is evaluated on SPLIT_LOW_DEGREE - 1 cosets only and joins h(X) through zk_cosets_to_pieces_dev.  Exact for every witness that satisfies the circuit (each identity
+    // then vanishes on the domain on its own, so both shares are polynomials).
+    std::vector<uint32_t> ypow_exps;      // y^e constants this program reads, e >= 2
+    uint32_t folds_taken = 0, folds_skipped = 0;
+    std::shared_ptr<QuotProgram> part_hi, part_lo;
     // column ids
     uint32_t col_fixed = 0, col_advice = 0, col_instance = 0, col_l0 = 0, col_llast = 0, col_lactive = 0, col_sigma = 0, col_z = 0,
              col_lk_z = 0, col_lk_a = 0, col_lk_s = 0;
     bool uses_xpow = false;
-    void* d_code29 = nullptr;
     void* d_code = nullptr;               // immutable after the load; the constants / column pointers / rotation offsets of a RUN live in the calling context's ws_quot,
     int device = 0;                       // so contexts of one device can share a program (zk_quotient_program_share) and run it concurrently
-    ~QuotProgram() { if (d_code) { (void)hipSetDevice(device); (void)hipFree(d_code); } if (d_code29) { (void)hipSetDevice(device); (void)hipFree(d_code29); } }
+    ~QuotProgram() { if (d_code) { (void)hipSetDevice(device); (void)hipFree(d_code); } }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -73,8 +79,9 @@ struct QuotArgs {
     uint32_t lo_bits;
     int uses_xpow;
     uint32_t xpow_mul, xpow_add;   // X of row idx = extended_omega^(idx * xpow_mul + xpow_add): (1, 0) on the whole extended domain, (2^(ek-k), j) on coset j
+    uint32_t strided, sub_log, stride_log, k_log;   // strided: thread t works on row ((t >> sub_log) << stride_log) + (t & (2^sub_log - 1)) of extended-layout columns
+                                                    // and writes out[((t & (2^sub_log - 1)) << k_log) + (t >> sub_log)]: the first 2^sub_log cosets, coset-major
     uint32_t row_base;             // first row of this launch (a launch may cover a slice of the rows: out[i] = numerator of row row_base + i)
-    uint32_t lds_slots;            // quotient29_kernel: slots that live in LDS (its 4-byte plane starts after their two 16-byte planes)
     void* out;
 };
 
@@ -82,225 +89,92 @@ struct QuotArgs {
 // constant operands of instruction pc + 1 are already in flight (the kernel is otherwise bound by the latency of ~850
 // dependent 32-byte loads per row, not by arithmetic: profiles/r01).  Slot, accumulator and X-power operands are read at
 // execute time because the previous instruction may just have written them.
-// NR rows per thread (rows idx, idx + T, ...): one decode of a micro-op serves NR rows — the decode is ≈50 issue slots against ≈300 for a product.
-template <int NR>
-ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(NR == 1 ? 4 : 2) quotient_kernel(QuotArgs q) {
+ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) quotient_kernel(QuotArgs q) {
     ZK_DYN_SHARED(uint4, smem);
     const uint32_t T = blockDim.x, tid = threadIdx.x;
-    const uint32_t idx0 = q.row_base + blockIdx.x * (T * NR) + tid;   // row r of this thread: idx0 + r * T
-    const uint32_t mask = (1u << q.size_log) - 1u;
-    u256 acc[NR], xpow[NR], rg0[NR];                            // slot 0 lives in VGPRs
-#pragma unroll
-    for (int r = 0; r < NR; r++) {
-        acc[r] = Fr::zero(); xpow[r] = Fr::one(); rg0[r] = Fr::zero();
-        if (q.uses_xpow) {  // extended_omega^(position of this row in the extended domain)
-            const uint32_t xi = (idx0 + r * T) * q.xpow_mul + q.xpow_add;
-            xpow[r] = load_u256(q.tw_lo, xi & ((1u << q.lo_bits) - 1u));
-            const uint32_t h = xi >> q.lo_bits;
-            if (h) xpow[r] = Fr::mul(xpow[r], load_u256(q.tw_hi, h));
-        }
+    uint32_t idx0 = q.row_base + blockIdx.x * T + tid;                // this thread's row
+    uint32_t oidx = idx0 - q.row_base;
+    if (q.strided) {
+        const uint32_t j = idx0 & ((1u << q.sub_log) - 1u), i = idx0 >> q.sub_log;
+        idx0 = (i << q.stride_log) + j;
+        oidx = (j << q.k_log) + i;
     }
-    struct Rows { u256 v[NR]; };
-    auto prefetch = [&](uint32_t src) -> Rows {        // memory operands only; everything else is resolved later
-        const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
-        Rows o;
-        if (kind == K_COL) {
-            const uint32_t off = q.rot_off[pay & 0xffu];
-            const void* col = q.cols[pay >> 8];
-#pragma unroll
-            for (int r = 0; r < NR; r++) o.v[r] = load_u256(col, (idx0 + r * T + off) & mask);
-            return o;
-        }
-        if (kind == K_CONST) {
-            const u256 c = load_u256(q.consts, pay);
-#pragma unroll
-            for (int r = 0; r < NR; r++) o.v[r] = c;
-            return o;
-        }
-#pragma unroll
-        for (int r = 0; r < NR; r++) o.v[r] = Fr::zero();
-        return o;
-    };
-    auto resolve = [&](uint32_t src, const Rows& pre, int r) -> u256 {
-        const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
-        switch (kind) {
-            case K_SLOT: {
-                switch (pay) {
-                    case 0: return rg0[r];
-                    default: break;
-                }
-                const uint32_t ls = (pay - QUOT_NREG) * NR + r;
-                uint4 l = smem[(2 * ls) * T + tid], h = smem[(2 * ls + 1) * T + tid];
-                u256 o;
-                o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w;
-                return o;
-            }
-            case K_ACC: return acc[r];
-            case K_XPOW: return xpow[r];
-            default: return pre.v[r];       // K_COL / K_CONST (already loaded) or K_NONE
-        }
-    };
-    uint4 ins = q.n_instr ? q.code[0] : make_uint4(M_MOV | (1u << 8), K_NONE << 28, K_NONE << 28, K_NONE << 28);
-    Rows pa = prefetch(ZK_UNIFORM(ins.y)), pb = prefetch(ZK_UNIFORM(ins.z)), pc_ = prefetch(ZK_UNIFORM(ins.w));
-    for (uint32_t pc = 0; pc < q.n_instr; pc++) {
-        const uint32_t w0 = ZK_UNIFORM(ins.x), sa = ZK_UNIFORM(ins.y), sb = ZK_UNIFORM(ins.z), sc = ZK_UNIFORM(ins.w);
-        // put the next instruction's loads in flight before this one's arithmetic
-        uint4 nxt = ins;
-        Rows na = pa, nb = pb, nc = pc_;
-        if (pc + 1 < q.n_instr) {
-            nxt = q.code[pc + 1];
-            na = prefetch(ZK_UNIFORM(nxt.y)); nb = prefetch(ZK_UNIFORM(nxt.z)); nc = prefetch(ZK_UNIFORM(nxt.w));
-        }
-        const uint32_t op = w0 & 0xffu;
-        u256 res[NR];
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const u256 a = resolve(sa, pa, r);
-            switch (op) {
-                // every value of a row (slots, accumulator) lives in [0, 2p] (field.cuh, redundant ranges): products skip their final subtraction, sums and
-                // differences are corrected by 2p (same cost as by p), memory operands arrive canonical, and the row's result is normalised once at the end
-                case M_ADD: res[r] = Fr::red2p(Fr::add_lazy(a, resolve(sb, pb, r))); break;
-                case M_SUB: res[r] = Fr::sub2(a, resolve(sb, pb, r)); break;
-                case M_MUL: res[r] = Fr::mul_lazy(a, resolve(sb, pb, r)); break;
-                case M_SQR: res[r] = Fr::sqr_lazy(a); break;
-                case M_DBL: res[r] = Fr::dbl2(a); break;
-                case M_NEG: res[r] = Fr::neg2(a); break;
-                case M_MULADD: res[r] = Fr::red2p(Fr::add_lazy(Fr::mul_lazy(a, resolve(sb, pb, r)), resolve(sc, pc_, r))); break;
-                case M_FOLD2: res[r] = Fr::mul2_add_2p(acc[r], resolve(sc, pc_, r), a, resolve(sb, pb, r)); break;
-                default: res[r] = a; break;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            if ((w0 >> 8) & 0xffu) {
-                acc[r] = res[r];
-            } else {
-                const uint32_t slot = w0 >> 16;
-                switch (slot) {
-                    case 0: rg0[r] = res[r]; break;
-                    default: {
-                        const uint32_t ls = (slot - QUOT_NREG) * NR + r;
-                        smem[(2 * ls) * T + tid] = make_uint4(res[r].v[0], res[r].v[1], res[r].v[2], res[r].v[3]);
-                        smem[(2 * ls + 1) * T + tid] = make_uint4(res[r].v[4], res[r].v[5], res[r].v[6], res[r].v[7]);
-                    }
-                }
-            }
-        }
-        ins = nxt; pa = na; pb = nb; pc_ = nc;
-    }
-#pragma unroll
-    for (int r = 0; r < NR; r++) store_u256(q.out, idx0 - q.row_base + r * T, Fr::normalize(acc[r]));
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same interpreter on carry-free 29-bit limbs (field29.cuh; round 3).  Every value of a row — slots, accumulator, X power — is x * 2^261 in N-form limbs; a column
-// operand enters through the limb conversion's shift by 5 (x * 2^256 -> x * 2^261, below 32 p), a constant arrives as x * 2^261 mod p (quotient_run multiplies the
-// run's constant table by 32).  There is no modular correction in the loop: a product returns below a b / 151 + 1 (in multiples of p), sums add their bounds, a
-// difference a - b + K p adds K, and the COMPILER tracks those bounds statically (bound29_pass): it picks K = 2^(class + 1) > bound(b) for every subtraction / negation
-// and flags the (rare) result that must be brought back below 3 p.  Sums and differences take one parallel carry round before they are stored, so every stored value
-// has N-form limbs and every product sees N-form operands.  One product with 2^256 mod p takes the row's result back to the library's form.
-// w0 of a 29-bit instruction: op [0,8) | writes the accumulator [8] | bias class [9,13) | reduce the result [13] | slot [16,32).
-// ------------------------------------------------------------------------------------------------
-// K p for K = 2^(cls + 1), written so that every limb 0..7 dominates an N-form limb: digits of (2p << cls) plus 2^30 on limbs 0..7, each 2^30 paid for by 2 units of
-// the next limb (2^30 * 2^(29 i) = 2 * 2^(29 (i + 1))).  Computed from the compile-time digits of 2p and the UNIFORM class with a few scalar shifts — a table in
-// constant memory cost a scalar load + a full s_waitcnt per subtraction (35 % of the wave cycles parked, profiles/r03 run98).
-struct TwoP29 { uint32_t d[9]; };
-constexpr TwoP29 make_two_p29() {
-    TwoP29 t{};
-    uint32_t carry = 0;
-    for (int i = 0; i < 9; i++) { const uint32_t v = 2u * Fr29::p29(i) + carry; t.d[i] = i < 8 ? (v & Fr29::M29) : v; carry = i < 8 ? v >> 29 : 0; }
-    return t;
-}
-ZK_HD uint32_t bias29_limb(int i, uint32_t cls) {                       // limb i of the dominant form of 2^(cls + 1) p, cls <= 7
-    constexpr TwoP29 tp = make_two_p29();
-    uint32_t digit = tp.d[i] << cls;                                   // (2p << cls): this limb's bits shifted up, the previous limb's top bits shifted in
-    if (i > 0) digit |= tp.d[i - 1] >> (29 - cls);
-    if (i < 8) digit &= Fr29::M29;
-    return digit + (i < 8 ? (1u << 30) : 0u) - (i > 0 ? 2u : 0u);
-}
-
-ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) quotient29_kernel(QuotArgs q) {
-    ZK_DYN_SHARED(uint4, smem);
-    const uint32_t T = blockDim.x, tid = threadIdx.x;
-    const uint32_t idx0 = q.row_base + blockIdx.x * T + tid;
     const uint32_t mask = (1u << q.size_log) - 1u;
-    uint32_t* const top_plane = reinterpret_cast<uint32_t*>(smem + (size_t)2 * q.lds_slots * T);      // limb 8 of every LDS slot, after the two 16-byte planes
-    u261 acc = Fr29::zero(), xpow = Fr29::one(), rg0 = Fr29::zero();
-    if (q.uses_xpow) {  // extended_omega^(position of this row in the extended domain), as x * 2^261 below 8 p
+    u256 acc = Fr::zero(), xpow = Fr::one(), rg0 = Fr::zero();        // slot 0 lives in VGPRs
+    if (q.uses_xpow) {  // extended_omega^(position of this row in the extended domain)
         const uint32_t xi = idx0 * q.xpow_mul + q.xpow_add;
-        const u261 lo = Fr29::from32<5>(load_u256(q.tw_lo, xi & ((1u << q.lo_bits) - 1u)));
+        xpow = load_u256(q.tw_lo, xi & ((1u << q.lo_bits) - 1u));
         const uint32_t h = xi >> q.lo_bits;
-        xpow = Fr29::mul(lo, h ? Fr29::from32<5>(load_u256(q.tw_hi, h)) : Fr29::one());
+        if (h) xpow = Fr::mul(xpow, load_u256(q.tw_hi, h));
     }
-    auto prefetch = [&](uint32_t src) -> u256 {        // memory operands only, still in the library's 32-bit words; everything else is resolved later
+    auto prefetch = [&](uint32_t src) -> u256 {        // memory operands only; everything else is resolved later
         const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
         if (kind == K_COL) return load_u256(q.cols[pay >> 8], (idx0 + q.rot_off[pay & 0xffu]) & mask);
         if (kind == K_CONST) return load_u256(q.consts, pay);
         return Fr::zero();
     };
-    auto resolve = [&](uint32_t src, const u256& pre) -> u261 {
+    auto resolve = [&](uint32_t src, const u256& pre) -> u256 {
         const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
         switch (kind) {
             case K_SLOT: {
-                if (pay == 0) return rg0;
+                switch (pay) {
+                    case 0: return rg0;
+                    default: break;
+                }
                 const uint32_t ls = pay - QUOT_NREG;
-                const uint4 l = smem[(2 * ls) * T + tid], h = smem[(2 * ls + 1) * T + tid];
-                u261 o;
-                o.l[0] = l.x; o.l[1] = l.y; o.l[2] = l.z; o.l[3] = l.w; o.l[4] = h.x; o.l[5] = h.y; o.l[6] = h.z; o.l[7] = h.w;
-                o.l[8] = top_plane[ls * T + tid];
+                uint4 l = smem[(2 * ls) * T + tid], h = smem[(2 * ls + 1) * T + tid];
+                u256 o;
+                o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w;
                 return o;
             }
             case K_ACC: return acc;
             case K_XPOW: return xpow;
-            case K_COL: return Fr29::from32<5>(pre);
-            default: return Fr29::from32<0>(pre);        // K_CONST (x * 2^261 mod p already) or K_NONE (zero)
+            default: return pre;       // K_COL / K_CONST (already loaded) or K_NONE
         }
-    };
-    auto biased = [&](const u261& a, const u261& b, uint32_t cls, bool with_a) -> u261 {   // a - b + K p (or K p - b), K = 2^(cls + 1)
-        u261 o;
-#pragma unroll
-        for (int i = 0; i < 9; i++) o.l[i] = (with_a ? a.l[i] : 0u) + bias29_limb(i, cls) - b.l[i];
-        return o;
     };
     uint4 ins = q.n_instr ? q.code[0] : make_uint4(M_MOV | (1u << 8), K_NONE << 28, K_NONE << 28, K_NONE << 28);
     u256 pa = prefetch(ZK_UNIFORM(ins.y)), pb = prefetch(ZK_UNIFORM(ins.z)), pc_ = prefetch(ZK_UNIFORM(ins.w));
     for (uint32_t pc = 0; pc < q.n_instr; pc++) {
         const uint32_t w0 = ZK_UNIFORM(ins.x), sa = ZK_UNIFORM(ins.y), sb = ZK_UNIFORM(ins.z), sc = ZK_UNIFORM(ins.w);
+        // put the next instruction's loads in flight before this one's arithmetic
         uint4 nxt = ins;
         u256 na = pa, nb = pb, nc = pc_;
-        if (pc + 1 < q.n_instr) {                      // the next instruction's loads go out before this one's arithmetic
+        if (pc + 1 < q.n_instr) {
             nxt = q.code[pc + 1];
             na = prefetch(ZK_UNIFORM(nxt.y)); nb = prefetch(ZK_UNIFORM(nxt.z)); nc = prefetch(ZK_UNIFORM(nxt.w));
         }
-        const uint32_t op = w0 & 0xffu, cls = (w0 >> 9) & 0xfu;
-        const u261 a = resolve(sa, pa);
-        u261 res;
+        const uint32_t op = w0 & 0xffu;
+        u256 res;
+        const u256 a = resolve(sa, pa);
         switch (op) {
-            case M_ADD: res = Fr29::carry(Fr29::add(a, resolve(sb, pb))); break;
-            case M_SUB: res = Fr29::carry(biased(a, resolve(sb, pb), cls, true)); break;
-            case M_MUL: res = Fr29::mul(a, resolve(sb, pb)); break;
-            case M_SQR: res = Fr29::sqr(a); break;
-            case M_DBL: res = Fr29::carry(Fr29::dbl(a)); break;
-            case M_NEG: res = Fr29::carry(biased(a, a, cls, false)); break;
-            case M_MULADD: res = Fr29::carry(Fr29::add(Fr29::mul(a, resolve(sb, pb)), resolve(sc, pc_))); break;
-            case M_FOLD2: res = Fr29::mul2(acc, resolve(sc, pc_), a, resolve(sb, pb)); break;
+            // every value of a row (slots, accumulator) lives in [0, 2p] (field.cuh, redundant ranges): products skip their final subtraction, sums and
+            // differences are corrected by 2p (same cost as by p), memory operands arrive canonical, and the row's result is normalised once at the end
+            case M_ADD: res = Fr::red2p(Fr::add_lazy(a, resolve(sb, pb))); break;
+            case M_SUB: res = Fr::sub2(a, resolve(sb, pb)); break;
+            case M_MUL: res = Fr::mul_lazy(a, resolve(sb, pb)); break;
+            case M_SQR: res = Fr::sqr_lazy(a); break;
+            case M_DBL: res = Fr::dbl2(a); break;
+            case M_NEG: res = Fr::neg2(a); break;
+            case M_MULADD: res = Fr::red2p(Fr::add_lazy(Fr::mul_lazy(a, resolve(sb, pb)), resolve(sc, pc_))); break;
+            case M_FOLD2: res = Fr::mul2_add_2p(acc, resolve(sc, pc_), a, resolve(sb, pb)); break;
             default: res = a; break;
         }
-        if ((w0 >> 13) & 1u) res = Fr29::reduce_small(res);
-        if ((w0 >> 8) & 1u) acc = res;
-        else {
+        if ((w0 >> 8) & 0xffu) {
+            acc = res;
+        } else {
             const uint32_t slot = w0 >> 16;
-            if (slot == 0) rg0 = res;
-            else {
-                const uint32_t ls = slot - QUOT_NREG;
-                smem[(2 * ls) * T + tid] = make_uint4(res.l[0], res.l[1], res.l[2], res.l[3]);
-                smem[(2 * ls + 1) * T + tid] = make_uint4(res.l[4], res.l[5], res.l[6], res.l[7]);
-                top_plane[ls * T + tid] = res.l[8];
+            switch (slot) {
+                case 0: rg0 = res; break;
+                default: {
+                    const uint32_t ls = slot - QUOT_NREG;
+                    smem[(2 * ls) * T + tid] = make_uint4(res.v[0], res.v[1], res.v[2], res.v[3]);
+                    smem[(2 * ls + 1) * T + tid] = make_uint4(res.v[4], res.v[5], res.v[6], res.v[7]);
+                }
             }
         }
         ins = nxt; pa = na; pb = nb; pc_ = nc;
     }
-    store_u256(q.out, idx0 - q.row_base, Fr29::leave(acc));
+    store_u256(q.out, oidx, Fr::normalize(acc));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -424,7 +298,9 @@ struct Builder {
     QuotProgram& P;
     std::vector<VIns> ins;
     int next_vreg = 0;
-    explicit Builder(QuotProgram& p) : P(p) {}
+    int mode = 0;                            // 0: every identity; 1: only those of degree > low_deg; 2: only those of degree <= low_deg
+    uint32_t low_deg = 3, pending = 0;       // pending: folds skipped since the last one taken (the next fold multiplies by y^(pending + 1))
+    Builder(QuotProgram& p, int m, uint32_t ld) : P(p), mode(m), low_deg(ld) {}
     static uint32_t enc(uint32_t kind, uint32_t pay) { return (kind << 28) | pay; }
     struct Opnd { uint32_t word; int vreg; };
     Opnd slot(int v) { return Opnd{enc(K_SLOT, 0), v}; }
@@ -458,7 +334,26 @@ struct Builder {
         shared[key] = v;
         return v;
     }
-    void fold(Opnd term) { emit(M_MULADD, -1, {acc(), cst(P.c_y), term}); }   // value = value*y + term
+    Opnd ypow(uint32_t e) {                  // the run's constant y^e
+        if (e == 1) return cst(P.c_y);
+        for (size_t i = 0; i < P.ypow_exps.size(); i++) if (P.ypow_exps[i] == e) return cst(P.c_ypow + (uint32_t)i);
+        P.ypow_exps.push_back(e);
+        return cst(P.c_ypow + (uint32_t)P.ypow_exps.size() - 1);
+    }
+    bool is_ypow(uint32_t word) const {
+        if ((word >> 28) != K_CONST) return false;
+        const uint32_t pay = word & 0x0fffffffu;
+        return pay == P.c_y || (pay >= P.c_ypow && pay < P.c_ypow + P.ypow_exps.size());
+    }
+    // value = value*y + term for an identity of degree `deg` (in the columns); a part of the program that leaves this identity out owes the accumulator one power of y
+    void fold(Opnd term, uint32_t deg) {
+        const bool take = mode == 0 || (mode == 2) == (deg <= low_deg);
+        if (!take) { pending++; P.folds_skipped++; return; }
+        emit(M_MULADD, -1, {acc(), ypow(pending + 1), term});
+        pending = 0;
+        P.folds_taken++;
+    }
+    void flush_pending() { if (pending && P.folds_taken) emit(M_MUL, -1, {acc(), ypow(pending)}); pending = 0; }
     // Peephole over the finished program: value = value*y + t, where t = a*b is the instruction just before and nothing else reads t, becomes
     // acc = acc*y + a*b with ONE Montgomery reduction (M_FOLD2, Field::mul2_add): 192 limb products instead of 256 on each of the ~90 folds of a row.
     void fuse_folds_pass() {
@@ -466,7 +361,7 @@ struct Builder {
         for (auto& v : ins) for (int i = 0; i < v.nsrc; i++) if (v.vsrc[i] >= 0) uses[v.vsrc[i]]++;
         std::vector<VIns> out;
         for (auto& v : ins) {
-            const bool is_fold = v.op == M_MULADD && v.dst < 0 && v.nsrc == 3 && (v.src[0] >> 28) == K_ACC && v.src[1] == enc(K_CONST, P.c_y) &&
+            const bool is_fold = v.op == M_MULADD && v.dst < 0 && v.nsrc == 3 && (v.src[0] >> 28) == K_ACC && is_ypow(v.src[1]) &&
                                  (v.src[2] >> 28) == K_SLOT && v.vsrc[2] >= 0;
             if (is_fold && !out.empty() && out.back().op == M_MUL && out.back().dst == v.vsrc[2] && uses[v.vsrc[2]] == 1 &&
                 (out.back().src[0] >> 28) != K_ACC && (out.back().src[1] >> 28) != K_ACC) {
@@ -474,7 +369,7 @@ struct Builder {
                 out.pop_back();
                 VIns f; f.op = M_FOLD2; f.dst = -1; f.nsrc = 3;
                 f.src[0] = m.src[0]; f.vsrc[0] = m.vsrc[0]; f.src[1] = m.src[1]; f.vsrc[1] = m.vsrc[1];
-                f.src[2] = enc(K_CONST, P.c_y); f.vsrc[2] = -1;
+                f.src[2] = v.src[1]; f.vsrc[2] = -1;
                 out.push_back(f);
             } else out.push_back(v);
         }
@@ -485,56 +380,9 @@ struct Builder {
 
 }  // namespace
 
-// Static bound analysis of a finished micro-program for the 29-bit-limb interpreter (quotient29_kernel): bounds in multiples of p, rounded up.
-//   column 32 (the shifted limb conversion), constant 1, X power 8;  product a b / 151 + 1;  sum a + b;  a - b + K p -> a + K with K = 2^(class + 1) >= b + 1.
-// A result above 128 is flagged for reduce_small (-> 3), so a subtrahend never needs K above 256.  The pass cannot fail on a program the 32-bit interpreter accepts except by running out of bias classes
-// (a subtrahend above 1023 p, which the reduce flag rules out); it then leaves code29 empty and the program runs on the 32-bit interpreter.
-static void bound29_pass(QuotProgram& P) {
-    P.code29.clear();
-    std::vector<double> slot(P.n_slots + 1, 0.0);
-    double acc = 0.0;
-    auto bound_of = [&](uint32_t src) -> double {
-        const uint32_t kind = src >> 28, pay = src & 0x0fffffffu;
-        switch (kind) {
-            case K_SLOT: return pay < slot.size() ? slot[pay] : 1e9;
-            case K_CONST: return 1.0;
-            case K_COL: return 32.0;
-            case K_ACC: return acc;
-            case K_XPOW: return 8.0;
-            default: return 0.0;
-        }
-    };
-    auto prod = [](double a, double b) { return a * b / 151.0 + 1.0; };
-    std::vector<uint4> out;
-    for (const uint4& ins : P.code) {
-        const uint32_t op = ins.x & 0xffu;
-        const double a = bound_of(ins.y), b = bound_of(ins.z), c = bound_of(ins.w);
-        double r = a;
-        uint32_t cls = 0;
-        auto class_for = [&](double sub) { uint32_t k = 0; while ((double)(2u << k) < sub + 1.0 && k < 10) k++; return k; };
-        switch (op) {
-            case M_ADD: r = a + b; break;
-            case M_SUB: cls = class_for(b); r = a + (double)(2u << cls); break;
-            case M_MUL: r = prod(a, b); break;
-            case M_SQR: r = prod(a, a); break;
-            case M_DBL: r = 2 * a; break;
-            case M_NEG: cls = class_for(a); r = (double)(2u << cls); break;
-            case M_MULADD: r = prod(a, b) + c; break;
-            case M_FOLD2: r = (acc * c + a * b) / 151.0 + 1.0; break;
-            default: r = a; break;
-        }
-        if (cls > 7) return;                                          // K above 256: no bias class (top limbs would crowd 32 bits): stay on the 32-bit interpreter
-        uint32_t w0 = ins.x | (cls << 9);
-        if (r > 128.0) { w0 |= 1u << 13; r = 3.0; }
-        if ((ins.x >> 8) & 1u) acc = r;
-        else { const uint32_t sl = ins.x >> 16; if (sl < slot.size()) slot[sl] = r; }
-        out.push_back(make_uint4(w0, ins.y, ins.z, ins.w));
-    }
-    if (acc > 140.0) return;                                          // (the last product with 2^256 mod p must return below 2 p)
-    P.code29.swap(out);
-}
+constexpr uint32_t SPLIT_LOW_DEGREE = 3;     // identities up to this degree form the low part: their share of h(X) has degree below 2 n — two cosets
 
-static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, QuotProgram& P) {
+static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, QuotProgram& P, int mode = 0) {
     Reader r{words, nwords};
     if (r.get() != 0x31514B5Au) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: bad magic");
     P.k = r.get(); P.ek = r.get(); P.n_fixed = r.get(); P.n_advice = r.get(); P.n_instance = r.get(); P.n_challenges = r.get();
@@ -579,16 +427,18 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
     P.c_chal = ci; ci += P.n_challenges;
     P.c_beta = ci++; P.c_gamma = ci++; P.c_theta = ci++; P.c_y = ci++;
     P.c_delta = ci; ci += P.n_perm_cols;
+    P.c_ypow = ci;                               // y^e constants follow as the folds ask for them; n_consts is final after the last fold
     P.n_consts = ci;
 
-    Builder B(P);
+    Builder B(P, mode, SPLIT_LOW_DEGREE);
     // ---- graphs -------------------------------------------------------------------------------
     // Demand-driven emission: a calculation is emitted right before its first use (depth-first from
     // the graph's result), so e.g. the gate polynomials of halo2's final Horner(previous, gates, y)
     // are produced one at a time instead of all being live at once.  Unreachable calculations vanish.
-    auto run_graph = [&](const Graph& g, uint32_t cbase, bool prev_is_acc, int* result_vreg) -> int {
+    auto run_graph = [&](const Graph& g, uint32_t cbase, bool prev_is_acc, int* result_vreg, uint32_t* result_degree) -> int {
         const size_t nc = g.calcs.size();
         *result_vreg = -1;
+        *result_degree = 0;
         if (nc == 0) return ZK_OK;
         // resolve Intermediate(t) operands to the calculation that last wrote t before the reader
         std::vector<int> writer(g.num_intermediates, -1);
@@ -625,6 +475,29 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
             }
             writer[g.calcs[i].target] = (int)i;
         }
+        // degree of every calculation as a polynomial in the columns (a column query 1; constants, challenges, beta / gamma / theta / y and the previous value 0)
+        std::vector<uint32_t> cdeg(nc, 0);
+        auto leaf_deg = [](const VSrc& sv) -> uint32_t { return (sv.kind == VS_FIXED || sv.kind == VS_ADVICE || sv.kind == VS_INSTANCE) ? 1u : 0u; };
+        for (size_t i = 0; i < nc; i++) {
+            const Calc& k = g.calcs[i];
+            const std::vector<const VSrc*> ops = operands_of(k);
+            auto od = [&](size_t oi) -> uint32_t { return dep[i][oi] >= 0 ? cdeg[dep[i][oi]] : leaf_deg(*ops[oi]); };
+            uint32_t dg = od(0);
+            switch (k.op) {
+                case OP_ADD: case OP_SUB: dg = std::max(od(0), od(1)); break;
+                case OP_MUL: dg = od(0) + od(1); break;
+                case OP_SQUARE: dg = 2 * od(0); break;
+                case OP_HORNER: {
+                    const uint32_t np = (uint32_t)k.parts.size(), f = od(1);
+                    dg = od(0) + np * f;
+                    for (uint32_t pi = 0; pi < np; pi++) dg = std::max(dg, od(2 + pi) + (np - 1 - pi) * f);
+                    break;
+                }
+                default: break;                                        // DOUBLE, NEGATE, STORE: the operand's
+            }
+            cdeg[i] = std::min(dg, 1u << 16);
+        }
+        *result_degree = cdeg[nc - 1];
         // Store(column | constant | challenge) — what halo2's add_expression emits for every query — is an ALIAS here: its readers
         // take the memory operand directly (one more 32-byte load per use) instead of parking the value in a slot from its first
         // to its last use; with CSE'd selectors and rotations shared between gates those slots are what limits occupancy.
@@ -726,7 +599,7 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
                         // halo2's custom-gate evaluator ends in Horner(PreviousValue, gates, y): when that is the graph's result and the previous value IS the
                         // accumulator, every step is a fold of the accumulator itself (and fuses with the gate's last product, Builder::fold)
                         const bool in_acc = prev_is_acc && ci == (int)nc - 1 && d[0] < 0 && k.s0.kind == VS_PREV && d[1] < 0 && k.s1.kind == VS_Y && prev_reads == 1;
-                        if (in_acc) { B.fold(opnd_at(oi)); horner_cur[ci] = -2; }
+                        if (in_acc) { B.fold(opnd_at(oi), d[oi] >= 0 ? cdeg[d[oi]] : leaf_deg(k.parts[oi - 2])); horner_cur[ci] = -2; }
                         else if (zero_start) {
                             if (d[oi] >= 0 && !is_alias[d[oi]]) horner_cur[ci] = vreg[d[oi]];
                             else horner_first[ci] = (int)oi;
@@ -748,9 +621,11 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         return ZK_OK;
     };
     int res = -1;
-    int rc = run_graph(custom, gbase[0], true, &res);
+    uint32_t res_deg = 0;
+    int rc = run_graph(custom, gbase[0], true, &res, &res_deg);
     if (rc) return rc;
-    if (res >= 0) B.emit(M_MOV, -1, {B.slot(res)});
+    // (a custom-gate graph that does not end in halo2's Horner(previous, gates, y) arrives as ONE value: it counts as one identity of the high part)
+    if (res >= 0 && mode != 2) { B.emit(M_MOV, -1, {B.slot(res)}); P.folds_taken++; }
     else if (res != -2) B.emit(M_MOV, -1, {B.cst(P.c_zero)});   // no custom gates: value = 0 (GraphEvaluator returns zero); -2: the folds left it in the accumulator
 
     const Builder::Opnd one = B.cst(P.c_one), beta = B.cst(P.c_beta), gamma = B.cst(P.c_gamma);
@@ -761,15 +636,15 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         auto z = [&](uint32_t s, int32_t rot) { return B.col(P.col_z + s, rot); };
         int t = B.tmp(M_SUB, {one, z(0, 0)});
         t = B.tmp(M_MUL, {B.slot(t), l0});
-        B.fold(B.slot(t));
+        B.fold(B.slot(t), 2);
         t = B.tmp(M_SQR, {z(P.n_sets - 1, 0)});
         t = B.tmp(M_SUB, {B.slot(t), z(P.n_sets - 1, 0)});
         t = B.tmp(M_MUL, {B.slot(t), llast});
-        B.fold(B.slot(t));
+        B.fold(B.slot(t), 3);
         for (uint32_t s = 1; s < P.n_sets; s++) {
             t = B.tmp(M_SUB, {z(s, 0), z(s - 1, last_rot)});
             t = B.tmp(M_MUL, {B.slot(t), l0});
-            B.fold(B.slot(t));
+            B.fold(B.slot(t), 2);
         }
         for (uint32_t s = 0; s < P.n_sets; s++) {
             const uint32_t c0 = s * chunk_len, c1 = std::min(c0 + chunk_len, P.n_perm_cols);
@@ -795,14 +670,16 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
             }
             t = B.tmp(M_SUB, {B.slot(left), B.slot(right)});
             t = B.tmp(M_MUL, {B.slot(t), lact});
-            B.fold(B.slot(t));
+            B.fold(B.slot(t), 2 + (c1 - c0));                          // l_active * z * one degree-1 factor per column of the set
         }
     }
     // ---- lookup arguments ----------------------------------------------------------------------
     for (uint32_t n = 0; n < P.n_lookups; n++) {
         int tv = -1;
-        rc = run_graph(lookups[n], gbase[1 + n], false, &tv);
+        uint32_t tv_deg = 0;
+        rc = run_graph(lookups[n], gbase[1 + n], false, &tv, &tv_deg);
         if (rc) return rc;
+        if (tv < 0) tv_deg = 0;
         const Builder::Opnd table_value = tv >= 0 ? B.slot(tv) : B.cst(P.c_zero);
         auto zc = [&](int32_t rot) { return B.col(P.col_lk_z + n, rot); };
         auto ac = [&](int32_t rot) { return B.col(P.col_lk_a + n, rot); };
@@ -810,11 +687,11 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         int ams = B.tmp(M_SUB, {ac(0), sc});
         int t = B.tmp(M_SUB, {one, zc(0)});
         t = B.tmp(M_MUL, {B.slot(t), l0});
-        B.fold(B.slot(t));
+        B.fold(B.slot(t), 2);
         t = B.tmp(M_SQR, {zc(0)});
         t = B.tmp(M_SUB, {B.slot(t), zc(0)});
         t = B.tmp(M_MUL, {B.slot(t), llast});
-        B.fold(B.slot(t));
+        B.fold(B.slot(t), 3);
         t = B.tmp(M_ADD, {ac(0), beta});
         int u = B.tmp(M_ADD, {sc, gamma});
         t = B.tmp(M_MUL, {B.slot(t), B.slot(u)});
@@ -822,14 +699,16 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         u = B.tmp(M_MUL, {zc(0), table_value});
         t = B.tmp(M_SUB, {B.slot(t), B.slot(u)});
         t = B.tmp(M_MUL, {B.slot(t), lact});
-        B.fold(B.slot(t));
+        B.fold(B.slot(t), 1 + std::max(3u, 1 + tv_deg));             // l_active * (z(wX) (A' + beta) (S' + gamma) - z * (compressed input + beta) (compressed table + gamma))
         t = B.tmp(M_MUL, {B.slot(ams), l0});
-        B.fold(B.slot(t));
+        B.fold(B.slot(t), 2);
         t = B.tmp(M_SUB, {ac(0), ac(-1)});
         t = B.tmp(M_MUL, {B.slot(t), B.slot(ams)});
         t = B.tmp(M_MUL, {B.slot(t), lact});
-        B.fold(B.slot(t));
+        B.fold(B.slot(t), 3);
     }
+    B.flush_pending();
+    P.n_consts = P.c_ypow + (uint32_t)P.ypow_exps.size();
     if (P.rotations.size() > 255) return ctx->fail(ZK_ERR_LIMIT, "quotient program: more than 255 distinct rotations");
 
     B.fuse_folds_pass();
@@ -882,7 +761,6 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
         P.code.push_back(make_uint4(w0, w[0], w[1], w[2]));
     }
     P.n_slots = n_slots ? n_slots : 1;
-    bound29_pass(P);
     return ZK_OK;
 }
 
@@ -896,13 +774,23 @@ int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* p
     if (rc) return rc;
     if ((size_t)(P->n_slots > QUOT_NREG ? P->n_slots - QUOT_NREG : 0) * 64 * 32 > 160 * 1024)
         return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %u live intermediates; this build keeps at most 80 in LDS", P->n_slots);
-    hipError_t e = hipMalloc(&P->d_code, P->code.size() * 16 + 16);
-    if (e == hipSuccess) e = hipMemcpy(P->d_code, P->code.data(), P->code.size() * 16, hipMemcpyHostToDevice);
-    if (e == hipSuccess && !P->code29.empty()) {
-        e = hipMalloc(&P->d_code29, P->code29.size() * 16 + 16);
-        if (e == hipSuccess) e = hipMemcpy(P->d_code29, P->code29.data(), P->code29.size() * 16, hipMemcpyHostToDevice);
+    auto upload = [&](QuotProgram& Q) -> bool {
+        hipError_t e = hipMalloc(&Q.d_code, Q.code.size() * 16 + 16);
+        if (e == hipSuccess) e = hipMemcpy(Q.d_code, Q.code.data(), Q.code.size() * 16, hipMemcpyHostToDevice);
+        return e == hipSuccess;
+    };
+    if (!upload(*P)) return ctx->fail(ZK_ERR_HIP, "zk_quotient_program_load: device allocation failed");
+    // the same program by degree (QuotProgram::part_hi / part_lo): worth it when the extended domain has at least four cosets' worth of rows per low-part coset pair,
+    // i.e. cs_degree >= 4, and both parts hold identities
+    if (ctx->tune.quot_degree_split && P->degree > SPLIT_LOW_DEGREE && P->ek > P->k) {
+        std::shared_ptr<QuotProgram> hi(new QuotProgram()), lo(new QuotProgram());
+        hi->device = lo->device = ctx->device;
+        if (compile_program(ctx, words.data(), words.size(), *hi, 1) == ZK_OK && compile_program(ctx, words.data(), words.size(), *lo, 2) == ZK_OK &&
+            hi->folds_taken && lo->folds_taken && hi->n_slots <= P->n_slots + 8 && lo->n_slots <= P->n_slots + 8) {
+            if (!upload(*hi) || !upload(*lo)) return ctx->fail(ZK_ERR_HIP, "zk_quotient_program_load: device allocation failed");
+            P->part_hi = hi; P->part_lo = lo;
+        }
     }
-    if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "zk_quotient_program_load: device allocation failed");
     *prog = ctx->next_handle++;
     ctx->programs[*prog] = P;
     return ZK_OK;
@@ -933,16 +821,29 @@ int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_
     return ZK_OK;
 }
 // counts[op] = instructions with opcode op (add, sub, mul, sqr, dbl, neg, mov, muladd), counts[8] = memory (column / constant) operands
-int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]) {
+int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t part, uint32_t counts[9]) {
     auto it = ctx->programs.find(prog);
-    if (it == ctx->programs.end() || !counts) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_opmix: unknown program / null pointer");
+    if (it == ctx->programs.end() || !counts || part > 2) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_opmix: unknown program / null pointer / part");
+    if (part && (!it->second->part_hi || !it->second->part_lo)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_part_opmix: the program has no degree split");
     for (int i = 0; i < 9; i++) counts[i] = 0;
-    for (const uint4& ins : it->second->code) {
+    const QuotProgram& Q = part == 1 ? *it->second->part_hi : part == 2 ? *it->second->part_lo : *it->second;
+    for (const uint4& ins : Q.code) {
         const uint32_t op = ins.x & 0xffu;
         if (op < 8) counts[op]++;
         else if (op == M_FOLD2) counts[M_MULADD]++;        // a fused fold is a multiply-add (two products, one reduction)
         for (uint32_t src : {ins.y, ins.z, ins.w}) { const uint32_t kind = src >> 28; if (kind == K_COL || kind == K_CONST) counts[8]++; }
     }
+    return ZK_OK;
+}
+// the degree split of a program (QuotProgram::part_hi / part_lo): how many cosets its low part is evaluated on (0: the program has none) and the sizes of the two parts
+int quotient_program_split(zk_ctx* ctx, uint64_t prog, uint32_t* low_cosets, uint32_t* n_instr_high, uint32_t* n_instr_low) {
+    auto it = ctx->programs.find(prog);
+    if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_split: unknown program");
+    const QuotProgram& P = *it->second;
+    const bool has = P.part_hi && P.part_lo;
+    if (low_cosets) *low_cosets = has ? SPLIT_LOW_DEGREE - 1 : 0;
+    if (n_instr_high) *n_instr_high = has ? (uint32_t)P.part_hi->code.size() : 0;
+    if (n_instr_low) *n_instr_low = has ? (uint32_t)P.part_lo->code.size() : 0;
     return ZK_OK;
 }
 int quotient_program_release(zk_ctx* ctx, uint64_t prog) {
@@ -957,9 +858,7 @@ void release_programs(zk_ctx* ctx) {
 
 int quotient_set_lds_attr() {
 #ifndef ZK_EMU
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient29_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(quotient_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
     return 0;
 }
@@ -969,10 +868,16 @@ int quotient_set_lds_attr() {
 // independent, which is what lets a proof's quotient be split over GPUs: out receives the n numerator values of the coset.
 // row_count > 0: only rows [row_lo, row_lo + row_count) of that domain (the columns are complete, so rotations need no halo), out[i] = row row_lo + i —
 // the unit that lets more ranks than cosets share a quotient.
-int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int coset, uint64_t row_lo, uint64_t row_count) {
+// part: 0 = every identity; 1 / 2 = the high / low part of a program that has a degree split (QuotProgram::part_hi / part_lo).  low_cosets > 0 (part 2, coset < 0): the
+// columns are the whole extended domain but only the rows of its cosets 0 .. low_cosets-1 are evaluated — thread i of coset j reads row i * 2^(ek-k) + j — and
+// out receives low_cosets x n values, coset-major (what zk_cosets_to_pieces_dev takes).
+int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int coset, uint64_t row_lo, uint64_t row_count, int part, uint32_t low_cosets) {
     auto it = ctx->programs.find(prog);
     if (it == ctx->programs.end()) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_dev: unknown program %llu", (unsigned long long)prog);
-    QuotProgram& P = *it->second;
+    if (part && (!it->second->part_hi || !it->second->part_lo)) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_part_dev: program %llu has no degree split (zk_quotient_program_split)", (unsigned long long)prog);
+    QuotProgram& P = part == 1 ? *it->second->part_hi : part == 2 ? *it->second->part_lo : *it->second;
+    if (low_cosets && (part != 2 || coset >= 0 || row_count || (low_cosets & (low_cosets - 1)) || low_cosets > (1u << (P.ek - P.k))))
+        return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_low_dev: %u cosets of the extended domain: a power of two, at most 2^(extended_k - k), low part only", low_cosets);
     if (!a || !a->out || !a->l0 || !a->l_last || !a->l_active_row || !a->beta || !a->gamma || !a->theta || !a->y)
         return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_dev: null argument");
     if (a->n_sets != P.n_sets) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_dev: n_sets = %u but the program has %u permutation sets", a->n_sets, P.n_sets);
@@ -1000,20 +905,17 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
     for (uint32_t i = 0; i < P.n_challenges; i++) consts[P.c_chal + i] = rd((const char*)a->challenges + 32 * i);
     const u256 beta = rd(a->beta);
     consts[P.c_beta] = beta; consts[P.c_gamma] = rd(a->gamma); consts[P.c_theta] = rd(a->theta); consts[P.c_y] = rd(a->y);
+    for (size_t i = 0; i < P.ypow_exps.size(); i++) {                 // y^e for the folds that follow skipped identities (square and multiply on the host: a few dozen products)
+        u256 acc = Fr::one(), base = consts[P.c_y];
+        for (uint32_t e = P.ypow_exps[i]; e; e >>= 1) { if (e & 1) acc = Fr::mul(acc, base); base = Fr::sqr(base); }
+        consts[P.c_ypow + i] = acc;
+    }
     {   // delta_j = beta * ZETA * DELTA^j  (current_delta of evaluate_h without the omega^idx factor)
         const uint64_t zl[4] = BN254_FR_ZETA_M, dl[4] = BN254_FR_DELTA_M;
         u256 zeta, delta;
         for (int i = 0; i < 8; i++) { zeta.v[i] = (uint32_t)(zl[i >> 1] >> (32 * (i & 1))); delta.v[i] = (uint32_t)(dl[i >> 1] >> (32 * (i & 1))); }
         u256 cur = Fr::mul(beta, zeta);
         for (uint32_t j = 0; j < P.n_perm_cols; j++) { consts[P.c_delta + j] = cur; cur = Fr::mul(cur, delta); }
-    }
-    // the 29-bit-limb interpreter (tune quot_limb29) takes the run's constants as x * 2^261 mod p: the whole table times 32
-    const bool l29 = ctx->tune.quot_limb29 && P.d_code29 && ctx->tune.quot_rows < 2;
-    if (l29) {
-        u256 c32 = Fr::zero();
-        c32.v[0] = 32;
-        c32 = Fr::to_mont(c32);
-        for (auto& cst : consts) cst = Fr::mul(cst, c32);
     }
     if (coset >= (int)(1u << (P.ek - P.k))) return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_dev: coset %d out of range", coset);
     const bool cm = coset >= 0;
@@ -1038,7 +940,7 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
     ZK_HIP(hipMemcpyAsync(d_rot, rot_off.data(), rot_off.size() * 4, hipMemcpyHostToDevice, st));
     QuotArgs q;
     memset(&q, 0, sizeof q);
-    q.code = (const uint4*)(l29 ? P.d_code29 : P.d_code); q.n_instr = (uint32_t)P.code.size(); q.consts = d_consts;
+    q.code = (const uint4*)P.d_code; q.n_instr = (uint32_t)P.code.size(); q.consts = d_consts;
     q.cols = (const void* const*)d_cols; q.rot_off = (const uint32_t*)d_rot; q.size_log = size_log; q.out = a->out;
     q.uses_xpow = P.uses_xpow ? 1 : 0;
     q.xpow_mul = cm ? 1u << (P.ek - P.k) : 1u;
@@ -1048,6 +950,12 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
         if (rc) return rc;
     }
     uint64_t rows = size;
+    if (low_cosets) {
+        rows = (uint64_t)low_cosets << P.k;
+        q.sub_log = 0;
+        while ((1u << q.sub_log) < low_cosets) q.sub_log++;
+        q.stride_log = P.ek - P.k; q.k_log = P.k; q.strided = 1;
+    }
     if (row_count) {
         if (row_lo + row_count > size || (row_count & (row_count - 1)) || row_lo % row_count)
             return ctx->fail(ZK_ERR_ARG, "zk_quotient_run_coset_rows_dev: rows [%llu, +%llu) must be an aligned power-of-two slice of the %llu rows",
@@ -1060,18 +968,15 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
     const uint32_t lds_slots = P.n_slots > QUOT_NREG ? P.n_slots - QUOT_NREG : 0;
     while (T > 64 && (size_t)lds_slots * T * 32 > 32 * 1024) T >>= 1;
     if (T < 1) T = 1;
-    const uint32_t NR = (!l29 && ctx->tune.quot_rows >= 2 && rows % ((size_t)T * 2) == 0) ? 2u : 1u;      // rows per thread
-    const size_t lds = l29 ? (size_t)lds_slots * T * 36 + 16 : (size_t)lds_slots * T * 32 * NR;
-    q.lds_slots = lds_slots;
+    const size_t lds = (size_t)lds_slots * T * 32;
     if (lds > 160 * 1024) return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %zu bytes of LDS", lds);
     EvTimer tq(ctx, "quotient");
-    if (l29) { ZK_LAUNCH(quotient29_kernel, (uint32_t)(rows / T), T, lds, st, q); if (ctx->timing) ctx->last_ms["quotient29_launches"] += 1.0; }
-    else if (NR == 2) { ZK_LAUNCH(quotient_kernel<2>, (uint32_t)(rows / T / 2), T, lds, st, q); }
-    else { ZK_LAUNCH(quotient_kernel<1>, (uint32_t)(rows / T), T, lds, st, q); }
+    ZK_LAUNCH(quotient_kernel, (uint32_t)(rows / T), T, lds, st, q);
     ZK_CHECK_LAUNCH();
     tq.stop();
     ZK_HIP(hipStreamSynchronize(st));
     tq.resolve();
+    if (ctx->timing) ctx->last_ms["quotient_alg_bytes"] += (double)rows * (P.n_cols + 1) * 32.0;   // every column once + the output, per row
     return ZK_OK;
 }
 
@@ -1217,7 +1122,7 @@ int evaluate_h_host(zk_ctx* ctx, uint64_t pkh, const void* const* advice, const 
     qa.lookup_product = dyn + P.n_advice + P.n_instance + P.n_sets;
     qa.lookup_input = qa.lookup_product + P.n_lookups; qa.lookup_table = qa.lookup_input + P.n_lookups;
     qa.challenges = challenges; qa.beta = beta; qa.gamma = gamma; qa.theta = theta; qa.y = y; qa.out = pk->h_ext;
-    int rc = quotient_run(ctx, pk->prog, &qa, -1, 0, 0);
+    int rc = quotient_run(ctx, pk->prog, &qa, -1, 0, 0, 0, 0);
     if (rc) return rc;
     size_t out_bytes = (size_t)32 << P.ek;
     if (finish) {

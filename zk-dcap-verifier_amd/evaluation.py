@@ -126,15 +126,18 @@ class Evaluator:
         return self
 
     def evaluate_h(self, *, fixed, advice, instance, l0, l_last, l_active_row, perm_cosets, perm_products,
-                   lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out, coset: int | None = None, rows: tuple | None = None):
+                   lookup_product, lookup_input, lookup_table, challenges, beta, gamma, theta, y, out, coset: int | None = None, rows: tuple | None = None,
+                   part: int = 0, low_cosets: int = 0):
         """All columns are device buffers holding 2^extended_k Fr values (extended cosets);
         `out` receives the numerator of h(X) on the extended coset (before divide_by_vanishing_poly).  With `coset = j` every column holds the
         2^k values of coset j only (coeff_to_coset) and `out` that coset's numerator values — the unit a multi-GPU prover shards by;
-        `rows = (lo, count)` restricts the run to that aligned power-of-two slice of the coset's rows (ranks that share a coset)."""
+        `rows = (lo, count)` restricts the run to that aligned power-of-two slice of the coset's rows (ranks that share a coset).
+        `part` = 1 / 2: only the identities of degree above / up to 3 of a program that carries the degree split (Backend.quotient_program_split; include/zkmi355.h);
+        part 2 with `low_cosets` evaluates them on the rows of cosets 0 .. low_cosets-1 of extended-layout columns, `out` coset-major."""
         self.backend.quotient_run_dev(self.handle, fixed=fixed, advice=advice, instance=instance, l0=l0, l_last=l_last,
                                       l_active_row=l_active_row, perm_cosets=perm_cosets, perm_products=perm_products,
                                       lookup_product=lookup_product, lookup_input=lookup_input, lookup_table=lookup_table,
-                                      challenges=challenges, beta=beta, gamma=gamma, theta=theta, y=y, out=out, coset=coset, rows=rows)
+                                      challenges=challenges, beta=beta, gamma=gamma, theta=theta, y=y, out=out, coset=coset, rows=rows, part=part, low_cosets=low_cosets)
 
     # -- the shape of halo2's own call: polynomials in, polynomial out -----------------------------------
     def load_pk(self, fixed, sigma, l0, l_last, l_active_row, extended: bool = False) -> int:

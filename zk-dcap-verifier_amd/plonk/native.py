@@ -79,7 +79,7 @@ class NativeProver:
 
     TRANSCRIPTS = {"blake2b": 0, "poseidon": 1, "evm": 2}
 
-    def __init__(self, params: ParamsKZG, pk: ProvingKey, transcript: str = "blake2b", draw_schedule: int = 1, exchange=None):
+    def __init__(self, params: ParamsKZG, pk: ProvingKey, transcript: str = "blake2b", exchange=None):
         """exchange (sharded params only): the ranks' collective — an object with `all_gather(send_ptr, recv_ptr, nbytes)` and, optionally, the device
         buffers `send` / `recv` / `cap` the library should exchange through (TorchExchange above); every rank must prove with the same witness and rng stream."""
         assert (params.world == 1) == (pk.coset_parts is None or pk.pieces_from_cosets), "a sharded SRS goes with a proving key built on it (keygen(params.sharded(..)))"
@@ -156,7 +156,7 @@ class NativeProver:
                 d.xchg_send, d.xchg_recv, d.xchg_cap = exchange.send.data_ptr(), exchange.recv.data_ptr(), exchange.cap
         d.transcript_repr = repr_bytes.ctypes.data
         d.transcript = self.TRANSCRIPTS[transcript]         # which Fiat-Shamir transcript / proof encoding (zk_plonk_pk_desc.transcript)
-        d.draw_schedule = draw_schedule                     # 1: halo2's order of Fr::random draws; 0: rounds 1-2 of this repo (prover.py draw_plan)
+        d.draw_schedule = 1                                 # halo2_proofs v2023_01_20's order of Fr::random draws (prover.py draw_plan): the only schedule the library knows
         self.desc = d
         self.proof_cap = (64 if transcript == "evm" else 32) * (cs.num_advice_columns + 3 * len(cs.lookups) + len(cs.permutation_columns) + 16 +
                                len(aq) + len(fq) + 1 + len(cs.permutation_columns) + 3 * len(cs.permutation_columns) + 5 * len(cs.lookups) + 8)

@@ -39,28 +39,20 @@ def rotate_omega(x: int, rot: int, k: int) -> int:
     return x * pow(w, rot % (1 << k), R_MOD) % R_MOD
 
 
-def draw_plan(n_advice: int, n_lookups: int, n_sets: int, n_pieces: int, n: int, bf: int, schedule: int = 1):
+def draw_plan(n_advice: int, n_lookups: int, n_sets: int, n_pieces: int, n: int, bf: int):
     """The order in which create_proof consumes the caller's `&mut rng`, as a list of (purpose, index, count of Fr::random draws, squeeze) items; `squeeze` names the
     challenge squeezed AFTER the item's phase (the item is drawn before that squeeze happens in halo2) — tests/test_rust_vectors.py compares the running totals
-    with the Rust prover's counting RNG.  schedule 1 = halo2_proofs v2023_01_20 draw by draw ([3P-MEM]; include/zkmi355.h zk_rng_fn lists the source files):
-    every commitment also draws one Blind(Fr::random) that KZG discards ("blind" items).  schedule 0 = rounds 1-2 of this repo (no Blind draws, all lookups' input
-    rows before all table rows).  csrc/prover.hip builds the same plan."""
-    assert schedule in (0, 1)
-    up = schedule == 1
+    with the Rust prover's counting RNG.  This is halo2_proofs v2023_01_20 (PSE; stack A of the reference) draw by draw ([3P-MEM]; include/zkmi355.h zk_rng_fn lists
+    the source files): every commitment also draws one Blind(Fr::random) that KZG discards ("blind" items).  csrc/prover.hip builds the same plan (draw_schedule 1)."""
     plan = [("advice", i, bf + 1, "theta") for i in range(n_advice)]      # rows [usable_rows, n): the bf blinding rows and the one after
-    if up:
-        plan += [("blind", None, 1, "theta")] * n_advice
-        for l in range(n_lookups):
-            plan += [("bi", l, bf + 1, "beta"), ("bt", l, bf + 1, "beta"), ("blind", None, 1, "beta"), ("blind", None, 1, "beta")]
-    else:
-        plan += [("bi", l, bf + 1, "beta") for l in range(n_lookups)] + [("bt", l, bf + 1, "beta") for l in range(n_lookups)]
-    for s in range(n_sets):
-        plan += [("perm_blind", s, bf, "y")] + ([("blind", None, 1, "y")] if up else [])
+    plan += [("blind", None, 1, "theta")] * n_advice
     for l in range(n_lookups):
-        plan += [("lookup_blind", l, bf, "y")] + ([("blind", None, 1, "y")] if up else [])
-    plan.append(("random_poly", 0, n, "y"))
-    if up:
-        plan += [("blind", None, 1, "y")] + [("blind", None, 1, "x")] * n_pieces
+        plan += [("bi", l, bf + 1, "beta"), ("bt", l, bf + 1, "beta"), ("blind", None, 1, "beta"), ("blind", None, 1, "beta")]
+    for s in range(n_sets):
+        plan += [("perm_blind", s, bf, "y"), ("blind", None, 1, "y")]
+    for l in range(n_lookups):
+        plan += [("lookup_blind", l, bf, "y"), ("blind", None, 1, "y")]
+    plan += [("random_poly", 0, n, "y"), ("blind", None, 1, "y")] + [("blind", None, 1, "x")] * n_pieces
     return plan
 
 
@@ -75,7 +67,7 @@ class _Joiner:
 
 
 def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances: Sequence[Sequence[int]], rng: np.random.Generator, transcript,
-                 timings: Optional[dict] = None, capture: Optional[dict] = None, draw_schedule: int = 1) -> dict:
+                 timings: Optional[dict] = None, capture: Optional[dict] = None) -> dict:
     """advice: cs.num_advice_columns columns of n rows — (n, 4) uint64 Montgomery host arrays or device buffers; rows past
     `usable_rows` are overwritten with blinding and device buffers are consumed (they hold coefficients afterwards).  instances:
     canonical ints per instance column.  Writes the proof into `transcript` and returns bookkeeping for tests / benches
@@ -84,13 +76,13 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     copies of the proof's committed Lagrange columns and challenges, so that a driver of the per-call host-buffer entry points can replay them."""
     owned: List = []
     try:
-        return _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture, draw_schedule)
+        return _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture)
     finally:
         for d in owned:
             d.free()
 
 
-def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture=None, draw_schedule=1) -> dict:
+def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture=None) -> dict:
     be, cs, k, n = pk.backend, pk.vk.cs, params.k, params.n
     dom = pk.domain
     ek, en = dom.extended_k, dom.extended_n
@@ -141,7 +133,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     # hence the proof — is the same), while the GPU commits the advice columns; a phase waits only for its own items.
     chunk = cs.permutation_chunk_len()
     n_sets = (len(cs.permutation_columns) + chunk - 1) // chunk if cs.permutation_columns else 0
-    plan = draw_plan(len(advice), L, n_sets, dom.quotient_poly_degree, n, bf, draw_schedule)
+    plan = draw_plan(len(advice), L, n_sets, dom.quotient_poly_degree, n, bf)
     blinds = [rand_fr_array(rng, cnt) for _, _, cnt, _ in plan[:len(advice)]]
     if advice:
         be.upload_columns([d.ptr + usable * 32 for d in adv_values], blinds, (n - usable) * 32)

@@ -60,10 +60,12 @@ typedef struct {
     const zk_plonk_pk_host* host; const void* g; const void* g_lagrange; size_t n;
     const void** advice; const void** inst; const uint32_t* inst_len;
     stream st; const unsigned char* want; size_t want_len; int ok;
+    int gathers;                                                     /* calls of the collective this rank made (the same on every rank: 7 commitment phases + the numerators) */
 } rank_job;
 static int gather(void* user, const void* send_dev, void* recv_dev, size_t bytes) {
     rank_job* j = (rank_job*)user;
     fabric* f = j->fab;
+    j->gathers++;
     f->send[j->rank] = send_dev;
     pthread_barrier_wait(&f->bar);                                   /* every rank's send buffer is complete and published */
     int rc = 0;
@@ -214,12 +216,13 @@ int main(int argc, char** argv) {
             apply_tune(ctx);
             rank_job* j = &jobs[r];
             j->fab = &fab; j->rank = r; j->host = &host; j->g = g; j->g_lagrange = g_lagrange; j->n = n;
-            j->advice = advice; j->inst = inst; j->inst_len = inst_len; j->st = st; j->st.at = 0; j->want = want; j->want_len = want_len; j->ok = 0;
+            j->advice = advice; j->inst = inst; j->inst_len = inst_len; j->st = st; j->st.at = 0; j->want = want; j->want_len = want_len; j->ok = 0; j->gathers = 0;
         }
         for (int r = 0; r < W; r++) pthread_create(&th[r], NULL, rank_main, &jobs[r]);
         for (int r = 0; r < W; r++) pthread_join(th[r], NULL);
         for (int r = 0; r < W; r++) { if (!jobs[r].ok) { fprintf(stderr, "rank %d of %d: proof differs or failed\n", r, W); return 1; } zk_ctx_destroy(fab.ctx[r]); }
-        printf("%d ranks (sharded tables, sharded keys, all-gather callback): every rank emitted the expected bytes\n", W);
+        for (int r = 1; r < W; r++) if (jobs[r].gathers != jobs[0].gathers) { fprintf(stderr, "rank %d made %d all-gathers, rank 0 made %d\n", r, jobs[r].gathers, jobs[0].gathers); return 1; }
+        printf("%d ranks (sharded tables, sharded keys, all-gather callback): every rank emitted the expected bytes, %d all-gathers per proof\n", W, jobs[0].gathers);
     }
     printf("capi_prove OK\n");
     return 0;

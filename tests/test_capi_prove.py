@@ -39,7 +39,7 @@ def test_plain_c_prover_sharded_over_ranks_emulated(emu, orc, tmp_path, world):
     path = tmp_path / "pk.zkpk"
     path.write_bytes(dp.toy_blob(emu, 6, 7))
     r = _run("capi_prove_emu", path, EMU_TUNE, world)
-    assert r.returncode == 0 and f"{world} ranks" in r.stdout and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and f"{world} ranks" in r.stdout and "8 all-gathers per proof" in r.stdout and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_plain_c_prover_has_no_cpu_fallback(emu, orc, tmp_path):
@@ -62,3 +62,15 @@ def test_plain_c_prover_on_gpu(gpu, orc, tmp_path, which, k):
     path.write_bytes(blob)
     r = _run("capi_prove", path, world=4 if k <= 8 else None)       # then 4 ranks (4 contexts on the one GPU): a coset of the quotient each
     assert r.returncode == 0 and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_plain_c_prover_eight_ranks_on_gpu(gpu, orc, tmp_path):
+    """BASELINE configs[4]'s rank count on the one GPU a builder has: 8 contexts = 8 ranks of the plain-C prover at k = 12 with the sgx census, each with 1/8 of both SRS
+    tables and a sharded key; the quotient's units are HALF cosets (8 ranks, 4 cosets), every commitment phase one all-gather of 128-byte points, the numerators one more:
+    8 collectives per proof, every rank the single-GPU prover's bytes.  What an 8-GPU node adds to this is RCCL as the collective, nothing else."""
+    import dump_pk_blob as dp
+    path = tmp_path / "pk.zkpk"
+    path.write_bytes(dp.sgx_blob(gpu, 12, 3))
+    r = _run("capi_prove", path, world=8)
+    assert r.returncode == 0 and "8 ranks" in r.stdout and "8 all-gathers per proof" in r.stdout and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

@@ -292,3 +292,14 @@ def test_census_of_the_real_circuit_is_recorded():
     for key in ("k", "num_advice_columns", "num_fixed_columns", "lookups", "permutation_columns", "degree", "blinding_factors"):
         assert key in cs
     print("real sgx_dcap_verifier census:", cs)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(DIR, "kzg_bn254_19.srs")), reason="no Rust-written SRS under tests/golden/rust (params/kzg_bn254_19.srs of a `cargo test` of the reference)")
+def test_srs_file_equals_the_one_gen_srs_writes():
+    """circuits/src/sgx_dcap_verifier.rs:799 `gen_srs(19)` caches params/kzg_bn254_19.srs: its G1 part must hash to tests/golden/srs_kat.json (this repo's ParamsKZG.setup + write
+    on the GPU with the re-derived trapdoor: tools/gen_srs_kat.py) — pins gen_srs's seed, Fr::from_u512, setup's powers, g_to_lagrange and the point encoding at once."""
+    import hashlib
+    kat = json.load(open(os.path.join(os.path.dirname(DIR), "srs_kat.json")))
+    data = open(os.path.join(DIR, "kzg_bn254_19.srs"), "rb").read()
+    assert data[:96].hex() == kat["first_96_bytes_hex"], "k / G / [tau] G differ: another seed or encoding"
+    assert len(data) == kat["bytes_g1_part"] + 128 and hashlib.sha256(data[:-128]).hexdigest() == kat["sha256_g1_part"]

@@ -90,3 +90,43 @@ def test_gpu_proof_bin_points_roundtrip(gpu):
 @pytest.mark.gpu
 def test_gpu_srs_file_roundtrip(gpu):
     _srs_roundtrip(gpu, 12)
+
+
+# ---- the SRS of the reference's own tests (halo2-lib gen_srs: ChaCha20, all-zero seed), as a known answer for the first machine with cargo -------------------------
+def _srs_kat():
+    import json
+    from conftest import ROOT
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "srs_kat.json")))
+
+
+def test_gen_srs_trapdoor_and_first_points_cpu(orc, pyref):
+    """tau of `gen_srs(k)` re-derived here (ChaCha20 block pinned by its published vector, Fr::from_u512 of the first 64 keystream bytes: tools/gen_srs_kat.py) is the
+    trapdoor SURVEY App. C.7 computed and every test SRS of this repo uses; the first 96 bytes of kzg_bn254_19.srs — k, G, [tau] G and the start of [tau^2] G,
+    compressed with the flag in bit 255 — recomputed with big-integer curve arithmetic equal the committed ones (which the GPU's ParamsKZG.setup + write produced)."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_srs_kat as gk
+    import test_create_proof as tcp
+    kat = _srs_kat()
+    tau = gk.gen_srs_tau()
+    assert tau == tcp.TAU == int(kat["tau_hex"], 16)
+    G = (1, 2)
+    want = (19).to_bytes(4, "little") + point_to_bytes(G) + point_to_bytes(pyref.g1_mul(G, tau)) + point_to_bytes(pyref.g1_mul(G, tau * tau))
+    assert want[:96].hex() == kat["first_96_bytes_hex"] and kat["bytes_g1_part"] == 4 + 2 * 32 * (1 << 19)
+
+
+@pytest.mark.gpu
+def test_gen_srs_file_hash_gpu(gpu):
+    """ParamsKZG.setup(19, tau) + write on the GPU (2^19 fixed-base multiplications, the EC-NTT g_to_lagrange, 2^20 point compressions) reproduces the committed SHA-256 of
+    the file's G1 part"""
+    import hashlib
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_srs_kat as gk
+    kat = _srs_kat()
+    params = z.kzg.ParamsKZG.setup(kat["k"], gk.gen_srs_tau(), backend=gpu)
+    part = gk.g1_part_of(params)
+    params.release()
+    assert len(part) == kat["bytes_g1_part"] and hashlib.sha256(part).hexdigest() == kat["sha256_g1_part"] and part[:96].hex() == kat["first_96_bytes_hex"]

@@ -35,6 +35,7 @@ struct Tune {
     int ntt_max_radix_log = 8;
     int ntt_full_twiddle_max_log = 24;   // up to this size inter-pass twiddles come from full HBM tables (32 B/element/pass)
     int ntt_ws_limit_mb = 24576; // a batched transform's out-of-place workspace (columns x N x 32 B) is capped here: larger batches run in slices of columns (k >= 22)
+    int ntt_fuse_scale = 1;      // the 1/n of an inverse transform rides on the last strided pass's inter-pass twiddle table (one product per element fewer in the final pass)
     int ntt_quarter_input = 1;   // coeff_to_extended: skip the arithmetic of the first two stages when 3/4 of the input is the zero padding
     int vec_block = 256;
     int quot_threads = 128;
@@ -89,6 +90,10 @@ struct TwiddleSet {           // per (omega, log_n)
     void* d_full[3] = {nullptr, nullptr, nullptr};   // per non-final pass: inter-pass twiddles in store order
     uint32_t radix_log[3] = {0, 0, 0};
     int passes = 0;
+    // a transform that ends in a multiplication of every output by one constant (lagrange_to_coeff's 1/n, extended_to_coeff's 1/2^extended_k) takes it through the
+    // inter-pass twiddles of its LAST strided pass instead (that pass multiplies every element anyway): such a set's d_full[passes - 2] holds twiddle * scale
+    bool scale_fused = false;
+    u256 fused_scale;
 };
 
 struct QuotProgram;  // quotient.hip

@@ -103,6 +103,20 @@ struct Field29 {
         return o;
     }
 
+    // the same for limbs that are already exact (0..7 below 2^29: what a product returns): no carry chain, word w is two or three limbs shifted together
+    static ZK_HD u256 to32_exact(const u261& a) {
+        u256 o;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const int bit = w * 32, i = bit / 29, sh = bit % 29;
+            uint64_t v = (uint64_t)a.l[i] >> sh;
+            if (i + 1 < 9) v |= (uint64_t)a.l[i + 1] << (29 - sh);
+            if (i + 2 < 9 && 58 - sh < 32) v |= (uint64_t)a.l[i + 2] << (58 - sh);
+            o.v[w] = (uint32_t)v;
+        }
+        return o;
+    }
+
     // ---- products -------------------------------------------------------------------------------------------------------------------------------------------------
     static ZK_HD u261 mul(const u261& a, const u261& b) {
         uint64_t acc = 0;

@@ -47,11 +47,7 @@ struct NttPassArgs {
     u256 scale29, zeta29[2];
 };
 
-ZK_HD uint32_t bitrev(uint32_t x, uint32_t bits) {
-    uint32_t r = 0;
-    for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
-    return r;
-}
+ZK_HD uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? __builtin_bitreverse32(x) >> (32u - bits) : 0u; }   // (v_bfrev_b32 + one shift; x < 2^bits)
 ZK_HD u256 zeta_pow(uint32_t k) {  // ZETA^k, k in {1, 2}
     const uint64_t z1[4] = BN254_FR_ZETA_M, z2[4] = BN254_FR_ZETA2_M;
     u256 o;
@@ -344,7 +340,7 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) ntt_strided_pass29_kerne
             if (h) w = Fr29::mul(w, Fr29::from32<5>(load_u256(a.tw_hi, h)));                // below 8 p
             v = Fr29::mul(v, Fr29::mul(w, Fr29::one()));                                      // (w below 2 p first: the store must stay below 2 p)
         }
-        store_u256(a.dst, base + ((size_t)row << cols_log) + col, Fr29::to32(v));      // below 2 p, exact integer: the next pass takes it as it is
+        store_u256(a.dst, base + ((size_t)row << cols_log) + col, Fr29::to32_exact(v));      // a product's limbs are exact (no carry round needed); below 2 p: the next pass takes it as it is
     }
 }
 
@@ -447,15 +443,21 @@ static void plan_passes(uint32_t log_n, const Tune& tn, uint32_t rl[3], int* pas
     *passes = p;
 }
 
-static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleSet** out) {
+// scale (optional): a constant every output of the transform is multiplied by; folded into the last strided pass's full twiddle table when the plan has one
+// (TwiddleSet::scale_fused tells the caller whether it was)
+static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, const u256* scale, TwiddleSet** out) {
     uint32_t rl[3];
     int passes;
     plan_passes(log_n, ctx->tune, rl, &passes);
+    const bool full = passes > 1 && (int)log_n <= ctx->tune.ntt_full_twiddle_max_log;
+    const bool fuse = scale && full && ctx->tune.ntt_fuse_scale;
     for (auto& t : ctx->twiddles)
         if (t.log_n == log_n && Fr::eq(t.omega, omega) && t.passes == passes && t.radix_log[0] == rl[0] && t.radix_log[1] == rl[1] &&
-            t.radix_log[2] == rl[2] && (t.d_full[0] != nullptr) == (passes > 1 && (int)log_n <= ctx->tune.ntt_full_twiddle_max_log)) { *out = &t; return ZK_OK; }
+            t.radix_log[2] == rl[2] && (t.d_full[0] != nullptr) == full && t.scale_fused == fuse && (!fuse || Fr::eq(t.fused_scale, *scale))) { *out = &t; return ZK_OK; }
     TwiddleSet ts;
     ts.log_n = log_n; ts.omega = omega; ts.passes = passes;
+    ts.scale_fused = fuse;
+    if (fuse) ts.fused_scale = *scale;
     // the strided passes run on 29-bit limbs and multiply with twiddles in the form w * 2^261: their stage and inter-pass tables hold 32 * (w * 2^256) mod p, canonical
     // (the final pass stays on the 32-bit form — measured, profiles/r03 — and the two-level power tables in the library's form: the quotient kernel reads them too)
     u256 c32 = Fr::zero();
@@ -490,7 +492,8 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, TwiddleS
             ZK_LAUNCH(ntt_full_twiddle_kernel, (uint32_t)((cnt + blk - 1) / blk), blk, 0, ctx->stream, (const void*)ts.d_lo, (const void*)ts.d_hi, ts.lo_bits,
                       cols_log, rl[i], log_n - blk_log, ts.d_full[i]);
             ZK_CHECK_LAUNCH();
-            ZK_LAUNCH(fr_vec_kernel, 1024, blk, 0, ctx->stream, 3, (const void*)ts.d_full[i], (const void*)ts.d_full[i], ts.d_full[i], cnt, c32);
+            ZK_LAUNCH(fr_vec_kernel, 1024, blk, 0, ctx->stream, 3, (const void*)ts.d_full[i], (const void*)ts.d_full[i], ts.d_full[i], cnt,
+                      (fuse && i + 2 == passes) ? Fr::mul(c32, *scale) : c32);
             ZK_CHECK_LAUNCH();
             blk_log -= rl[i];
         }
@@ -551,7 +554,7 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
         return ZK_OK;
     }
     TwiddleSet* ts;
-    int rc = get_twiddles(ctx, log_n, omega, &ts);
+    int rc = get_twiddles(ctx, log_n, omega, nf.post_scale ? &nf.scale : nullptr, &ts);
     if (rc) return rc;
     const Tune& tn = ctx->tune;
     const uint32_t tl = (uint32_t)tn.ntt_tile_log;
@@ -595,7 +598,7 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
         a.stage_tw = ts->d_stage[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits; a.tw_full = last ? nullptr : ts->d_full[p];
         if (first && nf.cs_stride) { a.cs_lo = nf.cs_lo; a.cs_hi = nf.cs_hi; a.cs_lo_bits = nf.cs_lo_bits; a.cs_stride = nf.cs_stride; a.cs_log = nf.cs_log; }
         if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; a.quarter_input = tn.ntt_quarter_input && nf.n_valid && (size_t)nf.n_valid * 4 <= N && a.r >= 2; }
-        if (last) { a.post_scale = nf.post_scale; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
+        if (last) { a.post_scale = nf.post_scale && !ts->scale_fused; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
         if (!last) {                                                  // strided pass: 29-bit limbs, the constants of its fused operations as x * 2^261
             u256 c32 = Fr::zero();
             c32.v[0] = 32;
@@ -848,7 +851,7 @@ namespace zk {
 // power tables of omega (shared with the quotient kernel for extended_omega^idx)
 int ntt_pow_tables(zk_ctx* ctx, uint32_t log_n, const u256& omega, const void** lo, const void** hi, uint32_t* lo_bits) {
     TwiddleSet* ts;
-    int rc = get_twiddles(ctx, log_n, omega, &ts);
+    int rc = get_twiddles(ctx, log_n, omega, nullptr, &ts);
     if (rc) return rc;
     *lo = ts->d_lo; *hi = ts->d_hi; *lo_bits = ts->lo_bits;
     return ZK_OK;

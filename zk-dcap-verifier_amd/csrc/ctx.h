@@ -42,6 +42,7 @@ struct Tune {
     int quot_piece_cosets = 1;   // zk_plonk_pk_build on one GPU: keep cosets 0 .. cs_degree-2 of the key's columns instead of their extended forms when cs_degree - 1 < 2^(extended_k - k) (zk_cosets_to_pieces_dev)
     int quot_degree_split = 1;   // quotient compiler + zk_plonk_create_proof: identities of degree <= 3 are evaluated on two cosets of the extended domain only and join h(X) through
                                  // zk_cosets_to_pieces_dev; 0 = every identity on every row, halo2's bytes also for a witness that violates its circuit
+    int quot_group_factors = 1;  // quotient compiler: the identities of the permutation and lookup arguments are summed per common factor (l_0, l_last, l_active_row) and multiplied by it once
     int quot_factor_horner = 1;  // quotient compiler: q * Horner([a_j], theta) for a theta-compression whose parts all carry the factor q (selector-switched lookups): m - 1 products fewer per row
     int quot_remat_ops = 4;      // quotient compiler: a shared sub-expression of at most this many operations ...
     int quot_remat_distance = 24;   // ... is recomputed when its previous copy lies further back than this many micro-ops

@@ -13,6 +13,7 @@
 // documented in INTEGRATION.md.
 #include "ctx.h"
 #include <algorithm>
+#include <functional>
 #include <mutex>
 
 namespace zk {
@@ -353,6 +354,7 @@ struct Builder {
         pending = 0;
         P.folds_taken++;
     }
+    void skip_fold() { pending++; P.folds_skipped++; }
     void flush_pending() { if (pending && P.folds_taken) emit(M_MUL, -1, {acc(), ypow(pending)}); pending = 0; }
     // Peephole over the finished program: value = value*y + t, where t = a*b is the instruction just before and nothing else reads t, becomes
     // acc = acc*y + a*b with ONE Montgomery reduction (M_FOLD2, Field::mul2_add): 192 limb products instead of 256 on each of the ~90 folds of a row.
@@ -435,6 +437,38 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
     // Demand-driven emission: a calculation is emitted right before its first use (depth-first from
     // the graph's result), so e.g. the gate polynomials of halo2's final Horner(previous, gates, y)
     // are produced one at a time instead of all being live at once.  Unreachable calculations vanish.
+    // degree (in the columns) of a graph's result without emitting anything: what decides an identity's part before its instructions exist
+    auto graph_degree = [&](const Graph& g, uint32_t* out) -> int {
+        const size_t nc = g.calcs.size();
+        *out = 0;
+        std::vector<int> writer(g.num_intermediates, -1);
+        std::vector<uint32_t> cdeg(nc, 0);
+        for (size_t i = 0; i < nc; i++) {
+            const Calc& k = g.calcs[i];
+            auto od = [&](const VSrc& sv) -> uint32_t {
+                if (sv.kind == VS_INTER) return (sv.a < writer.size() && writer[sv.a] >= 0) ? cdeg[writer[sv.a]] : 0u;
+                return (sv.kind == VS_FIXED || sv.kind == VS_ADVICE || sv.kind == VS_INSTANCE) ? 1u : 0u;
+            };
+            uint32_t dg = od(k.s0);
+            switch (k.op) {
+                case OP_ADD: case OP_SUB: dg = std::max(od(k.s0), od(k.s1)); break;
+                case OP_MUL: dg = od(k.s0) + od(k.s1); break;
+                case OP_SQUARE: dg = 2 * od(k.s0); break;
+                case OP_HORNER: {
+                    const uint32_t np = (uint32_t)k.parts.size(), f = od(k.s1);
+                    dg = od(k.s0) + np * f;
+                    for (uint32_t pi = 0; pi < np; pi++) dg = std::max(dg, od(k.parts[pi]) + (np - 1 - pi) * f);
+                    break;
+                }
+                default: break;
+            }
+            cdeg[i] = std::min(dg, 1u << 16);
+            if (k.target >= writer.size()) return ctx->fail(ZK_ERR_PROGRAM, "quotient program: calculation target out of range");
+            writer[k.target] = (int)i;
+        }
+        if (nc) *out = cdeg[nc - 1];
+        return ZK_OK;
+    };
     auto run_graph = [&](const Graph& g, uint32_t cbase, bool prev_is_acc, int* result_vreg, uint32_t* result_degree) -> int {
         const size_t nc = g.calcs.size();
         *result_vreg = -1;
@@ -630,84 +664,120 @@ static int compile_program(zk_ctx* ctx, const uint32_t* words, size_t nwords, Qu
 
     const Builder::Opnd one = B.cst(P.c_one), beta = B.cst(P.c_beta), gamma = B.cst(P.c_gamma);
     const Builder::Opnd l0 = B.col(P.col_l0, 0), llast = B.col(P.col_llast, 0), lact = B.col(P.col_lactive, 0);
-    // ---- permutation argument ------------------------------------------------------------------
+    // ---- permutation and lookup arguments -----------------------------------------------------------
+    // Every identity of the two arguments is l_0, l_last or l_active_row times a cofactor.  They are collected here in halo2's order (the order fixes each identity's
+    // power of y) as closures that emit the COFACTOR, and then emitted either one by one (cofactor * l, fold with y: halo2's own sequence) or — tune quot_group_factors,
+    // the default — group by group: h's numerator is a plain sum of y-weighted identities, so
+    //     sum_i y^(e_i) l_G U_i  =  l_G * y^(e_last) * Horner_y(U_i with the gaps between the group's members as exponents),
+    // one product per identity fewer (the cofactor joins the group's accumulator directly, fused with its own last product where it ends in one) at the price of two
+    // products per group.  Same field element either way.
+    enum { G_L0 = 0, G_LAST = 1, G_ACT = 2 };
+    struct Ident { int group; uint32_t deg; std::function<int()> emit; };   // emit(): instructions that leave the cofactor in a virtual register; returns it
+    std::vector<Ident> idents;
+    int deferred_rc = ZK_OK;
+    auto z = [&](uint32_t s_, int32_t rot) { return B.col(P.col_z + s_, rot); };
     if (P.n_sets) {
         const int32_t last_rot = -(int32_t)(P.blinding + 1);
-        auto z = [&](uint32_t s, int32_t rot) { return B.col(P.col_z + s, rot); };
-        int t = B.tmp(M_SUB, {one, z(0, 0)});
-        t = B.tmp(M_MUL, {B.slot(t), l0});
-        B.fold(B.slot(t), 2);
-        t = B.tmp(M_SQR, {z(P.n_sets - 1, 0)});
-        t = B.tmp(M_SUB, {B.slot(t), z(P.n_sets - 1, 0)});
-        t = B.tmp(M_MUL, {B.slot(t), llast});
-        B.fold(B.slot(t), 3);
-        for (uint32_t s = 1; s < P.n_sets; s++) {
-            t = B.tmp(M_SUB, {z(s, 0), z(s - 1, last_rot)});
-            t = B.tmp(M_MUL, {B.slot(t), l0});
-            B.fold(B.slot(t), 2);
+        for (uint32_t j = 0; j < P.n_perm_cols; j++) {
+            const uint32_t ty = P.perm_cols[2 * j], ix = P.perm_cols[2 * j + 1];
+            if (ty > 2 || ix >= (ty == 0 ? P.n_advice : ty == 1 ? P.n_fixed : P.n_instance))
+                return ctx->fail(ZK_ERR_PROGRAM, "quotient program: permutation column out of range");
         }
-        for (uint32_t s = 0; s < P.n_sets; s++) {
-            const uint32_t c0 = s * chunk_len, c1 = std::min(c0 + chunk_len, P.n_perm_cols);
-            auto vcol = [&](uint32_t j) {
-                const uint32_t ty = P.perm_cols[2 * j], ix = P.perm_cols[2 * j + 1];
-                return B.col((ty == 0 ? P.col_advice : ty == 1 ? P.col_fixed : P.col_instance) + ix, 0);
-            };
-            for (uint32_t j = c0; j < c1; j++) {
-                const uint32_t ty = P.perm_cols[2 * j], ix = P.perm_cols[2 * j + 1];
-                if (ty > 2 || ix >= (ty == 0 ? P.n_advice : ty == 1 ? P.n_fixed : P.n_instance))
-                    return ctx->fail(ZK_ERR_PROGRAM, "quotient program: permutation column out of range");
-            }
-            int left = -1, right = -1;
-            for (uint32_t j = c0; j < c1; j++) {
-                int u = B.tmp(M_MULADD, {beta, B.col(P.col_sigma + j, 0), vcol(j)});
-                u = B.tmp(M_ADD, {B.slot(u), gamma});
-                left = B.tmp(M_MUL, {left < 0 ? z(s, 1) : B.slot(left), B.slot(u)});
-            }
-            for (uint32_t j = c0; j < c1; j++) {
-                int u = B.tmp(M_MULADD, {B.cst(P.c_delta + j), B.xpow(), vcol(j)});
-                u = B.tmp(M_ADD, {B.slot(u), gamma});
-                right = B.tmp(M_MUL, {right < 0 ? z(s, 0) : B.slot(right), B.slot(u)});
-            }
-            t = B.tmp(M_SUB, {B.slot(left), B.slot(right)});
-            t = B.tmp(M_MUL, {B.slot(t), lact});
-            B.fold(B.slot(t), 2 + (c1 - c0));                          // l_active * z * one degree-1 factor per column of the set
+        idents.push_back({G_L0, 2, [&]() { return B.tmp(M_SUB, {one, z(0, 0)}); }});
+        idents.push_back({G_LAST, 3, [&]() { const int t = B.tmp(M_SQR, {z(P.n_sets - 1, 0)}); return B.tmp(M_SUB, {B.slot(t), z(P.n_sets - 1, 0)}); }});
+        for (uint32_t s_ = 1; s_ < P.n_sets; s_++) idents.push_back({G_L0, 2, [&, s_, last_rot]() { return B.tmp(M_SUB, {z(s_, 0), z(s_ - 1, last_rot)}); }});
+        for (uint32_t s_ = 0; s_ < P.n_sets; s_++) {
+            const uint32_t c0 = s_ * chunk_len, c1 = std::min(c0 + chunk_len, P.n_perm_cols);
+            idents.push_back({G_ACT, 2 + (c1 - c0), [&, s_, c0, c1]() {   // l_active * z * one degree-1 factor per column of the set
+                auto vcol = [&](uint32_t j) {
+                    const uint32_t ty = P.perm_cols[2 * j], ix = P.perm_cols[2 * j + 1];
+                    return B.col((ty == 0 ? P.col_advice : ty == 1 ? P.col_fixed : P.col_instance) + ix, 0);
+                };
+                int left = -1, right = -1;
+                for (uint32_t j = c0; j < c1; j++) {
+                    int u = B.tmp(M_MULADD, {beta, B.col(P.col_sigma + j, 0), vcol(j)});
+                    u = B.tmp(M_ADD, {B.slot(u), gamma});
+                    left = B.tmp(M_MUL, {left < 0 ? z(s_, 1) : B.slot(left), B.slot(u)});
+                }
+                for (uint32_t j = c0; j < c1; j++) {
+                    int u = B.tmp(M_MULADD, {B.cst(P.c_delta + j), B.xpow(), vcol(j)});
+                    u = B.tmp(M_ADD, {B.slot(u), gamma});
+                    right = B.tmp(M_MUL, {right < 0 ? z(s_, 0) : B.slot(right), B.slot(u)});
+                }
+                return B.tmp(M_SUB, {B.slot(left), B.slot(right)});
+            }});
         }
     }
-    // ---- lookup arguments ----------------------------------------------------------------------
     for (uint32_t n = 0; n < P.n_lookups; n++) {
-        int tv = -1;
         uint32_t tv_deg = 0;
-        rc = run_graph(lookups[n], gbase[1 + n], false, &tv, &tv_deg);
+        rc = graph_degree(lookups[n], &tv_deg);
         if (rc) return rc;
-        if (tv < 0) tv_deg = 0;
-        const Builder::Opnd table_value = tv >= 0 ? B.slot(tv) : B.cst(P.c_zero);
-        auto zc = [&](int32_t rot) { return B.col(P.col_lk_z + n, rot); };
-        auto ac = [&](int32_t rot) { return B.col(P.col_lk_a + n, rot); };
-        const Builder::Opnd sc = B.col(P.col_lk_s + n, 0);
-        int ams = B.tmp(M_SUB, {ac(0), sc});
-        int t = B.tmp(M_SUB, {one, zc(0)});
-        t = B.tmp(M_MUL, {B.slot(t), l0});
-        B.fold(B.slot(t), 2);
-        t = B.tmp(M_SQR, {zc(0)});
-        t = B.tmp(M_SUB, {B.slot(t), zc(0)});
-        t = B.tmp(M_MUL, {B.slot(t), llast});
-        B.fold(B.slot(t), 3);
-        t = B.tmp(M_ADD, {ac(0), beta});
-        int u = B.tmp(M_ADD, {sc, gamma});
-        t = B.tmp(M_MUL, {B.slot(t), B.slot(u)});
-        t = B.tmp(M_MUL, {B.slot(t), zc(1)});
-        u = B.tmp(M_MUL, {zc(0), table_value});
-        t = B.tmp(M_SUB, {B.slot(t), B.slot(u)});
-        t = B.tmp(M_MUL, {B.slot(t), lact});
-        B.fold(B.slot(t), 1 + std::max(3u, 1 + tv_deg));             // l_active * (z(wX) (A' + beta) (S' + gamma) - z * (compressed input + beta) (compressed table + gamma))
-        t = B.tmp(M_MUL, {B.slot(ams), l0});
-        B.fold(B.slot(t), 2);
-        t = B.tmp(M_SUB, {ac(0), ac(-1)});
-        t = B.tmp(M_MUL, {B.slot(t), B.slot(ams)});
-        t = B.tmp(M_MUL, {B.slot(t), lact});
-        B.fold(B.slot(t), 3);
+        auto zc = [&, n](int32_t rot) { return B.col(P.col_lk_z + n, rot); };
+        auto ac = [&, n](int32_t rot) { return B.col(P.col_lk_a + n, rot); };
+        auto sc = [&, n]() { return B.col(P.col_lk_s + n, 0); };
+        idents.push_back({G_L0, 2, [&, zc]() { return B.tmp(M_SUB, {one, zc(0)}); }});
+        idents.push_back({G_LAST, 3, [&, zc]() { const int t = B.tmp(M_SQR, {zc(0)}); return B.tmp(M_SUB, {B.slot(t), zc(0)}); }});
+        // l_active * (z(wX) (A' + beta) (S' + gamma) - z * (compressed input + beta) (compressed table + gamma)): the graph's result is the second product
+        idents.push_back({G_ACT, 1 + std::max(3u, 1 + tv_deg), [&, n, zc, ac, sc]() {
+            int tv = -1;
+            uint32_t dg = 0;
+            const int r_ = run_graph(lookups[n], gbase[1 + n], false, &tv, &dg);
+            if (r_ && !deferred_rc) deferred_rc = r_;
+            const Builder::Opnd table_value = tv >= 0 ? B.slot(tv) : B.cst(P.c_zero);
+            int t = B.tmp(M_ADD, {ac(0), beta});
+            int u = B.tmp(M_ADD, {sc(), gamma});
+            t = B.tmp(M_MUL, {B.slot(t), B.slot(u)});
+            t = B.tmp(M_MUL, {B.slot(t), zc(1)});
+            u = B.tmp(M_MUL, {zc(0), table_value});
+            return B.tmp(M_SUB, {B.slot(t), B.slot(u)});
+        }});
+        idents.push_back({G_L0, 2, [&, ac, sc]() { return B.tmp(M_SUB, {ac(0), sc()}); }});
+        idents.push_back({G_ACT, 3, [&, ac, sc]() {
+            const int ams = B.tmp(M_SUB, {ac(0), sc()});
+            const int t = B.tmp(M_SUB, {ac(0), ac(-1)});
+            return B.tmp(M_MUL, {B.slot(t), B.slot(ams)});
+        }});
     }
-    B.flush_pending();
+    auto lcol = [&](int g_) { return g_ == G_L0 ? l0 : g_ == G_LAST ? llast : lact; };
+    auto takes = [&](uint32_t deg) { return mode == 0 || (mode == 2) == (deg <= SPLIT_LOW_DEGREE); };
+    const uint32_t M = (uint32_t)idents.size();
+    if (!ctx->tune.quot_group_factors) {
+        for (auto& id : idents) {
+            if (!takes(id.deg)) { B.skip_fold(); continue; }
+            const int u = id.emit();
+            const int t = B.tmp(M_MUL, {B.slot(u), lcol(id.group)});
+            B.fold(B.slot(t), id.deg);
+        }
+        B.flush_pending();
+    } else {
+        // the value so far (the custom gates, folded with y) owes one power of y per identity that follows it
+        int T = -1;
+        if (P.folds_taken) {
+            const uint32_t e = B.pending + M;
+            T = e ? B.tmp(M_MUL, {B.acc(), B.ypow(e)}) : B.tmp(M_MOV, {B.acc()});
+        }
+        B.pending = 0;
+        for (int g_ : {G_ACT, G_L0, G_LAST}) {
+            int prev = -1;
+            for (uint32_t i = 0; i < M; i++) {
+                if (idents[i].group != g_) continue;
+                if (!takes(idents[i].deg)) { P.folds_skipped++; continue; }
+                const int u = idents[i].emit();
+                if (prev < 0) B.emit(M_MOV, -1, {B.slot(u)});
+                else B.emit(M_MULADD, -1, {B.acc(), B.ypow(i - (uint32_t)prev), B.slot(u)});
+                prev = (int)i;
+                P.folds_taken++;
+            }
+            if (prev < 0) continue;
+            const uint32_t e = M - 1 - (uint32_t)prev;
+            const int t2 = B.tmp(M_MUL, {B.acc(), lcol(g_)});
+            if (T < 0) T = e ? B.tmp(M_MUL, {B.slot(t2), B.ypow(e)}) : t2;
+            else T = e ? B.tmp(M_MULADD, {B.slot(t2), B.ypow(e), B.slot(T)}) : B.tmp(M_ADD, {B.slot(t2), B.slot(T)});
+        }
+        if (T >= 0) B.emit(M_MOV, -1, {B.slot(T)});
+        else B.emit(M_MOV, -1, {B.cst(P.c_zero)});
+    }
+    if (deferred_rc) return deferred_rc;
     P.n_consts = P.c_ypow + (uint32_t)P.ypow_exps.size();
     if (P.rotations.size() > 255) return ctx->fail(ZK_ERR_LIMIT, "quotient program: more than 255 distinct rotations");
 

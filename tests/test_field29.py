@@ -28,7 +28,7 @@ def limbs_of(x, loose=None, rnd=None):
     l = [(x >> (29 * i)) & M29 for i in range(8)] + [x >> 232]
     if loose:
         for i in range(8, 0, -1):
-            room = (1 << loose) - 1 - l[i - 1]
+            room = int(2 ** loose) - 1 - l[i - 1]
             take = min(l[i], room >> 29, rnd.randrange(0, 8))
             l[i] -= take
             l[i - 1] += take << 29
@@ -187,7 +187,8 @@ def model_shoup(mod, a, w, wq):
 @pytest.mark.parametrize("field", [0, 1])
 def test_shoup_product_with_a_precomputed_quotient(hh, orc, pyref, field):
     """mul_shoup: a * w mod p for a constant w, wq = floor(w 2^261 / p) — what the NTT butterflies multiply their twiddles with.  shoup_quotient is exact; the product equals the
-    column model limb for limb, is congruent to a * w, below 3 p, for every a below 2^261 with limbs up to 2^30 (q is the true quotient or one below)."""
+    column model limb for limb, is congruent to a * w, below 3 p, for every a below 2^261 with limbs up to 3 * 2^30 — a biased difference of N-form values, the loosest operand a
+    butterfly multiplies (q is the true quotient or one below).  mul_shoup = shoup_r(shoup_q(..)), the two halves the NTT kernels call."""
     mod = pyref.P if field == 0 else pyref.R
     rnd = random.Random(41 + field)
     ws = [0, 1, 2, mod - 1, mod - 2, (mod + 1) // 2, 1 << 253] + [rnd.randrange(0, mod) for _ in range(80)]
@@ -199,10 +200,12 @@ def test_shoup_product_with_a_precomputed_quotient(hh, orc, pyref, field):
     avals = [0, 1, mod - 1, mod, 3 * mod - 1, 32 * mod, 150 * mod, RAD - 1] + [rnd.randrange(0, RAD) for _ in range(40)] + [rnd.randrange(0, 8 * mod) for _ in range(40)]
     A, Wl, Wq = [], [], []
     for j in range(len(ws)):
-        for loose in (None, 30):
+        for loose in (None, 30, 31.58):
             a = rnd.choice(avals)
             A.append(limbs_of(a, loose, rnd)); Wl.append(limbs_of(ws[j])); Wq.append(wq[j])
     A.append([(1 << 30) - 1] * 8 + [(1 << 28) - 1]); Wl.append(limbs_of(mod - 1)); Wq.append(limbs_of((mod - 1) * RAD // mod))     # every limb at its bound (the integer is still below 2^261)
+    assert value(A[-1]) < RAD
+    A.append([3 * (1 << 30)] * 8 + [(1 << 26)]); Wl.append(limbs_of(mod - 1)); Wq.append(limbs_of((mod - 1) * RAD // mod))           # ... and at the bound of a biased difference
     assert value(A[-1]) < RAD
     got = run_raw(hh, field, 10, A, Wl, Wq)
     low = 0

@@ -88,6 +88,8 @@ struct TwiddleSet {           // per (omega, log_n)
     void* d_hi = nullptr;     // omega^(e << lo_bits)
     uint32_t lo_bits = 0;
     void* d_stage[3] = {nullptr, nullptr, nullptr};  // per pass: omega_R^k, k < R/2
+    void* d_stage_sh[3] = {nullptr, nullptr, nullptr};   // per pass: the same twiddles as Shoup pairs (w, floor(w 2^261 / p)), 80 bytes each
+    void* d_stage29[3] = {nullptr, nullptr, nullptr};    // per pass: the same twiddles x 2^261 (Montgomery operands of the 29-bit form)
     void* d_full[3] = {nullptr, nullptr, nullptr};   // per non-final pass: inter-pass twiddles in store order
     uint32_t radix_log[3] = {0, 0, 0};
     int passes = 0;

@@ -144,16 +144,26 @@ struct Field29 {
     }
 
     // a * w mod p for a CONSTANT w (a twiddle factor): w canonical, wq = shoup_quotient(w) = floor(w 2^261 / p).  q = floor(a wq / 2^261) is taken from the columns 7 .. 16
-    // of a * wq only — the columns below add less than 2^-26 of a unit, so q is the true quotient or one below — and r = a w - q p is read off the low 261 bits of
-    // a w + q (2^261 - p).  For any a below 2^261 (limbs below 2^30): r is N-form with limbs below 2^29, congruent to a w, below 3 p.  143 mads against the 162 + 9 multiplications of
-    // the Montgomery product, and NO Montgomery factor: a, r stay in whatever form a is in.
-    static ZK_HD u261 mul_shoup(const u261& a, const u261& w, const u261& wq) {
+    // of a * wq only — the columns below add less than 2^-23 of a unit, so q is the true quotient or up to two below — and r = a w - q p is read off the low 261 bits of
+    // a w + q (2^261 - p).  For any a below 2^261 with limbs below 3 * 2^30 (a biased difference of N-form values): r has exact limbs below 2^29, is congruent to a w and below 3 p.
+    // 143 mads against the 162 + 9 multiplications of the Montgomery product, and NO Montgomery factor: a, r stay in whatever form a is in.  In two halves, so that a caller
+    // which fetches wq, then w keeps one of the two constants live at a time (the NTT butterflies: ntt.hip mul_tw).
+    struct Quot9 { uint32_t q[9]; };
+    static ZK_HD Quot9 shoup_q(const u261& a, const u261& wq) {
         uint64_t acc = 0;
-        uint32_t q[9];
+        Quot9 o;
+        uint32_t* q = o.q;
+#include "field29_shoupq_body.inc"
+        return o;
+    }
+    static ZK_HD u261 shoup_r(const u261& a, const u261& w, const Quot9& qq) {
+        uint64_t acc = 0;
+        const uint32_t* q = qq.q;
         u261 r;
-#include "field29_shoup_body.inc"
+#include "field29_shoupr_body.inc"
         return r;
     }
+    static ZK_HD u261 mul_shoup(const u261& a, const u261& w, const u261& wq) { return shoup_r(a, w, shoup_q(a, wq)); }
     // p^-1 mod 2^261 (Hensel, bit by bit), as limbs
     static constexpr Limbs9 pinv261() {
         uint64_t x[5] = {0, 0, 0, 0, 0}, px[5] = {0, 0, 0, 0, 0};        // px = p * x mod 2^320

@@ -29,7 +29,9 @@ struct NttPassArgs {
     uint32_t c_log;     // log2 columns per tile
     uint32_t q_log;     // final pass: log2 of the fast output digit range (Q)
     uint32_t p_log;     // final pass: log2 of the middle digit range (P)
-    const void* stage_tw;   // omega_R^k, k < R/2
+    const void* stage_tw;   // omega_R^k, k < R/2 (final pass: the library's form)
+    const void* stage_sh;   // 29-bit passes: the same twiddles as Shoup pairs (ntt_shoup_table_kernel)
+    const void* stage_tw29; // 29-bit passes: the same twiddles x 2^261 (Montgomery operands of the last step of a radix above 2^6)
     const void* tw_lo;      // omega^e, e < 2^lo_bits
     const void* tw_hi;      // omega^(h << lo_bits)
     uint32_t lo_bits;
@@ -185,14 +187,7 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
 // a twiddle enters a product as w * 2^261 (the stage tables and the full inter-pass tables of a 29-bit plan are generated that way; the two-level power tables
 // and the fused constants go through the limb conversion's shift by 5 or arrive as x * 2^261 in the arguments), so value * twiddle * 2^-261 stays in the library's
 // form with no correction.  The tile holds 36 bytes per element (two 16-byte planes + one 4-byte plane, same swizzled index).
-// Bounds, in multiples of p (a product returns below a b / 151 + 1, limbs 0..7 below 2^29):  tile values are N-form (limbs below 2^29 + 8) and below V.
-//   first step when it starts at stage 0 (every twiddle but one is 1: plain sums, V = 2 in):  t0, t2 = sums < 4;  t1 = x0 - x1 + 3p < 5;  t3 = (x2 - x3 + 3p) w < 1.04;
-//       out0 < 8, out1 < 6.1, out2 = t0 - t2 + 5p < 9, out3 = t1 - t3 + 3p < 8                                                            -> V = 9
-//   every other radix-4 step multiplies on ALL lanes (a wave mixes twiddle indices, so a "trivial twiddle" branch would run both sides anyway; index 0 of a
-//       table is 2^261 mod p):  x1', x3' < V/151 + 1 < 2;  t0, t2 < V + 2;  t1, t3 < V + 3;  t2', t3' < 2;  outputs < V + 6;  the odd last stage: V + 3
-//   so a pass of radix 2^7 ends below 24 p, of 2^8 below 27 p; the inter-pass twiddle product (or the final store's reduction) brings that below 2 p again.
-//   Limbs: a biased difference has limbs below 2^31 + 8 — fine against a product's or a table's exact limbs — and every output of a step is below 2^32 before
-//   its one carry round.
+// (bounds of the butterflies: at ntt_tile_stages29)
 // ------------------------------------------------------------------------------------------------
 struct Tile29 {
     uint4* lo; uint4* hi; uint32_t* top;
@@ -210,7 +205,36 @@ ZK_HD u261 lds_get29(const Tile29& t, uint32_t idx) {
     o.l[8] = t.top[idx];
     return o;
 }
-__device__ __forceinline__ void ntt_tile_stages29(const Tile29& t, uint32_t r, uint32_t c_log, const Tile29& tw, bool quarter_input) {
+// The stage twiddles of the 29-bit passes are CONSTANT operands, so their products take Shoup's form (field29.cuh shoup_q / shoup_r): w as its canonical integer with the precomputed
+// quotient wq = floor(w 2^261 / p), 143 multiply-adds against the 162 + 9 of a Montgomery product, no Montgomery factor (value * w stays in the library's form), result
+// with exact limbs below 3 p for any operand below 2^261 with limbs below 3 * 2^30.  The pairs live in LDS after the tile, in what a 40 KB share of the CU's LDS leaves: all R/2 of
+// them up to radix 2^6, every second one above — which serves every step but the last (twiddle indices are multiples of 2^(r - 2 - s)); the last step of such a pass multiplies the
+// Montgomery way, with the R/2 twiddles (x 2^261) written over the same LDS area just before it.  Uniform per step, and every twiddle read is a plain LDS read.
+struct TwPairs {
+    Tile29 w, q;          // Shoup pairs of the twiddles whose index is a multiple of 2^lds_log
+    Tile29 mont;          // the same area as R/2 Montgomery twiddles, once stage_to_mont() has run
+    uint32_t lds_log;
+};
+// x * w: the quotient digits from wq first, w fetched only then (one of the two constants live at a time)
+ZK_HD u261 mul_tw(const TwPairs& tp, const u261& x, uint32_t idx) {
+    const Fr29::Quot9 q = Fr29::shoup_q(x, lds_get29(tp.q, idx >> tp.lds_log));
+    return Fr29::shoup_r(x, lds_get29(tp.w, idx >> tp.lds_log), q);
+}
+// Bounds, in multiples of p: a Shoup product returns below 3 with exact limbs; tile values are N-form (limbs below 2^29 + 8) and below V.
+//   first step when it starts at stage 0 (every twiddle but one is 1: plain sums, V = 2 in):  t0, t2 = sums < 4;  t1 = x0 - x1 + 3p < 5;  t3 = (x2 - x3 + 3p) w < 3;
+//       out0 < 8, out1 < 8, out2 = t0 - t2 + 5p < 9, out3 = t1 - t3 + 4p < 9                                                              -> V = 9
+//   every other radix-4 step multiplies on ALL lanes (a wave mixes twiddle indices, so a "trivial twiddle" branch would run both sides anyway; index 0 of a table is 1):
+//       x1', x3' < 3;  t0, t2 < V + 3;  t1, t3 < V + 4;  t2', t3' < 3;  outputs < V + 8;  the odd last stage: V + 4
+//   so a pass of radix 2^7 ends below 9 + 8 + 8 + 4 = 29 p, of 2^8 below 33 p (far below the 151 p a value may reach); the inter-pass twiddle product (Montgomery, with the
+//   full table) brings that below 2 p again.  Limbs: a biased difference has limbs below 2^31 + 8 — fine as an operand of a product (3.05 * 2^30) — and every output of a step is
+//   below 2^32 before its one carry round.
+// stage_tw: the pass's R/2 stage twiddles as x 2^261 Montgomery operands (32 bytes each, global), for the step that leaves the Shoup pairs' reach
+__device__ __forceinline__ void ntt_tile_stages29(const Tile29& t, uint32_t r, uint32_t c_log, const TwPairs& tp, const void* stage_tw, bool quarter_input) {
+    auto to_mont = [&]() {                                             // (all threads; the tile is not touched) overwrite the pair area with the R/2 Montgomery twiddles
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < (1u << (r - 1)); e += blockDim.x) lds_put29(tp.mont, e, Fr29::from32<0>(load_u256(stage_tw, e)));
+        __syncthreads();
+    };
     const uint32_t C = 1u << c_log;
     uint32_t s = 0;
     if (quarter_input && r >= 2) {
@@ -228,6 +252,8 @@ __device__ __forceinline__ void ntt_tile_stages29(const Tile29& t, uint32_t r, u
     for (; s + 1 < r; s += 2) {
         const uint32_t h = 1u << s;
         const uint32_t nq = (1u << (r - 2)) << c_log;  // quads per step in the tile
+        const bool shoup = r - 2 - s >= tp.lds_log;    // (uniform) every twiddle index of this step is a multiple of 2^(r - 2 - s)
+        if (!shoup) to_mont();
         for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) {
             const uint32_t col = q & (C - 1), bq = q >> c_log;
             const uint32_t grp = bq >> s, pos = bq & (h - 1);
@@ -237,18 +263,32 @@ __device__ __forceinline__ void ntt_tile_stages29(const Tile29& t, uint32_t r, u
             u261 o0, o1, o2, o3;
             if (s == 0) {                                   // (uniform: the first step of a pass that starts at stage 0) every twiddle but the last is 1
                 const u261 t0 = Fr29::add(x0, x1), t1 = Fr29::sub_bias<3, 30>(x0, x1), t2 = Fr29::add(x2, x3);
-                const u261 t3 = Fr29::mul(Fr29::sub_bias<3, 30>(x2, x3), lds_get29(tw, (size_t)1 << (r - 2)));
+                const u261 t3 = shoup ? mul_tw(tp, Fr29::sub_bias<3, 30>(x2, x3), 1u << (r - 2)) : Fr29::mul(Fr29::sub_bias<3, 30>(x2, x3), lds_get29(tp.mont, 1u << (r - 2)));
                 o0 = Fr29::add(t0, t2); o1 = Fr29::add(t1, t3);
-                o2 = Fr29::sub_bias<5, 30>(t0, t2); o3 = Fr29::sub_bias<3, 30>(t1, t3);
-            } else {
-                const u261 w1 = lds_get29(tw, (size_t)pos << (r - 1 - s));
+                o2 = Fr29::sub_bias<5, 30>(t0, t2); o3 = Fr29::sub_bias<4, 30>(t1, t3);
+            } else if (shoup) {
+                {   // x1, x3 share w1: both quotients while wq is live, then both remainders with w
+                    const uint32_t i1w = (pos << (r - 1 - s)) >> tp.lds_log;
+                    const u261 w1q = lds_get29(tp.q, i1w);
+                    const Fr29::Quot9 q1 = Fr29::shoup_q(x1, w1q), q3 = Fr29::shoup_q(x3, w1q);
+                    const u261 w1 = lds_get29(tp.w, i1w);
+                    x1 = Fr29::shoup_r(x1, w1, q1);
+                    x3 = Fr29::shoup_r(x3, w1, q3);
+                }
+                const u261 t0 = Fr29::add(x0, x1), t1 = Fr29::sub_bias<4, 30>(x0, x1);
+                const u261 t2 = mul_tw(tp, Fr29::add(x2, x3), pos << (r - 2 - s));
+                const u261 t3 = mul_tw(tp, Fr29::sub_bias<4, 30>(x2, x3), (pos + h) << (r - 2 - s));
+                o0 = Fr29::add(t0, t2); o1 = Fr29::add(t1, t3);
+                o2 = Fr29::sub_bias<4, 30>(t0, t2); o3 = Fr29::sub_bias<4, 30>(t1, t3);
+            } else {                                        // the last step of a radix above 2^6: Montgomery products (below 2 p: the biases of the Shoup steps cover them)
+                const u261 w1 = lds_get29(tp.mont, pos << (r - 1 - s));
                 x1 = Fr29::mul(x1, w1);
                 x3 = Fr29::mul(x3, w1);
-                const u261 t0 = Fr29::add(x0, x1), t1 = Fr29::sub_bias<3, 30>(x0, x1);
-                const u261 t2 = Fr29::mul(Fr29::add(x2, x3), lds_get29(tw, (size_t)pos << (r - 2 - s)));
-                const u261 t3 = Fr29::mul(Fr29::sub_bias<3, 30>(x2, x3), lds_get29(tw, (size_t)(pos + h) << (r - 2 - s)));
+                const u261 t0 = Fr29::add(x0, x1), t1 = Fr29::sub_bias<4, 30>(x0, x1);
+                const u261 t2 = Fr29::mul(Fr29::add(x2, x3), lds_get29(tp.mont, pos << (r - 2 - s)));
+                const u261 t3 = Fr29::mul(Fr29::sub_bias<4, 30>(x2, x3), lds_get29(tp.mont, (pos + h) << (r - 2 - s)));
                 o0 = Fr29::add(t0, t2); o1 = Fr29::add(t1, t3);
-                o2 = Fr29::sub_bias<3, 30>(t0, t2); o3 = Fr29::sub_bias<3, 30>(t1, t3);
+                o2 = Fr29::sub_bias<4, 30>(t0, t2); o3 = Fr29::sub_bias<4, 30>(t1, t3);
             }
             lds_put29(t, i0, Fr29::carry(o0));
             lds_put29(t, i1, Fr29::carry(o1));
@@ -260,6 +300,8 @@ __device__ __forceinline__ void ntt_tile_stages29(const Tile29& t, uint32_t r, u
     if (s < r) {
         const uint32_t half = 1u << s;
         const uint32_t nbf = (1u << (r - 1)) << c_log;  // butterflies of the stage in the tile
+        const bool shoup = r - 1 - s >= tp.lds_log;
+        if (!shoup && s) to_mont();
         for (uint32_t q = threadIdx.x; q < nbf; q += blockDim.x) {
             const uint32_t col = q & (C - 1), bq = q >> c_log;
             const uint32_t grp = bq >> s, pos = bq & (half - 1);
@@ -271,9 +313,9 @@ __device__ __forceinline__ void ntt_tile_stages29(const Tile29& t, uint32_t r, u
                 lds_put29(t, i0, Fr29::carry(Fr29::add(x, y)));
                 lds_put29(t, i1, Fr29::carry(Fr29::sub_bias<3, 30>(x, y)));
             } else {
-                y = Fr29::mul(y, lds_get29(tw, (size_t)pos << (r - 1 - s)));
+                y = shoup ? mul_tw(tp, y, pos << (r - 1 - s)) : Fr29::mul(y, lds_get29(tp.mont, pos << (r - 1 - s)));
                 lds_put29(t, i0, Fr29::carry(Fr29::add(x, y)));
-                lds_put29(t, i1, Fr29::carry(Fr29::sub_bias<3, 30>(x, y)));
+                lds_put29(t, i1, Fr29::carry(Fr29::sub_bias<4, 30>(x, y)));
             }
         }
         __syncthreads();
@@ -304,14 +346,32 @@ ZK_HD Tile29 tile29_at(uint4* base, uint32_t count) {                 // planes 
     return t;
 }
 
+// the twiddle area of a 29-bit pass (after the tile): the Shoup pairs of its stage twiddles — all R/2 up to radix 2^6, every second one above — staged by the whole workgroup
+__device__ __forceinline__ TwPairs stage_pairs(const NttPassArgs& a, uint4* smem, uint32_t tile, uint32_t half) {
+    TwPairs tp;
+    tp.lds_log = a.r >= 7 ? 1u : 0u;
+    const uint32_t n_lds = half >> tp.lds_log;
+    uint4* const area = smem + (tile * 36 + 15) / 16;
+    tp.w = tile29_at(area, n_lds);
+    tp.q = tile29_at(area + (n_lds * 36 + 15) / 16, n_lds);
+    tp.mont = tile29_at(area, half);
+    for (uint32_t e = threadIdx.x; e < n_lds; e += blockDim.x) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.stage_sh) + (size_t)20 * (e << tp.lds_log);
+        u261 w, wq;
+        for (int i = 0; i < 9; i++) { w.l[i] = src[i]; wq.l[i] = src[9 + i]; }
+        lds_put29(tp.w, e, w);
+        lds_put29(tp.q, e, wq);
+    }
+    return tp;
+}
+
 ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) ntt_strided_pass29_kernel(NttPassArgs a) {
     ZK_DYN_SHARED(uint4, smem);
     if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
     const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
     const Tile29 t = tile29_at(smem, tile);
     const uint32_t half = R >> 1 ? R >> 1 : 1;
-    const Tile29 tw = tile29_at(smem + (tile * 36 + 15) / 16, half);   // R/2 stage twiddles (x 2^261, canonical) after the tile
-    for (uint32_t e = threadIdx.x; e < half; e += blockDim.x) lds_put29(tw, e, Fr29::from32<0>(load_u256(a.stage_tw, e)));
+    const TwPairs tp = stage_pairs(a, smem, tile, half);
     const uint32_t cols_log = a.blk_log - a.r;
     const uint32_t tiles_per_blk_log = cols_log - a.c_log;
     const uint32_t tb = blockIdx.x;
@@ -324,7 +384,7 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) ntt_strided_pass29_kerne
         lds_put29(t, tile_at(bitrev(row, a.r), col, a.r, a.c_log), ntt_load_input29(a, idx));
     }
     __syncthreads();
-    ntt_tile_stages29(t, a.r, a.c_log, tw, a.quarter_input != 0);
+    ntt_tile_stages29(t, a.r, a.c_log, tp, a.stage_tw29, a.quarter_input != 0);
     const uint32_t sh = a.log_n - a.blk_log;
     const uint32_t lomask = (1u << a.lo_bits) - 1;
     for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
@@ -381,6 +441,17 @@ ZK_KERNEL void fr_pow_table_kernel(u256 base, uint32_t count, void* out) {
         if ((k >> b) & 1) acc = Fr::mul(acc, base);
     }
     store_u256(out, k, acc);
+}
+
+// Shoup pairs of a strided pass's stage twiddles: entry k = 9 limbs of the canonical integer w_k | 9 limbs of floor(w_k 2^261 / p) | 2 words of padding (80 bytes)
+ZK_KERNEL void ntt_shoup_table_kernel(const void* tw_lib, uint32_t count, void* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const u256 w = Fr::from_mont(load_u256(tw_lib, k));
+    const u261 wl = Fr29::from32<0>(w), wq = Fr29::shoup_quotient(w);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out) + (size_t)20 * k;
+    for (int i = 0; i < 9; i++) { o[i] = wl.l[i]; o[9 + i] = wq.l[i]; }
+    o[18] = o[19] = 0;
 }
 
 // full inter-pass twiddle table of a non-final pass: out[row * cols + m] = omega^((m * row) << sh)
@@ -478,10 +549,14 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, const u2
         ZK_HIP(hipMalloc(&ts.d_stage[i], (size_t)half * 32));
         ZK_LAUNCH(fr_pow_table_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, fr_pow2k_host(omega, log_n - rl[i]), half, ts.d_stage[i]);
         ZK_CHECK_LAUNCH();
-        if (i + 1 < passes) {
-            ZK_LAUNCH(fr_vec_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, 3, (const void*)ts.d_stage[i], (const void*)ts.d_stage[i], ts.d_stage[i], (size_t)half, c32);
-            ZK_CHECK_LAUNCH();
-        }
+        if (i + 1 == passes) continue;                                // (the final pass stays on the 32-bit form: a 29-bit Shoup final pass measured the same, profiles/r04)
+        // the strided passes multiply with Shoup pairs of these twiddles — and, in the last step of a radix above 2^6, with their x 2^261 Montgomery forms
+        ZK_HIP(hipMalloc(&ts.d_stage_sh[i], (size_t)half * 80));
+        ZK_LAUNCH(ntt_shoup_table_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, (const void*)ts.d_stage[i], half, ts.d_stage_sh[i]);
+        ZK_CHECK_LAUNCH();
+        ZK_HIP(hipMalloc(&ts.d_stage29[i], (size_t)half * 32));
+        ZK_LAUNCH(fr_vec_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, 3, (const void*)ts.d_stage[i], (const void*)ts.d_stage[i], ts.d_stage29[i], (size_t)half, c32);
+        ZK_CHECK_LAUNCH();
     }
     if ((int)log_n <= ctx->tune.ntt_full_twiddle_max_log) {
         uint32_t blk_log = log_n;
@@ -508,7 +583,7 @@ void release_twiddles(zk_ctx* ctx) {
     for (auto& t : ctx->twiddles) {
         if (t.d_lo) (void)hipFree(t.d_lo);
         if (t.d_hi) (void)hipFree(t.d_hi);
-        for (int i = 0; i < 3; i++) { if (t.d_stage[i]) (void)hipFree(t.d_stage[i]); if (t.d_full[i]) (void)hipFree(t.d_full[i]); }
+        for (int i = 0; i < 3; i++) { if (t.d_stage[i]) (void)hipFree(t.d_stage[i]); if (t.d_stage_sh[i]) (void)hipFree(t.d_stage_sh[i]); if (t.d_stage29[i]) (void)hipFree(t.d_stage29[i]); if (t.d_full[i]) (void)hipFree(t.d_full[i]); }
     }
     ctx->twiddles.clear();
 }
@@ -595,11 +670,11 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             a.dsts = (last && !via_tmp) ? (void* const*)d_dst : (void* const*)d_tmp;
         }
         a.log_n = log_n; a.blk_log = blk_log; a.r = ts->radix_log[p];
-        a.stage_tw = ts->d_stage[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits; a.tw_full = last ? nullptr : ts->d_full[p];
+        a.stage_tw = ts->d_stage[p]; a.stage_sh = ts->d_stage_sh[p]; a.stage_tw29 = ts->d_stage29[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits; a.tw_full = last ? nullptr : ts->d_full[p];
         if (first && nf.cs_stride) { a.cs_lo = nf.cs_lo; a.cs_hi = nf.cs_hi; a.cs_lo_bits = nf.cs_lo_bits; a.cs_stride = nf.cs_stride; a.cs_log = nf.cs_log; }
         if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; a.quarter_input = tn.ntt_quarter_input && nf.n_valid && (size_t)nf.n_valid * 4 <= N && a.r >= 2; }
         if (last) { a.post_scale = nf.post_scale && !ts->scale_fused; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
-        if (!last) {                                                  // strided pass: 29-bit limbs, the constants of its fused operations as x * 2^261
+        if (!last) {                                                  // a 29-bit pass takes the constants of its fused operations as x * 2^261
             u256 c32 = Fr::zero();
             c32.v[0] = 32;
             c32 = Fr::to_mont(c32);
@@ -613,7 +688,8 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             const uint32_t cols_log = blk_log - a.r;
             a.c_log = room < cols_log ? room : cols_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
-            const size_t lds = ((((size_t)36 << (a.r + a.c_log)) + 15) & ~(size_t)15) + ((size_t)18 << a.r) + 64;     // 36-byte elements: tile + R/2 stage twiddles
+            const size_t half_tw = (size_t)1 << (a.r ? a.r - 1 : 0), n_pairs = a.r >= 7 ? half_tw / 2 : half_tw;
+            const size_t lds = ((((size_t)36 << (a.r + a.c_log)) + 15) & ~(size_t)15) + std::max(2 * ((n_pairs * 36 + 15) & ~(size_t)15), a.r >= 7 ? half_tw * 36 : 0) + 64;     // 36-byte elements: tile + the twiddle area (ntt_tile_stages29)
             if (tn.ntt_threads > 256) return ctx->fail(ZK_ERR_ARG, "ntt_threads: the strided passes take at most 256 threads per workgroup");
             ZK_LAUNCH(ntt_strided_pass29_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();

@@ -1046,7 +1046,9 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
     tq.stop();
     ZK_HIP(hipStreamSynchronize(st));
     tq.resolve();
-    if (ctx->timing) ctx->last_ms["quotient_alg_bytes"] += (double)rows * (P.n_cols + 1) * 32.0;   // every column once + the output, per row
+    // every column once + the output, per row of the extended domain — counted once per evaluation of h's numerator (on its high part when the program is split; the
+    // theta-compression programs of the lookups, which run on this interpreter too, are not part of that figure though their time is inside the "quotient" timer)
+    if (ctx->timing && P.ek > P.k && part != 2) ctx->last_ms["quotient_alg_bytes"] += (double)rows * (P.n_cols + 1) * 32.0;
     return ZK_OK;
 }
 

@@ -12,7 +12,7 @@
 namespace zk {
 
 constexpr uint32_t PE_T = 256;      // threads per workgroup
-constexpr uint32_t PE_E = 128;      // coefficients per thread per workgroup (the per-workgroup x^T and x^tid powers cost ~22 products per thread: 32 made them 40 % of the kernel)
+constexpr uint32_t PE_E = 126;      // coefficients per thread per workgroup (the per-workgroup x^T and x^tid powers cost ~22 products per thread: 32 made them 40 % of the kernel)
 
 ZK_HD u256 fr_pow_u32(u256 base, uint32_t e) {
     u256 acc = Fr::one();
@@ -51,20 +51,34 @@ ZK_KERNEL void pe_eval_partial_kernel(const void* const* polys, const void* poin
     const uint32_t span = T * PE_E, start = blockIdx.x * span;
     u256 xT = x;                                   // x^T, T a power of two
     for (uint32_t t = T; t > 1; t >>= 1) xT = Fr::sqr(xT);
-    // Horner in x^T over c[start + tid + e*T], two coefficients per step: acc*x^2T + c_hi*x^T with ONE Montgomery reduction for both products, sums in the
-    // redundant range [0, 2p) (field.cuh); the product with x^tid below is a full one and returns the canonical value
-    static_assert(PE_E % 2 == 0, "two coefficients per Horner step");
-    const u256 xT2 = Fr::sqr(xT);
-    u256 acc = Fr::zero();
-#pragma unroll 4
-    for (int e = (int)PE_E - 1; e >= 1; e -= 2) {
-        const uint32_t ih = start + tid + (uint32_t)e * T, il = ih - T;
-        const u256 ch = ih < n ? load_u256(poly, ih) : Fr::zero(), cl = il < n ? load_u256(poly, il) : Fr::zero();
-        acc = Fr::red2p(Fr::add_lazy(Fr::mul2_add_2p(acc, xT2, ch, xT), cl));
+    // Horner in x^T over c[start + tid + e*T], SIX coefficients per step on carry-free limbs (field29.cuh, sums of products): acc * x^6T + c5 x^5T + .. + c1 x^T with ONE
+    // reduction for the six products, c0 added as it is; the powers are the same in every thread (scalar registers).  The product with x^tid below is a full one and
+    // returns the canonical value.
+    static_assert(PE_E % 6 == 0, "six coefficients per Horner step");
+    __shared__ uint32_t X[6][12];                  // x^T .. x^6T as x 2^261 operands (exact limbs): the same in every thread, read back from LDS (a broadcast) at each use
+    if (tid < 6) {
+        u256 c32 = Fr::zero();
+        c32.v[0] = 32;
+        u256 pw = Fr::mul(xT, Fr::to_mont(c32));   // x^T * 32
+        for (uint32_t k = 0; k < tid; k++) pw = Fr::mul(pw, xT);
+        const u261 t = Fr29::from32<0>(pw);
+        for (int i = 0; i < 9; i++) X[tid][i] = t.l[i];
     }
-    acc = Fr::mul(acc, fr_pow_u32(x, tid));
-    acc = pe_block_sum(acc);
-    if (tid == 0) store_u256(partial, (size_t)q * gridDim.x + blockIdx.x, acc);
+    __syncthreads();
+    auto xp = [&](int k) -> u261 { u261 o; for (int i = 0; i < 9; i++) o.l[i] = X[k][i]; return o; };
+    u261 acc = Fr29::zero();
+    auto coef = [&](uint32_t e) -> u261 { const uint32_t idx = start + tid + e * T; return idx < n ? Fr29::from32<0>(load_u256(poly, idx)) : Fr29::zero(); };
+    for (int e = (int)PE_E - 6; e >= 0; e -= 6) {
+        Fr29::Dot29 d;
+        Fr29::dot_clear(d);
+        Fr29::dot_add(d, acc, xp(5));
+#pragma unroll 1
+        for (int k = 5; k >= 1; k--) Fr29::dot_add(d, coef((uint32_t)e + k), xp(k - 1));
+        acc = Fr29::carry(Fr29::add(Fr29::dot_reduce(d), coef((uint32_t)e)));       // below 2.05 p, N-form
+    }
+    u256 acc32 = Fr::mul(Fr29::to32(acc), fr_pow_u32(x, tid));
+    acc32 = pe_block_sum(acc32);
+    if (tid == 0) store_u256(partial, (size_t)q * gridDim.x + blockIdx.x, acc32);
 }
 // out[q] = sum_b partial[q][b] * (x^span)^b
 ZK_KERNEL void pe_eval_final_kernel(const void* partial, const void* points, uint32_t nblk, uint32_t span, void* out) {
@@ -174,20 +188,24 @@ ZK_KERNEL void kd_carry_kernel(void* carries, uint32_t nblk, void* out) {
 // out[i] = sum_j s_j * p_j[i]: the `poly * power_of_y` ... `reduce(|acc, poly| acc + &poly)` chains of
 // halo2_proofs src/poly/kzg/multiopen/shplonk/prover.rs, one pass over all inputs instead of one pass per term.
 // args: [count pointers | pad to 32 B | count scalars]
-ZK_KERNEL void pe_lincomb_kernel(const void* const* polys, const void* scalars, uint32_t count, size_t n, void* out) {
+ZK_KERNEL void pe_lincomb_kernel(const void* const* polys, const void* scalars32, uint32_t count, size_t n, void* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    // terms are taken two at a time with ONE Montgomery reduction for both products (192 instead of 256 multiply-adds) and summed in the redundant range
-    // [0, 2p) (field.cuh); the element is normalised when it is stored.  (A scalar mont(1) is just another scalar: v * R * R^-1 = v.)
+    // terms are taken SIX at a time on carry-free limbs with ONE Montgomery reduction for the six products (field29.cuh, sums of products: 96 multiplications per term against
+    // 171); scalars32: the scalars times 32 (x 2^261 operands: value * scalar * 2^-261 stays in the library's form), the same in every thread.  Chunk sums are added with a
+    // carry round; the element is reduced and normalised when it is stored.
     for (; i < n; i += stride) {
-        u256 acc = Fr::zero();
-        uint32_t j = 0;
-        for (; j + 1 < count; j += 2) {
-            const u256 t = Fr::mul2_add_2p(load_u256(polys[j], i), load_u256(scalars, j), load_u256(polys[j + 1], i), load_u256(scalars, j + 1));
-            acc = Fr::red2p(Fr::add_lazy(acc, t));
+        u261 total = Fr29::zero();
+        uint32_t chunks = 0;
+        for (uint32_t j0 = 0; j0 < count; j0 += 6) {
+            Fr29::Dot29 d;
+            Fr29::dot_clear(d);
+            const uint32_t j1 = j0 + 6 < count ? j0 + 6 : count;
+            for (uint32_t j = j0; j < j1; j++) Fr29::dot_add(d, Fr29::from32<0>(load_u256(polys[j], i)), Fr29::from32<0>(load_u256(scalars32, j)));
+            total = Fr29::carry(Fr29::add(total, Fr29::dot_reduce(d)));              // every chunk adds less than 1.3 p
+            if ((++chunks & 15u) == 0) total = Fr29::reduce_small(total);            // (below 32 p at all times)
         }
-        if (j < count) acc = Fr::red2p(Fr::add_lazy(acc, Fr::mul_lazy(load_u256(polys[j], i), load_u256(scalars, j))));
-        store_u256(out, i, Fr::normalize(acc));
+        store_u256(out, i, Fr::normalize(Fr29::to32(Fr29::reduce_small(total))));
     }
 }
 
@@ -243,7 +261,14 @@ int fr_lincomb(zk_ctx* ctx, const void* const* polys, const void* scalars, size_
     char* base = (char*)ctx->ws_tmp.p;
     hipStream_t st = ctx->stream;
     ZK_HIP(hipMemcpyAsync(base, polys, count * sizeof(void*), hipMemcpyHostToDevice, st));
-    ZK_HIP(hipMemcpyAsync(base + off_sc, scalars, count * 32, hipMemcpyHostToDevice, st));
+    std::vector<u256> sc32(count);                                   // the kernel multiplies on 29-bit limbs (Montgomery radix 2^261): scalars as x 2^261 operands
+    {
+        u256 c32 = Fr::zero();
+        c32.v[0] = 32;
+        c32 = Fr::to_mont(c32);
+        for (size_t j = 0; j < count; j++) { u256 v; memcpy(&v, (const char*)scalars + 32 * j, 32); sc32[j] = Fr::mul(v, c32); }
+    }
+    ZK_HIP(hipMemcpyAsync(base + off_sc, sc32.data(), count * 32, hipMemcpyHostToDevice, st));
     const int blk = ctx->tune.vec_block;
     size_t grid = (n + blk - 1) / blk; if (grid > 8192) grid = 8192;
     ZK_LAUNCH(pe_lincomb_kernel, (uint32_t)grid, blk, 0, st, (const void* const*)base, (const void*)(base + off_sc), (uint32_t)count, n, d_out);

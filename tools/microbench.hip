@@ -313,6 +313,85 @@ static double run(const char* name, K kern, double ops_per_thread, int block, in
     return rate;
 }
 
+// ---- round 4, VERDICT r3 item 4: Montgomery REDUCTION on the matrix cores? -----------------------------------------------------------------------------------------------
+// Two of a Montgomery product's three multiplications have constant operands (m = T p' mod R, then m p), so they can be written as products of the data's BYTES with
+// constant Toeplitz matrices: for the 64 elements of a wave, D[column][element] = Toeplitz(p)[64 x 32] x bytes(m)[32 x 64] is four v_mfma_i32_32x32x32_i8 (with the data as
+// the B operand the 64 column sums of an element come out in the element's own lane pair: a v_permlane32_swap per register, no LDS transposition).  The matrix pipe is idle
+// in every kernel of this library and runs beside the VALU — but what it hands back is 64 byte-column sums per element (each below 2^21, at bit offset 8 c) that the VALU must
+// fold into nine 29-bit limbs again, plus the byte extraction of m and the lane swaps.  The go / no-go question is therefore a VALU one and needs no MFMA to answer:
+//   k_mp_mads        the m p block as the library does it today: 81 v_mad_u64_u32 with p's limbs as scalar operands + the 9 v_mul_lo that make m, 16 shifts
+//   k_mfma_recombine the VALU work that would REMAIN with m p on the matrix cores: m's bytes out of its limbs (B operand), 16 lane swaps, 64 column sums shifted and
+//                    added into 64-bit accumulators and cut into limbs — with the column sums faked by cheap VALU ops (the MFMA itself is free here: an upper bound in favour
+//                    of the matrix route).  m must then be known BEFORE the product (today it falls out of the column scan), so its 45-mad half product is charged too.
+// If k_mfma_recombine is not clearly faster than k_mp_mads the route is dead whatever the MFMA costs.
+__global__ void k_mp_mads(uint32_t* out, uint32_t seed) {
+    u261 t;
+    for (int i = 0; i < 9; i++) t.l[i] = (threadIdx.x * 2654435761u + seed + i * 0x9e3779b9u) & Fq29::M29;
+    uint32_t sink = 0;
+    for (int it = 0; it < ITER / 8; it++) {
+        uint64_t acc = t.l[0];
+        uint32_t m[9];
+#pragma unroll
+        for (int k = 0; k < 17; k++) {                                // the reduction half of field29_mul_body.inc: m_k from the running column, then m * p down the columns
+#pragma unroll
+            for (int i = (k > 8 ? k - 8 : 0); i < (k < 9 ? k : 9); i++) acc += (uint64_t)m[i] * Fq29::p29(k - i);
+            if (k < 9) { m[k] = ((uint32_t)acc * Fq29::INV29) & Fq29::M29; acc += (uint64_t)m[k] * Fq29::p29(0); acc += t.l[k < 8 ? k + 1 : 0]; }
+            else t.l[k - 9] = (uint32_t)acc & Fq29::M29;
+            acc >>= 29;
+        }
+        t.l[8] = (uint32_t)acc;
+        sink ^= t.l[3];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sink ^ t.l[0] ^ t.l[8];
+}
+__global__ void k_mfma_recombine(uint32_t* out, uint32_t seed) {
+    u261 t;
+    for (int i = 0; i < 9; i++) t.l[i] = (threadIdx.x * 2654435761u + seed + i * 0x9e3779b9u) & Fq29::M29;
+    uint32_t sink = 0;
+    for (int it = 0; it < ITER / 8; it++) {
+        // (1) m = T p' mod 2^261 ahead of the product: the low half of a 9 x 9 limb product, 45 multiply-adds
+        uint32_t m[9];
+        {
+            uint64_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+#pragma unroll
+                for (int i = 0; i <= k; i++) acc += (uint64_t)t.l[i] * Fq29::p29(k - i);      // (p' has limbs like p's: any constant serves the timing)
+                m[k] = (uint32_t)acc & Fq29::M29;
+                acc >>= 29;
+            }
+        }
+        // (2) the B operand: m as 33 bytes in 9 registers -> 8 packed words (v_alignbit / shifts), then the other half-wave's registers through v_permlane32_swap
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int bit = 32 * j, i = bit / 29, sh = bit % 29;
+            uint64_t v = (uint64_t)m[i] >> sh;
+            if (i + 1 < 9) v |= (uint64_t)m[i + 1] << (29 - sh);
+            if (i + 2 < 9 && 58 - sh < 32) v |= (uint64_t)m[i + 2] << (58 - sh);
+            w[j] = (uint32_t)v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = __builtin_amdgcn_ds_bpermute(((threadIdx.x ^ 32u) & 63u) << 2, w[j]) ^ w[j];     // (stands in for 8 of the 16 v_permlane32_swap: same issue cost class)
+        // (3) 64 column sums S_c (< 2^21) at bit offsets 8 c, as the MFMA would leave them; here: cheap functions of the operand words
+        // (4) fold them into 64-bit accumulators limb by limb: one shift-add per column, one mask + one shift per limb
+        uint64_t acc = 0;
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (; c < 64 && 8 * c < 29 * (k + 1); c++) {
+                const uint32_t S = (w[c & 7] >> (c >> 3)) & 0x1fffffu;
+                acc += (uint64_t)S << (8 * c - 29 * k);
+            }
+            t.l[k] = ((uint32_t)acc & Fq29::M29) ^ (k < 8 ? 0u : 0u);
+            acc >>= 29;
+        }
+        sink ^= t.l[5] + (uint32_t)acc;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sink ^ t.l[0] ^ t.l[8];
+}
+
 // ---- FETCH_SIZE calibration on this repo's own access patterns (MI355X_MICROARCH.md, HBM: "other access widths are uncalibrated: calibrate on a known byte count in your own
 // access pattern").  `microbench --gather64` / `--stream32` run ONE kernel each with a known byte count, to be read next to `rocprofv3 --pmc FETCH_SIZE`:
 //   gather64: every lane reads ONE 64-byte table point (4 x 16 B, as msm_accumulate_kernel gathers its affine points) at a pseudo-random index of a 512 MiB table;
@@ -399,6 +478,12 @@ int main(int argc, char** argv) {
         run("fq29_sqr", k_sqr29, 2.0 * (ITER / 4), 256, bpc);
         run("fq29_mul_shoup (constant operand, precomputed quotient)", k_shoup29, 2.0 * (ITER / 4), 256, bpc);
         run("fq_addsub", k_fqadd, 2.0 * ITER, 256, bpc);
+    }
+    printf("-- round 4: the m*p block of a Montgomery reduction on the VALU vs the VALU work that a matrix-core (i8 MFMA, constant Toeplitz operand) formulation would leave behind\n");
+    for (int bpc : {2, 4}) {
+        const double a = run("montgomery_mp_81_mads", k_mp_mads, 1.0 * (ITER / 8), 256, bpc);
+        const double b = run("mfma_route_valu_residue", k_mfma_recombine, 1.0 * (ITER / 8), 256, bpc);
+        printf("   VALU residue of the MFMA route / today's m*p block: %.2f x the time (> ~0.75: no-go, the matrix cores cannot pay for the recombination)\n", a / b);
     }
     for (int bpc : {1, 2, 4}) run("xyzz_madd", k_madd, 1.0 * (ITER / 8), 256, bpc);
     for (int bpc : {1, 2, 4}) run("xyzz_madd_lazy", k_madd_lazy, 1.0 * (ITER / 8), 256, bpc);

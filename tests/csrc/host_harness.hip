@@ -66,6 +66,10 @@ void hh_fq_lazy(int op, const u256* a, const u256* b, const u256* c, const u256*
             case 8: o[i] = Fq::sub_lazy(a[i], b[i]); break;
             case 9: o[i] = Fq::normalize(a[i]); break;
             case 10: o[i] = Fq::zero(); o[i].v[0] = Fq::is_zero_mod(a[i]) ? 1 : 0; break;
+            case 14: o[i] = Fq::shoup_quotient(a[i]); break;                // floor(w 2^256 / p) from w's library form
+            case 15: o[i] = Fr::shoup_quotient(a[i]); break;
+            case 12: o[i] = Fq::mul_shoup_lazy(a[i], b[i], c[i]); break;   // a * w with wq = floor(w 2^256 / p): no Montgomery factor, [0, 2p)
+            case 13: o[i] = Fr::mul_shoup_lazy(a[i], b[i], c[i]); break;
             default: o[i] = Fq::mul(a[i], b[i]); break;              // 11: the full product on inputs up to 4p
         }
     }

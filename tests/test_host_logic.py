@@ -139,6 +139,15 @@ def test_redundant_range_arithmetic_on_the_range_boundaries(hh, orc, pyref):
         assert got == (1 if a % q == 0 else 0)
     for got, a, b in zip(run(11, r4, canon), r4, canon):              # the full product accepts a redundant left operand (ntt_post)
         assert got == a * b * Rinv % q
+    # mul_shoup_lazy (the final NTT pass's twiddle products): a * w mod p, no Montgomery factor, for ANY a below 2^256 (the butterflies hand it [0, 4p)) and canonical w
+    # with wq = floor(w 2^256 / p); result in [0, 2p).  Both fields; the edges of a's range and w in {0, 1, p - 1, ...} included.
+    for op, mod in ((12, pyref.P), (13, pyref.R)):
+        ws = [0, 1, 2, mod - 1, mod - 2, (mod + 1) // 2] + [rnd.randrange(mod) for _ in range(300)]
+        As = [0, 1, mod - 1, mod, 2 * mod - 1, 2 * mod, 4 * mod - 1, (1 << 256) - 1] + [rnd.randrange(4 * mod) for _ in range(200)] + [rnd.randrange(1 << 256) for _ in range(98)]
+        wqs = [w * (1 << 256) // mod for w in ws]
+        assert run(op + 2, [w * (1 << 256) % mod for w in ws]) == wqs                               # shoup_quotient: from w's library form, exact
+        for got, a, w in zip(run(op, As, ws, wqs), As, ws):
+            assert got < 2 * mod and got % mod == a * w % mod, (op, a, w)
 
 
 def test_lazy_mixed_addition_chain_equals_the_canonical_one(hh, orc, pyref):

@@ -249,6 +249,63 @@ struct Field {
         return reduce_once(r);
     }
 
+    // a * w mod p for a CONSTANT w (an NTT twiddle): w as its canonical integer, wq = floor(w 2^256 / p) precomputed (Shoup; Harvey's lazy butterflies).  q = floor(a wq / 2^256)
+    // is the true quotient of a w by p or up to two below it for any a below 2^256 (one from wq's truncation, one from the columns 0 .. 5 of a * wq that are not computed),
+    // so r = a w - q p, read off the low 256 bits of a w + q (2^256 - p), lies in [0, 3p) and one conditional subtraction of 2p returns [0, 2p) — mul_lazy's range, from 115
+    // partial products instead of 128 + 8, with NO Montgomery factor: a value in the library's form stays in it.  field_shoup{q,r}_body.inc (tools/gen_mac.py).
+    static ZK_HD constexpr uint32_t np(int i) {                        // limb i of 2^256 - p
+        uint64_t borrow = 0, limb = 0;
+        for (int j = 0; j <= i; j++) {                                 // 0 - p, limb by limb (the minuend 2^256 shows only as the final borrow)
+            const uint64_t pj = p(j);
+            limb = (0x100000000ull - pj - borrow) & 0xffffffffull;
+            borrow = (pj + borrow) ? 1 : 0;
+        }
+        return (uint32_t)limb;
+    }
+    // wq = floor(w 2^256 / p) from w's library form w_lib = w 2^256 mod p: w 2^256 = wq p + w_lib, so wq = -w_lib p^-1 mod 2^256 (a low-half product; table builds only)
+    struct Limbs8 { uint32_t l[8]; };
+    static constexpr Limbs8 pinv256() {                                // p^-1 mod 2^256 by Hensel lifting on 32-bit limbs: x <- x (2 - p x), the precision doubling each step
+        uint32_t x[8] = {1, 0, 0, 0, 0, 0, 0, 0};                      // p is odd: correct to 1 bit
+        for (int it = 0; it < 9; it++) {
+            uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 8; i++) {                              // t = p x mod 2^256
+                uint64_t c = 0;
+                for (int j = 0; i + j < 8; j++) { c += (uint64_t)p(i) * x[j] + t[i + j]; t[i + j] = (uint32_t)c; c >>= 32; }
+            }
+            uint64_t br = 0;                                           // t = 2 - t
+            for (int i = 0; i < 8; i++) { const uint64_t m = (i == 0 ? 2ull : 0ull), s_ = (uint64_t)t[i] + br; t[i] = (uint32_t)(m - s_); br = m < s_ ? 1 : 0; }
+            for (int i = 0; i < 8; i++) {                              // u = x t mod 2^256
+                uint64_t c = 0;
+                for (int j = 0; i + j < 8; j++) { c += (uint64_t)x[i] * t[j] + u[i + j]; u[i + j] = (uint32_t)c; c >>= 32; }
+            }
+            for (int i = 0; i < 8; i++) x[i] = u[i];
+        }
+        Limbs8 o{};
+        for (int i = 0; i < 8; i++) o.l[i] = x[i];
+        return o;
+    }
+    static ZK_HD u256 shoup_quotient(const u256& w_lib) {
+        constexpr Limbs8 pi = pinv256();
+        uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 8; i++) {                                  // t = w_lib p^-1 mod 2^256
+            uint64_t c = 0;
+            for (int j = 0; i + j < 8; j++) { c += (uint64_t)w_lib.v[i] * pi.l[j] + t[i + j]; t[i + j] = (uint32_t)c; c >>= 32; }
+        }
+        u256 o;
+        uint64_t br = 0;                                               // o = -t mod 2^256
+        for (int i = 0; i < 8; i++) { const uint64_t s_ = (uint64_t)t[i] + br; o.v[i] = (uint32_t)(0ull - s_); br = s_ ? 1 : 0; }
+        return o;
+    }
+    static ZK_HD u256 mul_shoup_lazy(const u256& a, const u256& w, const u256& wq) {
+        uint64_t acc = 0;
+        uint32_t cnt = 0;
+        uint32_t q[8];
+        u256 r;
+#include "field_shoupq_body.inc"
+#include "field_shoupr_body.inc"
+        return red2p(r);
+    }
+
     // a * R^-1: the Montgomery reduction alone (64 m_i*p_j products; a product with the constant 1 would spend 128) — field_redc_body.inc
     static ZK_HD u256 from_mont(const u256& a) {
         uint64_t acc = 0;

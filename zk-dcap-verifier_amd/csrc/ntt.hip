@@ -115,7 +115,10 @@ ZK_HD uint32_t tile_at(uint32_t row, uint32_t col, uint32_t r, uint32_t c_log) {
 // and an LDS read returns in ~50 cycles where the L2 hit of a global load takes 200+)
 __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r, uint32_t c_log, const uint4* stage_tw, bool quarter_input) {
     const uint32_t C = 1u << c_log;
-    auto tw_at = [&](size_t i) { const uint4 l = stage_tw[2 * i], h = stage_tw[2 * i + 1]; u256 o; o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w; return o; };
+    // stage_tw holds Shoup pairs, 64 bytes per twiddle: the canonical integer w | wq = floor(w 2^256 / p) — Fr::mul_shoup_lazy: 115 partial products against 136, [0, 2p) out
+    // like mul_lazy, no Montgomery factor (a tile value stays in the library's form)
+    auto half_at = [&](size_t i) { const uint4 l = stage_tw[2 * i], h = stage_tw[2 * i + 1]; u256 o; o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w; return o; };
+    auto mul_tw = [&](const u256& x, size_t i) { return Fr::mul_shoup_lazy(x, half_at(2 * i), half_at(2 * i + 1)); };
     uint32_t s = 0;
     if (quarter_input && r >= 2) {
         // coeff_to_extended with extended_k >= k + 2: rows >= R/4 of the first pass are the zero padding, i.e. (rows are stored bit-reversed) only
@@ -144,9 +147,10 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
             const uint32_t i0 = tile_at(rb, col, r, c_log), i1 = tile_at(rb + h, col, r, c_log), i2 = tile_at(rb + 2 * h, col, r, c_log), i3 = tile_at(rb + 3 * h, col, r, c_log);
             u256 x0 = lds_get(lo, hi, i0), x1 = lds_get(lo, hi, i1), x2 = lds_get(lo, hi, i2), x3 = lds_get(lo, hi, i3);
             if (pos) {
-                const u256 w1 = tw_at((size_t)pos << (r - 1 - s));
-                x1 = Fr::mul_lazy(x1, w1);
-                x3 = Fr::mul_lazy(x3, w1);
+                const size_t i1 = (size_t)pos << (r - 1 - s);
+                const u256 w1 = half_at(2 * i1), w1q = half_at(2 * i1 + 1);
+                x1 = Fr::mul_shoup_lazy(x1, w1, w1q);
+                x3 = Fr::mul_shoup_lazy(x3, w1, w1q);
             } else {
                 x1 = Fr::red2p(x1);
                 x3 = Fr::red2p(x3);
@@ -155,8 +159,8 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
             x2 = Fr::red2p(x2);
             const u256 t0 = Fr::red2p(Fr::add_lazy(x0, x1)), t1 = Fr::red2p(Fr::sub_lazy(x0, x1));
             u256 t2 = Fr::add_lazy(x2, x3), t3 = Fr::sub_lazy(x2, x3);
-            t2 = pos ? Fr::mul_lazy(t2, tw_at((size_t)pos << (r - 2 - s))) : Fr::red2p(t2);
-            t3 = Fr::mul_lazy(t3, tw_at((size_t)(pos + h) << (r - 2 - s)));
+            t2 = pos ? mul_tw(t2, (size_t)pos << (r - 2 - s)) : Fr::red2p(t2);
+            t3 = mul_tw(t3, (size_t)(pos + h) << (r - 2 - s));
             lds_put(lo, hi, i0, Fr::add_lazy(t0, t2));
             lds_put(lo, hi, i1, Fr::add_lazy(t1, t3));
             lds_put(lo, hi, i2, Fr::sub_lazy(t0, t2));
@@ -174,7 +178,7 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
             const uint32_t i0 = tile_at(rb, col, r, c_log), i1 = tile_at(rb + half, col, r, c_log);
             const u256 x = Fr::red2p(lds_get(lo, hi, i0));
             u256 y = lds_get(lo, hi, i1);
-            y = pos ? Fr::mul_lazy(y, tw_at((size_t)pos << (r - 1 - s))) : Fr::red2p(y);
+            y = pos ? mul_tw(y, (size_t)pos << (r - 1 - s)) : Fr::red2p(y);
             lds_put(lo, hi, i0, Fr::add_lazy(x, y));
             lds_put(lo, hi, i1, Fr::sub_lazy(x, y));
         }
@@ -412,8 +416,8 @@ ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
     const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
     uint4* lo = smem;
     uint4* hi = smem + tile;
-    uint4* twl = smem + 2 * tile;
-    for (uint32_t e = threadIdx.x; e < R; e += blockDim.x) twl[e] = reinterpret_cast<const uint4*>(a.stage_tw)[e];
+    uint4* twl = smem + 2 * tile;                                  // R/2 Shoup pairs of stage twiddles, 4 x uint4 each
+    for (uint32_t e = threadIdx.x; e < 2 * R; e += blockDim.x) twl[e] = reinterpret_cast<const uint4*>(a.stage_sh)[e];
     const uint32_t t = blockIdx.x;
     const uint32_t jm = t & ((1u << a.p_log) - 1);
     const uint32_t j10 = (t >> a.p_log) << a.c_log;
@@ -452,6 +456,15 @@ ZK_KERNEL void ntt_shoup_table_kernel(const void* tw_lib, uint32_t count, void* 
     uint32_t* o = reinterpret_cast<uint32_t*>(out) + (size_t)20 * k;
     for (int i = 0; i < 9; i++) { o[i] = wl.l[i]; o[9 + i] = wq.l[i]; }
     o[18] = o[19] = 0;
+}
+
+// ... and of the final pass's (32-bit form): entry k = the canonical integer w_k | floor(w_k 2^256 / p), 64 bytes
+ZK_KERNEL void ntt_shoup32_table_kernel(const void* tw_lib, uint32_t count, void* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const u256 wl = load_u256(tw_lib, k);
+    store_u256(out, 2 * (size_t)k, Fr::from_mont(wl));
+    store_u256(out, 2 * (size_t)k + 1, Fr::shoup_quotient(wl));
 }
 
 // full inter-pass twiddle table of a non-final pass: out[row * cols + m] = omega^((m * row) << sh)
@@ -549,7 +562,12 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, const u2
         ZK_HIP(hipMalloc(&ts.d_stage[i], (size_t)half * 32));
         ZK_LAUNCH(fr_pow_table_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, fr_pow2k_host(omega, log_n - rl[i]), half, ts.d_stage[i]);
         ZK_CHECK_LAUNCH();
-        if (i + 1 == passes) continue;                                // (the final pass stays on the 32-bit form: a 29-bit Shoup final pass measured the same, profiles/r04)
+        if (i + 1 == passes) {                                        // the final pass stays on the 32-bit form (a 29-bit Shoup final pass measured the same as the 32-bit Montgomery one,
+            ZK_HIP(hipMalloc(&ts.d_stage_sh[i], (size_t)half * 64));  // profiles/r04) and multiplies with 32-bit Shoup pairs
+            ZK_LAUNCH(ntt_shoup32_table_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, (const void*)ts.d_stage[i], half, ts.d_stage_sh[i]);
+            ZK_CHECK_LAUNCH();
+            continue;
+        }
         // the strided passes multiply with Shoup pairs of these twiddles — and, in the last step of a radix above 2^6, with their x 2^261 Montgomery forms
         ZK_HIP(hipMalloc(&ts.d_stage_sh[i], (size_t)half * 80));
         ZK_LAUNCH(ntt_shoup_table_kernel, (half + blk - 1) / blk, blk, 0, ctx->stream, (const void*)ts.d_stage[i], half, ts.d_stage_sh[i]);
@@ -699,7 +717,7 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             a.p_log = P == 3 ? ts->radix_log[1] : 0;
             a.c_log = room < a.q_log ? room : a.q_log;
             const uint32_t grid = (uint32_t)(N >> (a.r + a.c_log));
-            const size_t lds = ((size_t)32 << (a.r + a.c_log)) + ((size_t)16 << a.r);   // tile (two planes) + R/2 stage twiddles
+            const size_t lds = ((size_t)32 << (a.r + a.c_log)) + ((size_t)32 << a.r);   // tile (two planes) + R/2 Shoup pairs of stage twiddles (64 bytes each)
             ZK_LAUNCH(ntt_final_pass_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();
             if (via_tmp)

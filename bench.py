@@ -713,9 +713,9 @@ def main(argv=None):
                 traffic = {"raw": None, "doubled_fetch": tjd.get("msm_accumulate_bytes_per_launch")}
         except Exception:
             traffic = None
-    # The bucket step in the kernel that ran: on carry-free 29-bit limbs (msm_limb29, the default since round 3: 1467 v_mad_u64_u32, no addc, ~650 other VALU instructions per
+    # The bucket step in the kernel that ran: on carry-free 29-bit limbs (the only form since round 4: 1467 v_mad_u64_u32, no addc, ~650 other VALU instructions per
     # mixed addition — the kernel's own ISA census) or round 2's 32-bit redundant form (1160 mad + addc pairs + ~700 others).
-    limb29 = bool(be.tune_get("msm_limb29")) if hasattr(be, "tune_get") else True
+    limb29 = True
     # register-loop rate of the same step (tools/microbench, 4 blocks per CU: profiles/r03/run93_microbench_mad_issue_rate.txt) ...
     XYZZ_MADD_PEAK = 17.70e9 if limb29 else 13.84e9
     # ... and an integer bound that owes nothing to this repo's loops: instruction ISSUE rates measured on the box — v_mad_u64_u32 with 12 independent accumulators
@@ -824,7 +824,7 @@ def main(argv=None):
                                          "commitments": wls2[0].info["commitments"], "proof_bytes": len(wls2[0].proof),
                                          "shape": f"A={wls2[0].A} F={wls2[0].F} L={wls2[0].L} perm_columns={wls2[0].n_perm} degree={wls2[0].d}"}
             census2 = (wls2[0].pk.vk, [w_.proof for w_ in wls2])       # verified by the CPU leg
-            for w_ in wls2:
+            for w_ in reversed(wls2):                                  # (borrowers of the shared key first, its owner last)
                 for d_ in w_.master + w_.work:
                     d_.free()
                 w_.pk.release()

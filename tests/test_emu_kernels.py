@@ -193,13 +193,3 @@ def test_ntt_with_two_level_inter_pass_twiddles(emu, orc, pyref):
         pc.check_domain(emu, orc, pyref, 9, 3)
     finally:
         emu.tune(ntt_full_twiddle_max_log=24)
-
-
-def test_msm_on_the_32_bit_bucket_chain(emu, orc, pyref):
-    """msm_limb29 = 0: round 2's bucket accumulation (8 x 32-bit redundant form) stays selectable; same group elements"""
-    emu.tune(msm_limb29=0)
-    try:
-        for n in (5, 200, 700):
-            pc.check_msm(emu, orc, pyref, n, seed=900 + n)
-    finally:
-        emu.tune(msm_limb29=1)

@@ -201,12 +201,3 @@ def test_ntt_with_two_level_inter_pass_twiddles(gpu, orc, pyref):
         pc.check_domain(gpu, orc, pyref, 5, 12)
     finally:
         gpu.tune(ntt_full_twiddle_max_log=24)
-
-
-def test_msm_on_the_32_bit_bucket_chain(gpu, orc, pyref):
-    gpu.tune(msm_limb29=0)
-    try:
-        for n in (100, 4096, 20000):
-            pc.check_msm(gpu, orc, pyref, n, seed=900 + n)
-    finally:
-        gpu.tune(msm_limb29=1)

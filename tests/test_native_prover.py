@@ -210,6 +210,8 @@ def test_native_provers_on_two_contexts_in_threads(built, orc):
     for t in ts:
         t.join()
     assert out["a"] == out["b"] == [tcp._golden(tcp.GOLDEN_PROOF)] * 2
+    with pytest.raises(RuntimeError):                                 # the owner's columns are still borrowed: it refuses to free them under the borrower
+        pka.release()
     pkb.release()
     assert plonk.NativeProver(pa, pka).create_proof([c.copy() for c in advice], instances, np.random.default_rng(7)) == tcp._golden(tcp.GOLDEN_PROOF)    # the owner is intact
     pka.release()

@@ -27,8 +27,6 @@ struct Tune {
     int msm_merge_fanin = 8;
     int msm_tree_fanin = 2;
     int msm_block = 128;         // threads per workgroup of the curve-arithmetic kernels
-    int msm_limb29 = 1;          // bucket accumulation on carry-free 29-bit limbs (field29.cuh; 0 = the 8 x 32-bit redundant form of round 2)
-    int msm_acc_waves = 4;       // waves per SIMD the 29-bit accumulate kernel is compiled for (4: 128 VGPRs, 3: 168, 2: 256)
     int msm_runs = 1;            // commit run-heavy columns through adjacent differences against the prefix-sum table (when the table has one)
     int ntt_tile_log = 10;       // log2(elements) of the LDS tile of one NTT workgroup (sweep: profiles/r01/run6_ntt_plan_sweep.txt)
     int ntt_threads = 256;

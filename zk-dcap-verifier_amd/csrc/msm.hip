@@ -530,9 +530,8 @@ ZK_KERNEL void msm_scan_apply_kernel(MsmPlan p) {
 // ------------------------------------------------------------------------------------------------
 // bucket accumulation: one thread per sub-bucket (<= L references), XYZZ mixed additions
 // ------------------------------------------------------------------------------------------------
-// LIMB29 = 1: the chain runs on carry-free 29-bit limbs (ec.cuh xyzz29_madd, field29.cuh) — the same group elements, fewer VALU instructions per product
-template <int LIMB29, int WPE>
-ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(WPE) msm_accumulate_kernel(MsmPlan p) {
+// the chain runs on carry-free 29-bit limbs (ec.cuh xyzz29_madd_fast, field29.cuh); the 32-bit loop behind it finishes a chain that met a rare case
+ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) msm_accumulate_kernel(MsmPlan p) {
     const uint32_t col = blockIdx.y, B = p.B;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t* sm = plan_small(p, col);
@@ -557,7 +556,7 @@ ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(WPE) msm_accumulate_kernel(
     const void* table = p.col_tables ? p.col_tables[col] : p.table;
     Affine pt = load_affine(table, ref & 0x7fffffffu);
     XYZZ acc = xyzz_identity();
-    if (LIMB29) {
+    {
         // the chain on carry-free limbs: the first point enters the 2^261 form, every further point is one xyzz29_madd_fast; the (rare) step that form does not cover —
         // an identity base, a doubling, a cancellation — ends the fast loop and the 32-bit loop below finishes the chain from there
         XYZZ29 a29 = xyzz29_identity();
@@ -1096,10 +1095,7 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     if (blk > 256) return ctx->fail(ZK_ERR_ARG, "msm_block: at most 256 threads per workgroup");
     {
         const dim3 grid((uint32_t)((cap[0] + blk - 1) / blk), nb);
-        if (!tn.msm_limb29) { ZK_LAUNCH((msm_accumulate_kernel<0, 4>), grid, blk, 0, st, p); }
-        else if (tn.msm_acc_waves == 3) { ZK_LAUNCH((msm_accumulate_kernel<1, 3>), grid, blk, 0, st, p); }
-        else if (tn.msm_acc_waves == 2) { ZK_LAUNCH((msm_accumulate_kernel<1, 2>), grid, blk, 0, st, p); }
-        else { ZK_LAUNCH((msm_accumulate_kernel<1, 4>), grid, blk, 0, st, p); }
+        ZK_LAUNCH(msm_accumulate_kernel, grid, blk, 0, st, p);
     }
     ZK_CHECK_LAUNCH();
     t_acc.stop();

@@ -57,6 +57,8 @@ class ProvingKey:
     lookup_compressors: list = field(default_factory=list)   # per lookup: (input Evaluator, table Evaluator) over the 2^k rows
     coset_parts: Optional[dict] = None   # params.by_cosets(): coset j -> {"fixed", "sigma", "l"}: the 2^k values of that coset only (this rank's cosets)
     borrowed: bool = False               # shared_with(): the columns belong to another ProvingKey of the process (same GPU); only the program handles are this key's
+    owner: Optional["ProvingKey"] = None  # shared_with(): whose columns these are
+    borrowers: int = 0                   # keys of other contexts that share this key's columns (an owner with borrowers refuses release())
     pieces_from_cosets: bool = False     # one GPU, cs_degree - 1 < 2^(extended_k - k): coset_parts holds cosets 0 .. cs_degree-2 and there are NO extended forms — the prover
                                          # evaluates h(X)'s numerator on those cosets only and takes the pieces from zk_cosets_to_pieces_dev
 
@@ -68,16 +70,23 @@ class ProvingKey:
         assert other.coset_parts is None or other.pieces_from_cosets, "sharded keys are per rank"
         ev_ = ev.Evaluator.shared(other.evaluator, backend)
         comps = [(ev.Evaluator.shared(a, backend), ev.Evaluator.shared(b, backend)) for a, b in other.lookup_compressors]
+        root = other.owner or other
+        root.borrowers += 1
         return cls(other.vk, EvaluationDomain(other.vk.cs.degree(), other.vk.k, backend=backend), backend, other.fixed_values, other.fixed_polys, other.fixed_cosets,
                    other.sigma_values, other.sigma_polys, other.sigma_cosets, other.l0, other.l_last, other.l_active_row, ev_, other.program, comps, other.coset_parts, True,
-                   other.pieces_from_cosets)
+                   owner=root, pieces_from_cosets=other.pieces_from_cosets)
 
     def release(self):
+        if not self.borrowed and self.borrowers:
+            raise RuntimeError(f"ProvingKey.release: {self.borrowers} borrowed key(s) still share these columns (shared_with): release them first")
         self.evaluator.release()
         for a, b in self.lookup_compressors:
             a.release()
             b.release()
         if self.borrowed:
+            if self.owner is not None:
+                self.owner.borrowers -= 1
+                self.owner = None
             return
         for grp in (self.fixed_values, self.fixed_polys, self.fixed_cosets, self.sigma_values, self.sigma_polys, self.sigma_cosets,
                     [d for d in (self.l0, self.l_last, self.l_active_row) if d is not None],
@@ -218,4 +227,4 @@ def keygen(params: ParamsKZG, cs: ConstraintSystem, fixed_columns, assembly: Opt
     evaluator = ev.Evaluator(program, backend=be)
     comps = [(_compressor(cs, k, lk.input_expressions, be), _compressor(cs, k, lk.table_expressions, be)) for lk in cs.lookups]
     return ProvingKey(vk, dom, be, fixed_values, fixed_polys, fixed_cosets, sigma_values, sigma_polys, sigma_cosets,
-                      lcosets[0], lcosets[1], lcosets[2], evaluator, program, comps, coset_parts, False, pieces_from_cosets)
+                      lcosets[0], lcosets[1], lcosets[2], evaluator, program, comps, coset_parts, False, pieces_from_cosets=pieces_from_cosets)

@@ -23,9 +23,29 @@ def _check(be, orc, pyref, k, e, seed):
     assert (out.download((n << e, 4)) == full[1]).all()
 
 
-@pytest.mark.parametrize("k,e", [(4, 1), (5, 2), (6, 3)])
+@pytest.mark.parametrize("k,e", [(4, 1), (5, 2), (6, 3), (7, 2), (8, 1), (9, 3)])      # above the fixture's tile (2^6) a coset transform takes its pre-scaling from ONE table (ntt_coset_table)
 def test_emulated_cosets(emu, orc, pyref, k, e):
     _check(emu, orc, pyref, k, e, seed=k)
+
+
+def test_emulated_coset_table_on_and_off(emu, orc, pyref):
+    """the pre-scaling table of a coset transform against the two-level powers it replaces: the same values, coset by coset"""
+    k, e = 8, 2
+    n = 1 << k
+    d = [emu.to_device(pc.rand_fr(orc, pyref, n, 90 + i)) for i in range(2)]
+    got = {}
+    try:
+        for mode in (1, 0):
+            emu.tune(ntt_coset_table=mode)
+            for j in range(1 << e):
+                outs = [emu.alloc(n * 32) for _ in d]
+                emu.coeff_to_coset_batch_dev(d, outs, k, k + e, j)
+                got[mode, j] = [o.download((n, 4)) for o in outs]
+    finally:
+        emu.tune(ntt_coset_table=1)
+    for j in range(1 << e):
+        for a, b in zip(got[1, j], got[0, j]):
+            assert (a == b).all(), j
 
 
 @pytest.mark.gpu

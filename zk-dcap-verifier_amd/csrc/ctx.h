@@ -31,6 +31,7 @@ struct Tune {
     int ntt_tile_log = 10;       // log2(elements) of the LDS tile of one NTT workgroup (sweep: profiles/r01/run6_ntt_plan_sweep.txt)
     int ntt_threads = 256;
     int ntt_max_radix_log = 8;
+    int ntt_coset_table = 1;             // coset transforms of two passes and more: the pre-scaling ZETA^(m mod 3) * ext_omega^(coset * m) from ONE table per coset (32 B/element, one product) instead of two-level powers (up to 2.67 products)
     int ntt_full_twiddle_max_log = 24;   // up to this size inter-pass twiddles come from full HBM tables (32 B/element/pass)
     int ntt_ws_limit_mb = 24576; // a batched transform's out-of-place workspace (columns x N x 32 B) is capped here: larger batches run in slices of columns (k >= 22)
     int ntt_fuse_scale = 1;      // the 1/n of an inverse transform rides on the last strided pass's inter-pass twiddle table (one product per element fewer in the final pass)
@@ -110,6 +111,7 @@ struct zk_ctx {
     uint64_t next_handle = 1;
     std::map<uint64_t, zk::BaseTable> bases;
     std::vector<zk::TwiddleSet> twiddles;
+    std::map<uint64_t, void*> coset_tables;                           // ntt.hip: (k, extended_k, coset) -> pre-scaling table of a coset transform
     std::map<uint64_t, std::shared_ptr<zk::QuotProgram>> programs;   // compiled micro-programs are immutable once loaded: contexts of one device may share them (zk_quotient_program_share)
     std::map<uint64_t, std::vector<uint32_t>> lookup_tie_hint;   // lookupperm.hip: columns whose rows tied on the sort window in the previous call of the same shape
     // workspaces (grow-only)
@@ -185,6 +187,7 @@ struct NttFuse {              // optional fused pre/post operations (EvaluationD
     u256 scale;
     int post_zeta_inv = 0;     // output i *= ZETA^-(i mod 3)          (extended_to_coeff)
     const void* cs_lo = nullptr; const void* cs_hi = nullptr; uint32_t cs_lo_bits = 0, cs_stride = 0, cs_log = 0;   // coset pre-scaling (ntt.hip)
+    const void* pre_full = nullptr;   // the same pre-scaling AND pre_zeta as one table of operands x 2^261 (transforms whose first pass runs on 29-bit limbs take it instead)
 };
 int ntt_dev(zk_ctx* ctx, void* d_a, uint32_t log_n, const u256& omega, const NttFuse* fuse);
 void release_twiddles(zk_ctx* ctx);

@@ -42,6 +42,7 @@ struct NttPassArgs {
     // first pass only: input i *= w^((cs_stride * i) mod 2^cs_log) with w's two-level power tables (coset NTT: w = extended_omega, stride = coset)
     const void* cs_lo; const void* cs_hi; uint32_t cs_lo_bits; uint32_t cs_stride; uint32_t cs_log;
     int pre_zeta;
+    const void* pre_full;   // first pass on 29-bit limbs only: [i] = 32 * ZETA^(i mod 3) * w^(cs_stride * i), replaces pre_zeta and the cs_ powers
     int post_scale;
     int post_zeta_inv;
     u256 scale;
@@ -329,6 +330,7 @@ __device__ __forceinline__ void ntt_tile_stages29(const Tile29& t, uint32_t r, u
 ZK_HD u261 ntt_load_input29(const NttPassArgs& a, size_t idx) {
     if (a.n_valid && idx >= a.n_valid) return Fr29::zero();
     u261 v = Fr29::from32<0>(load_u256(a.src, idx));
+    if (a.pre_full) return Fr29::mul(v, Fr29::from32<0>(load_u256(a.pre_full, idx)));           // one product for the whole pre-scaling (ntt_coset_table)
     if (a.pre_zeta) {
         const uint32_t m = (uint32_t)idx % 3u;
         if (m) v = Fr29::mul(v, Fr29::from32<0>(m == 1 ? a.zeta29[0] : a.zeta29[1]));    // (no runtime index into the argument block: that would send it to scratch)
@@ -604,6 +606,8 @@ void release_twiddles(zk_ctx* ctx) {
         for (int i = 0; i < 3; i++) { if (t.d_stage[i]) (void)hipFree(t.d_stage[i]); if (t.d_stage_sh[i]) (void)hipFree(t.d_stage_sh[i]); if (t.d_stage29[i]) (void)hipFree(t.d_stage29[i]); if (t.d_full[i]) (void)hipFree(t.d_full[i]); }
     }
     ctx->twiddles.clear();
+    for (auto& kv : ctx->coset_tables) (void)hipFree(kv.second);
+    ctx->coset_tables.clear();
 }
 
 int ntt_set_lds_attr() {
@@ -690,6 +694,7 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
         a.log_n = log_n; a.blk_log = blk_log; a.r = ts->radix_log[p];
         a.stage_tw = ts->d_stage[p]; a.stage_sh = ts->d_stage_sh[p]; a.stage_tw29 = ts->d_stage29[p]; a.tw_lo = ts->d_lo; a.tw_hi = ts->d_hi; a.lo_bits = ts->lo_bits; a.tw_full = last ? nullptr : ts->d_full[p];
         if (first && nf.cs_stride) { a.cs_lo = nf.cs_lo; a.cs_hi = nf.cs_hi; a.cs_lo_bits = nf.cs_lo_bits; a.cs_stride = nf.cs_stride; a.cs_log = nf.cs_log; }
+        if (first && !last && nf.pre_full) a.pre_full = nf.pre_full;
         if (first) { a.n_valid = nf.n_valid; a.pre_zeta = nf.pre_zeta; a.quarter_input = tn.ntt_quarter_input && nf.n_valid && (size_t)nf.n_valid * 4 <= N && a.r >= 2; }
         if (last) { a.post_scale = nf.post_scale && !ts->scale_fused; a.post_zeta_inv = nf.post_zeta_inv; a.scale = nf.scale; }
         if (!last) {                                                  // a 29-bit pass takes the constants of its fused operations as x * 2^261
@@ -773,6 +778,33 @@ int domain_coeff_to_extended_batch(zk_ctx* ctx, const void* const* coeffs, void*
     f.n_valid = 1u << k; f.pre_zeta = 1;
     return ntt_dev_batch(ctx, outs, coeffs, count, ek, domain_omega(ek), &f);
 }
+// the pre-scaling of a coset transform as one table: out[m] = 32 * ZETA^(m mod 3) * ext_omega^((coset * m) mod 2^ek), canonical — the operand x 2^261 of the ONE product the first
+// (29-bit) pass then spends on an input, where the two-level powers cost it up to 2.67 (ZETA, lo * hi, value * power).  16 MiB per coset at k = 19, built once per context.
+ZK_KERNEL void ntt_coset_table_kernel(const void* lo, const void* hi, uint32_t lo_bits, uint32_t stride, uint32_t log, u256 z0, u256 z1, u256 z2, uint32_t n, void* out) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const uint32_t e = (stride * m) & ((1u << log) - 1u), h = e >> lo_bits, z = m % 3u;
+    u256 w = load_u256(lo, e & ((1u << lo_bits) - 1u));
+    if (h) w = Fr::mul(w, load_u256(hi, h));
+    store_u256(out, m, Fr::mul(w, z == 0 ? z0 : (z == 1 ? z1 : z2)));
+}
+static int coset_table(zk_ctx* ctx, uint32_t k, uint32_t ek, uint32_t coset, const NttFuse& f, const void** out) {
+    const uint64_t key = ((uint64_t)k << 48) | ((uint64_t)ek << 32) | coset;
+    auto it = ctx->coset_tables.find(key);
+    if (it == ctx->coset_tables.end()) {
+        void* d = nullptr;
+        ZK_HIP(hipMalloc(&d, (size_t)32 << k));
+        u256 c32 = Fr::zero();
+        c32.v[0] = 32;
+        c32 = Fr::to_mont(c32);
+        ZK_LAUNCH(ntt_coset_table_kernel, (uint32_t)((((size_t)1 << k) + 255) / 256), 256, 0, ctx->stream, f.cs_lo, f.cs_hi, f.cs_lo_bits, coset, ek, c32, Fr::mul(zeta_pow(1), c32), Fr::mul(zeta_pow(2), c32),
+                  (uint32_t)1 << k, d);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(d); return ctx->fail(ZK_ERR_HIP, "ntt_coset_table_kernel: launch failed"); }
+        it = ctx->coset_tables.emplace(key, d).first;
+    }
+    *out = it->second;
+    return ZK_OK;
+}
 // evaluations of `count` polynomials (n = 2^k coefficients each) on coset `coset` of the extended domain: out[i] = f(ZETA * ext_omega^(i * 2^(ek-k) + coset)),
 // i.e. every 2^(ek-k)-th entry of coeff_to_extended starting at `coset` — one size-n NTT of f_m * ZETA^(m mod 3) * ext_omega^(coset * m)
 int domain_coeff_to_coset_batch(zk_ctx* ctx, const void* const* coeffs, void* const* outs, size_t count, uint32_t k, uint32_t ek, uint32_t coset) {
@@ -783,6 +815,10 @@ int domain_coeff_to_coset_batch(zk_ctx* ctx, const void* const* coeffs, void* co
         int rc = ntt_pow_tables(ctx, ek, domain_omega(ek), &f.cs_lo, &f.cs_hi, &f.cs_lo_bits);
         if (rc) return rc;
         f.cs_stride = coset; f.cs_log = ek;
+        if (ctx->tune.ntt_coset_table && k > (uint32_t)ctx->tune.ntt_tile_log) {       // (a single-pass transform runs on the 32-bit form: it keeps the powers)
+            rc = coset_table(ctx, k, ek, coset, f, &f.pre_full);
+            if (rc) return rc;
+        }
     }
     return ntt_dev_batch(ctx, outs, coeffs, count, k, domain_omega(k), &f);
 }

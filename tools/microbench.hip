@@ -406,6 +406,18 @@ __global__ void k_gather64(const uint4* table, uint32_t mask, uint32_t per_lane,
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+// the same gather with entries of 80 bytes (two coordinates as nine 29-bit limbs each, 72 bytes, padded to keep 16-byte loads): what a limb-form bucket table would cost the memory side.
+// An 80-byte entry at an 80-byte stride lies across two 64-byte lines in 3 of 4 positions.
+__global__ void k_gather80(const uint4* table, uint32_t mask, uint32_t per_lane, uint32_t* out) {
+    uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u, acc = 0;
+    for (uint32_t i = 0; i < per_lane; i++) {
+        x = x * 1664525u + 1013904223u;
+        const uint4* p = table + (size_t)((x >> 4) & mask) * 5;
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+        acc ^= a.x ^ b.y ^ c.z ^ d.w ^ e.x;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
 __global__ void k_stream32(const uint4* src, size_t n32, uint32_t* out) {
     uint32_t acc = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (size_t)gridDim.x * blockDim.x) {
@@ -418,14 +430,22 @@ static int calibrate(const char* which) {
     const int block = 256, grid = 256 * 8;
     uint32_t* out; CK(hipMalloc(&out, (size_t)grid * block * 4));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    if (!strcmp(which, "--gather64")) {
+    if (!strcmp(which, "--gather80")) {
+        const size_t points = (size_t)1 << 23;
+        uint4* t; CK(hipMalloc(&t, points * 80)); CK(hipMemset(t, 1, points * 80));
+        const uint32_t per_lane = 64;
+        CK(hipEventRecord(a)); hipLaunchKernelGGL(k_gather80, dim3(grid), dim3(block), 0, 0, (const uint4*)t, (uint32_t)(points - 1), per_lane, out); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        const double g = (double)grid * block * per_lane;
+        printf("k_gather80: %.0f gathers of 80 B (random over a 640 MiB table), %.3f ms, %.2f G gathers/s, %.1f GB/s requested\n", g, ms, g / ms / 1e6, g * 80 / ms / 1e6);
+    } else if (!strcmp(which, "--gather64")) {
         const size_t points = (size_t)1 << 23;                                       // 2^23 x 64 B = 512 MiB: the window-expanded table of one SRS at k = 19
         uint4* t; CK(hipMalloc(&t, points * 64)); CK(hipMemset(t, 1, points * 64));
         const uint32_t per_lane = 64;
         CK(hipEventRecord(a)); hipLaunchKernelGGL(k_gather64, dim3(grid), dim3(block), 0, 0, (const uint4*)t, (uint32_t)(points - 1), per_lane, out); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         const double bytes = (double)grid * block * per_lane * 64;
-        printf("k_gather64: %.0f gathers of 64 B = %.0f bytes requested (random over a 512 MiB table: at most 512 MiB of them can be first touches), %.3f ms, %.1f GB/s\n", bytes / 64, bytes, ms, bytes / ms / 1e6);
+        printf("k_gather64: %.0f gathers of 64 B = %.0f bytes requested (random over a 512 MiB table: at most 512 MiB of them can be first touches), %.3f ms, %.1f GB/s, %.2f G gathers/s\n", bytes / 64, bytes, ms, bytes / ms / 1e6, bytes / 64 / ms / 1e6);
     } else {
         const size_t bytes = (size_t)1 << 30;
         uint4* sbuf; CK(hipMalloc(&sbuf, bytes)); CK(hipMemset(sbuf, 1, bytes));
@@ -437,7 +457,7 @@ static int calibrate(const char* which) {
 }
 
 int main(int argc, char** argv) {
-    if (argc > 1 && (!strcmp(argv[1], "--gather64") || !strcmp(argv[1], "--stream32"))) return calibrate(argv[1]);
+    if (argc > 1 && (!strcmp(argv[1], "--gather64") || !strcmp(argv[1], "--gather80") || !strcmp(argv[1], "--stream32"))) return calibrate(argv[1]);
     {
         const int st = mont29_selftest();
         printf("mont29 host self-test (9 x 29-bit limbs vs Fq::mul): %s\n", st ? "FAILED" : "ok");

@@ -23,6 +23,8 @@ struct NttPassArgs {
     void* dst;
     const void* const* srcs;   // batch: device arrays of per-column pointers (blockIdx.y = column); null for one column
     void* const* dsts;
+    uint32_t col_major;        // strided passes of a batch: the grid is (columns, tiles) — consecutive workgroups take the SAME tile of different columns, so the tile's inter-pass twiddles
+                               // (and a coset transform's pre-scaling factors) are read from HBM once per batch and from L2 by the other columns
     uint32_t log_n;
     uint32_t blk_log;   // log2 of the sub-transform this pass works inside
     uint32_t r;         // log2 radix of this pass
@@ -373,14 +375,15 @@ __device__ __forceinline__ TwPairs stage_pairs(const NttPassArgs& a, uint4* smem
 
 ZK_KERNEL void ZK_LAUNCH_BOUNDS(256) ZK_WAVES_PER_EU(4) ntt_strided_pass29_kernel(NttPassArgs a) {
     ZK_DYN_SHARED(uint4, smem);
-    if (a.srcs) { a.src = a.srcs[blockIdx.y]; a.dst = a.dsts[blockIdx.y]; }
+    const uint32_t bcol = a.col_major ? blockIdx.x : blockIdx.y, btile = a.col_major ? blockIdx.y : blockIdx.x;
+    if (a.srcs) { a.src = a.srcs[bcol]; a.dst = a.dsts[bcol]; }
     const uint32_t R = 1u << a.r, C = 1u << a.c_log, tile = R << a.c_log;
     const Tile29 t = tile29_at(smem, tile);
     const uint32_t half = R >> 1 ? R >> 1 : 1;
     const TwPairs tp = stage_pairs(a, smem, tile, half);
     const uint32_t cols_log = a.blk_log - a.r;
     const uint32_t tiles_per_blk_log = cols_log - a.c_log;
-    const uint32_t tb = blockIdx.x;
+    const uint32_t tb = btile;
     const size_t o = tb >> tiles_per_blk_log;
     const uint32_t m0 = (tb & ((1u << tiles_per_blk_log) - 1)) << a.c_log;
     const size_t base = (o << a.blk_log) + m0;
@@ -714,7 +717,8 @@ int ntt_dev_batch(zk_ctx* ctx, void* const* h_cols, const void* const* h_srcs, s
             const size_t half_tw = (size_t)1 << (a.r ? a.r - 1 : 0), n_pairs = a.r >= 7 ? half_tw / 2 : half_tw;
             const size_t lds = ((((size_t)36 << (a.r + a.c_log)) + 15) & ~(size_t)15) + std::max(2 * ((n_pairs * 36 + 15) & ~(size_t)15), a.r >= 7 ? half_tw * 36 : 0) + 64;     // 36-byte elements: tile + the twiddle area (ntt_tile_stages29)
             if (tn.ntt_threads > 256) return ctx->fail(ZK_ERR_ARG, "ntt_threads: the strided passes take at most 256 threads per workgroup");
-            ZK_LAUNCH(ntt_strided_pass29_kernel, dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
+            a.col_major = tn.ntt_col_major && batch && grid <= 65535 ? 1u : 0u;
+            ZK_LAUNCH(ntt_strided_pass29_kernel, a.col_major ? dim3((uint32_t)count, grid) : dim3(grid, (uint32_t)count), tn.ntt_threads, lds, ctx->stream, a);
             ZK_CHECK_LAUNCH();
         } else {
             // o = j1 * Pm + jm with j1 the digit of pass 0 (Q = R_0) and jm the digit of pass 1 (if 3 passes)

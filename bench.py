@@ -871,11 +871,36 @@ def main(argv=None):
             wl.step(timings=tm)
             lat.append((time.time() - t1, tm))
         best = min(lat, key=lambda x: x[0])
-        extra["single_proof"] = {"ms": round(best[0] * 1e3, 2), "phase_ms": {k_: round(v, 2) for k_, v in best[1].items()}}
-        # the same proof once more with HIP-event timing on: alone on the GPU the event pairs bracket only this proof's kernels, so these
-        # (unlike event_span_ms_per_proof_pipelined above) are kernel times
+        extra["single_proof"] = {"ms": round(best[0] * 1e3, 2), "phase_ms": {k_: round(v, 2) for k_, v in best[1].items()},
+                                 "side_lane": "on (prover_side_lane = 1: a proof that is alone runs each phase's transforms on the context's helper context beside its commitments, DESIGN 3.7)"}
+        if PROVER == "native" and inflight >= 2:
+            # ... and what ONE and TWO proving threads give (the headline takes `inflight` of them): back-to-back proofs, same contexts
+            def few(nth, reps):
+                def loop_(w_):
+                    for _ in range(reps):
+                        w_.step()
+                ths_ = [threading.Thread(target=loop_, args=(w_,)) for w_ in wls[:nth]]
+                barrier()
+                t_ = time.time()
+                for t__ in ths_:
+                    t__.start()
+                for t__ in ths_:
+                    t__.join()
+                barrier()
+                return nth * reps / (time.time() - t_) * 3600.0
+            try:
+                extra["proofs_per_hour_by_proving_threads"] = {"1": round(few(1, 6), 1), "2": round(few(2, 5), 1), str(inflight): round(proofs_per_hour, 1)}
+            except Exception as e:
+                extra["proofs_per_hour_by_proving_threads_error"] = repr(e)
+        # the same proof once more with HIP-event timing on: alone on the GPU — and with the side lane OFF, so that no two kernels of the proof overlap — the event pairs
+        # bracket only this proof's kernels, so these (unlike event_span_ms_per_proof_pipelined above) are kernel times
+        be.tune(prover_side_lane=0)
+        t1 = time.time()
+        wl.step()
+        extra["single_proof"]["ms_without_side_lane"] = round((time.time() - t1) * 1e3, 2)
         be.timing(True)
         wl.step()
+        be.tune(prover_side_lane=bench_tune.get("prover_side_lane", 1))
         alone = {lab: be.timing_get(lab) for lab in ("msm_sort", "msm_accumulate", "msm_reduce", "quotient", "ntt_strided_pass", "ntt_final_pass")}
         pairs_alone = be.stat_get("msm_pairs")
         alone_stats = {lab: be.stat_get(lab) for lab in ("ntt_points", "ntt_pass_points", "quotient_alg_bytes")}

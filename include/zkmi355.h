@@ -378,10 +378,15 @@ typedef struct zk_plonk_pk_desc {
  * absent here), so under transcripts 1 / 2 the proofs verify and are deterministic in the rng stream, but byte parity with the axiom CPU prover is out of scope until its
  * schedule is pinned by shim/p256_k18_driver's dump.  Multi-phase advice and the Challenge API are not modelled either (zk_plonk_pk_build's caller must not pass such circuits). */
 typedef void (*zk_rng_fn)(void* user, size_t n, void* out_fr);
-/* advice: n_advice columns of 2^k x 32 B (HOST, or DEVICE when advice_on_device — then consumed: they hold coefficients afterwards); instances: HOST,
+/* advice: n_advice columns of 2^k x 32 B (HOST, or DEVICE when advice_on_device — then consumed: their last rows take the blinding values, and they hold coefficient
+ * forms or blinded values afterwards, whichever route the proof took); instances: HOST,
  * instance_lens[c] canonical 32-byte values per instance column.  The proof (32 bytes per commitment and per evaluation; 64 per commitment under transcript 2) is written to proof_out;
  * *proof_len receives its length (ZK_ERR_LIMIT when proof_cap is too small).  Errors of the entry points it drives are returned as they are
  * (e.g. ZK_ERR_ARG from zk_lookup_permute_batch_dev for a lookup input outside its table: halo2's Error::ConstraintSystemFailure). */
+/* One proof alone does not fill the GPU (a third of its commitment phases is the MSM's sort, reduction tail and host folds): a single-GPU proof on the extended domain
+ * therefore runs lagrange_to_coeff + coeff_to_extended of every phase's columns on a HELPER context the library keeps for `ctx` (own stream and workspaces, a helper host
+ * thread) while the phase's commitments run on `ctx` — tunable "prover_side_lane": 1 (default) when at most two proofs are in flight in the process, 2 always, 0 never.
+ * No byte of the proof depends on it; with three and more proofs in flight (one context per proving thread) the other proofs fill the GPU and it stays off. */
 int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
                           const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len);
 /* ---- the proving key as the library's own object: what a Rust / C caller uses instead of filling zk_plonk_pk_desc by hand ------------------------------ *

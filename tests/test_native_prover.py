@@ -92,6 +92,48 @@ def test_degree_split_changes_no_proof_byte_gpu(gpu, orc):
     _split_on_off(gpu, 13, "chip_estimate")
 
 
+def _side_lane_on_off(be, k, census, device_columns):
+    """the side lane of zk_plonk_create_proof (prover.hip: a phase's lagrange_to_coeff + coeff_to_extended on the context's helper context while the phase's commitments run)
+    changes no byte: always (2), never (0), and the default (1: on for a proof that is alone); with the side lane the caller's device columns keep their values (without it
+    they end as coefficient forms)"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sgx_shaped_circuit as sc
+    cs, fixed, asm, advice = sc.build(z, be, k, census=census)
+    params = z.kzg.ParamsKZG.setup(k, tcp.TAU, backend=be)
+    pk = plonk.keygen(params, cs, fixed, asm)
+    prover = plonk.NativeProver(params, pk)
+    proofs = []
+    try:
+        for mode in (2, 0, 1, 2):
+            be.tune(prover_side_lane=mode)
+            cols = [be.to_device(a) for a in advice] if device_columns else advice
+            proofs.append(prover.create_proof(cols, [], np.random.default_rng(3)))
+            if device_columns:
+                if mode == 2:
+                    assert all((c.download(a.shape)[:64] == a[:64]).all() for c, a in zip(cols[:3], advice[:3]))     # (the last rows are the blinding rows: the prover writes those)
+                for c in cols:
+                    c.free()
+    finally:
+        be.tune(prover_side_lane=1)
+    pk.release()
+    params.release()
+    assert all(p == proofs[0] for p in proofs)
+    return proofs[0]
+
+
+def test_side_lane_changes_no_proof_byte_emulated(emu, orc):
+    assert _side_lane_on_off(emu, 8, "chip_estimate", False) == tcp._golden(tcp.GOLDEN_SGX)
+    _side_lane_on_off(emu, 7, "chip_estimate", True)
+
+
+@pytest.mark.gpu
+def test_side_lane_changes_no_proof_byte_gpu(gpu, orc):
+    assert _side_lane_on_off(gpu, 8, "chip_estimate", True) == tcp._golden(tcp.GOLDEN_SGX)
+    _side_lane_on_off(gpu, 14, "chip_estimate", True)
+
+
 def test_draw_schedule_leaves_the_callers_rng_where_halo2_would(emu, orc):
     """A proof consumes exactly draw_plan's draws — blinding rows, random polynomial AND the Blind(Fr::random) of every commitment (advice,
     permuted pairs, grand products, random polynomial, h pieces) — and all of them are made before zk_plonk_create_proof returns, so a caller that proves twice

@@ -95,8 +95,35 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     return ZK_OK;
 }
 
+}  // extern "C"
+// the helper context of `ctx` (ctx.h): same device, made on first use, the caller's tunables as they are now (internal: prover.hip)
+zk_ctx* zk_internal_helper_ctx(zk_ctx* ctx) {
+    if (!ctx) return nullptr;
+    zk_ctx* h;
+    {
+        LOCK;
+        h = ctx->helper;
+    }
+    if (!h) {
+        if (zk_ctx_create(ctx->device, &h) != ZK_OK) return nullptr;
+        LOCK;
+        ctx->helper = h;
+    }
+    zk::Tune t;
+    bool timing;
+    {
+        LOCK;
+        t = ctx->tune; timing = ctx->timing;
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->tune = t;
+    h->timing = timing;
+    return h;
+}
+extern "C" {
 void zk_ctx_destroy(zk_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->helper) { zk_ctx_destroy(ctx->helper); ctx->helper = nullptr; }
     zk_internal_plonk_ctx_destroyed(ctx);       // proving keys built on / shared to this context (prover.hip)
     (void)zk_plonk_trim(ctx);                   // device buffers zk_plonk_create_proof kept for reuse on this context (a later context at the same address must not inherit them)
     {
@@ -123,7 +150,7 @@ static int* tune_slot(zk_ctx* ctx, const char* key) {
     struct { const char* k; int* v; } tab[] = {
         {"msm_c", &t.msm_c}, {"msm_sort_wgs", &t.msm_sort_wgs}, {"msm_sort_threads", &t.msm_sort_threads}, {"msm_sort_batch_wgs", &t.msm_sort_batch_wgs}, {"msm_bsort_threads", &t.msm_bsort_threads}, {"msm_two_level_sort", &t.msm_two_level_sort},
         {"msm_target_threads", &t.msm_target_threads}, {"msm_min_chunk", &t.msm_min_chunk}, {"msm_max_chunk", &t.msm_max_chunk},
-        {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block}, {"msm_runs", &t.msm_runs},
+        {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block}, {"msm_runs", &t.msm_runs}, {"prover_side_lane", &t.prover_side_lane},
         {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log}, {"ntt_coset_table", &t.ntt_coset_table}, {"ntt_col_major", &t.ntt_col_major},
         {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}, {"lookup_force_generic_sort", &t.lookup_force_generic_sort},
         {"ntt_quarter_input", &t.ntt_quarter_input}, {"ntt_fuse_scale", &t.ntt_fuse_scale}, {"quot_piece_cosets", &t.quot_piece_cosets}, {"quot_factor_horner", &t.quot_factor_horner}, {"quot_degree_split", &t.quot_degree_split}, {"quot_group_factors", &t.quot_group_factors}, {"ntt_ws_limit_mb", &t.ntt_ws_limit_mb}, 
@@ -147,17 +174,21 @@ int zk_tune_get(zk_ctx* ctx, const char* key, int* value) {
     return ZK_OK;
 }
 int zk_timing_enable(zk_ctx* ctx, int on) {
-    NEED_CTX; LOCK;
+    NEED_CTX;
+    if (ctx->helper) (void)zk_timing_enable(ctx->helper, on);
+    LOCK;
     if (on) { resolve_pending_timers(ctx); ctx->last_ms.clear(); }   // (switching the timing OFF keeps what was measured: zk_timing_get reads it afterwards)
     ctx->timing = on != 0;
     return ZK_OK;
 }
 double zk_timing_get(zk_ctx* ctx, const char* label) {
     if (!ctx || !label) return -1.0;
+    const double side = ctx->helper ? zk_timing_get(ctx->helper, label) : -1.0;      // what the helper context ran for this one counts as this one's
     LOCK;
     resolve_pending_timers(ctx);
     auto it = ctx->last_ms.find(label);
-    return it == ctx->last_ms.end() ? -1.0 : it->second;
+    if (it == ctx->last_ms.end()) return side;
+    return it->second + (side > 0 ? side : 0.0);
 }
 
 #define ENTER NEED_CTX; LOCK; ZK_HIP(hipSetDevice(ctx->device))

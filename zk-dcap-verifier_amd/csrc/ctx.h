@@ -27,6 +27,7 @@ struct Tune {
     int msm_merge_fanin = 8;
     int msm_tree_fanin = 2;
     int msm_block = 128;         // threads per workgroup of the curve-arithmetic kernels
+    int prover_side_lane = 1;    // zk_plonk_create_proof (single-GPU keys on the extended domain): lagrange_to_coeff + coeff_to_extended of a phase's columns on the helper context while the phase's commitments run; 1 = when at most two proofs are in flight in the process, 2 = always, 0 = never
     int msm_runs = 1;            // commit run-heavy columns through adjacent differences against the prefix-sum table (when the table has one)
     int ntt_tile_log = 10;       // log2(elements) of the LDS tile of one NTT workgroup (sweep: profiles/r01/run6_ntt_plan_sweep.txt)
     int ntt_threads = 256;
@@ -122,6 +123,9 @@ struct zk_ctx {
     std::map<std::string, double> last_ms;
     struct PendingTimer { const char* label; hipEvent_t a, b; };
     std::vector<PendingTimer> pending_timers;   // event pairs of asynchronous entry points, read by zk_timing_get
+    // a second context of the same device that belongs to this one (created on first use, destroyed with it): zk_plonk_create_proof runs the transforms of columns whose
+    // values are final there — its own stream, workspaces and lock — while this context commits them (prover.hip SideLane); timings and tunables pass through
+    zk_ctx* helper = nullptr;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];

@@ -12,6 +12,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -24,6 +26,7 @@
 using namespace zk;
 
 int zk_internal_fail(zk_ctx* ctx, int code, const char* msg);   // capi.hip: sets zk_last_error(ctx)
+zk_ctx* zk_internal_helper_ctx(zk_ctx* ctx);                      // capi.hip: the helper context of ctx (ctx.h), or null
 
 namespace {
 int pk_fail(zk_ctx* ctx, int code, const char* fmt, ...) {
@@ -316,6 +319,46 @@ struct Arena {                                                        // everyth
     ~Arena() { for (auto& h : held) if (h.first) put(h.first, h.second); }
 };
 
+// ---- transforms that need no challenge, beside the commitments that do ------------------------------------------------------------------------------------------------
+// A proof alone on the GPU spends a third of phases 2-5 in the MSM's sort, its reduction tail and the host's folds — latency, not arithmetic — and every commitment waits for
+// the transcript.  The coefficient and extended forms of a phase's columns depend on no challenge: as soon as a phase's values are final they go to the context's HELPER
+// context (own stream, workspaces, lock: ctx.h) from a helper host thread, jobs in submission order, while the proof's own thread commits the same columns; phase 6 waits
+// for them instead of transforming everything at once.  Same field elements, same bytes.
+struct SideLane {
+    zk_ctx* h = nullptr;
+    std::thread th;
+    std::mutex mu; std::condition_variable cv;
+    std::deque<std::function<int()>> q;
+    size_t open = 0; bool closing = false; int rc = ZK_OK;
+    void start(zk_ctx* helper) {
+        h = helper;
+        th = std::thread([this]() {
+            std::unique_lock<std::mutex> lk(mu);
+            while (true) {
+                cv.wait(lk, [&] { return closing || !q.empty(); });
+                if (q.empty()) break;
+                std::function<int()> f = std::move(q.front());
+                q.pop_front();
+                const int before = rc;
+                lk.unlock();
+                const int r = before ? before : f();                  // (after an error the remaining jobs are dropped)
+                lk.lock();
+                if (r && !rc) rc = r;
+                open--;
+                cv.notify_all();
+            }
+        });
+    }
+    void submit(std::function<int()> f) { { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); open++; } cv.notify_all(); }
+    int wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return open == 0; }); return rc; }
+    ~SideLane() {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); closing = true; }
+        cv.notify_all();
+        th.join();                                                     // (jobs in flight finish: they write buffers of the proof's arena, which outlives this object)
+    }
+};
+
 // ---- the caller's Fr::random draws, made on a helper thread in the order the phases consume them ---------------------------------------------------------
 struct Draws {
     std::vector<uint64_t> buf;                                        // all items back to back (count x 4 limbs each), borrowed from the context's pool
@@ -414,8 +457,14 @@ static const uint64_t POISON[4] = {~0ull, ~0ull, ~0ull, ~0ull};
 static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
                              const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len, ShardSignal& sig);
 
+// proofs this process has in flight (every device together: a prover process drives one GPU): the side lane fills a lone proof's idle issue slots — with three and more
+// in flight the other proofs do that already, and a helper context per proof only adds kernels to the crowd (measured: DESIGN 3.7)
+static std::atomic<int> g_proofs_in_flight{0};
+struct InFlight { InFlight() { g_proofs_in_flight.fetch_add(1); } ~InFlight() { g_proofs_in_flight.fetch_sub(1); } };
+
 extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
                                      const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len) {
+    InFlight counted;
     ShardSignal sig;
     const int rc = create_proof_body(ctx, pk, advice, advice_on_device, instances, instance_lens, rng, rng_user, proof_out, proof_cap, proof_len, sig);
     if (rc != ZK_OK && rc != ZK_ERR_COMM && sig.armed && sig.next < sig.sizes.size()) {
@@ -479,6 +528,7 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
     for (uint32_t i = 0; i < pk->n_fixed_queries; i++) if (pk->fixed_queries[2 * i] >= pk->n_fixed) return ZK_ERR_ARG;
     for (uint32_t i = 0; i < pk->n_advice; i++) if (!advice[i]) return ZK_ERR_ARG;
     Arena mem(ctx);
+    SideLane lane;                                                     // (after the arena: its destructor joins the helper thread before the buffers go back to the pool)
     if (pk->transcript > 2) return ZK_ERR_ARG;
     // exchange buffers of a sharded proof: the caller's (e.g. two torch tensors, so that its callback can hand RCCL tensors) or the proof's own.  First thing of all:
     // from here on this rank can tell the others about a failure of its own (ShardSignal)
@@ -567,6 +617,35 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
         for (uint32_t i = 0; i < pk->n_advice; i++) { bdst[i] = (char*)adv[i] + usable * 32; bsrc[i] = draws.take(i); }
         if (pk->n_advice) PK(zk_dev_upload_batch(ctx, bdst.data(), bsrc.data(), pk->n_advice, (n - usable) * 32));
     }
+    // the side lane (SideLane above): a single-GPU proof on the extended domain hands every phase's columns to the helper context as soon as their values are final
+    bool side = false;
+    {
+        int want = 0;
+        if (!sharded && !by_cosets && zk_tune_get(ctx, "prover_side_lane", &want) == ZK_OK && (want >= 2 || (want == 1 && g_proofs_in_flight.load() <= 2))) {
+            zk_ctx* h = zk_internal_helper_ctx(ctx);
+            if (h) { lane.start(h); side = true; }
+        }
+    }
+    std::vector<void*> coefA, extA, coefB, extB, coefC, extC;         // coefficient and extended forms of: advice + instance | permuted pairs | grand products
+    auto early = [&](const std::vector<void*>& vals, std::vector<void*>& coefs, std::vector<void*>& exts) -> int {
+        coefs.resize(vals.size()); exts.resize(vals.size());
+        for (size_t i = 0; i < vals.size(); i++) { coefs[i] = mem.get(col_bytes); exts[i] = mem.get(en * 32); if (!coefs[i] || !exts[i]) return ZK_ERR_HIP; }
+        if (vals.empty()) return ZK_OK;
+        PK(zk_dev_sync(ctx));                                         // the values are final: everything that wrote them ran on this context's stream
+        zk_ctx* h = lane.h;
+        lane.submit([h, vals, coefs, exts, col_bytes, k, ek]() -> int {
+            for (size_t i = 0; i < vals.size(); i++) { const int r = zk_dev_copy(h, coefs[i], vals[i], col_bytes); if (r) return r; }
+            int r = zk_lagrange_to_coeff_batch_dev(h, coefs.data(), coefs.size(), k);
+            if (!r) r = zk_coeff_to_extended_batch_dev(h, (const void* const*)coefs.data(), exts.data(), coefs.size(), k, ek);
+            return r ? r : zk_dev_sync(h);
+        });
+        return ZK_OK;
+    };
+    if (side) {
+        std::vector<void*> vals(adv);
+        vals.insert(vals.end(), inst_values.begin(), inst_values.end());
+        PK(early(vals, coefA, extA));
+    }
     auto commit = [&](uint64_t table, const std::vector<void*>& cols) -> int {
         if (cols.empty()) return ZK_OK;
         std::vector<uint64_t> out(cols.size() * 12);
@@ -623,6 +702,7 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
         PK(zk_lookup_permute_batch_dev(ctx, (const void* const*)cin.data(), (const void* const*)ctab.data(), L, k, bf, bi.data(), bt.data(), pin.data(), ptab.data()));
         std::vector<void*> flat;
         for (uint32_t l = 0; l < L; l++) { flat.push_back(pin[l]); flat.push_back(ptab[l]); }
+        if (side) PK(early(flat, coefB, extB));
         PK(commit(pk->srs_g_lagrange, flat));
     }
     clk.lap(2);
@@ -651,6 +731,7 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
     {
         std::vector<void*> both(zs);
         both.insert(both.end(), lzs.begin(), lzs.end());
+        if (side) PK(early(both, coefC, extC));
         PK(commit(pk->srs_g_lagrange, both));
     }
     clk.lap(3);
@@ -662,12 +743,22 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
     clk.lap(4);
     // ---- 6. y; coefficient form; extended cosets; h(X) numerator ----------------------------------------------------------------------------------------------
     const Fe y = tr.squeeze();
+    std::vector<void*> side_ext;
+    if (side) {                                                       // the helper context has brought every column to both forms: from here on the vectors name the coefficient forms
+        const int rc_side = lane.wait();
+        if (rc_side) return pk_fail(ctx, rc_side, "zk_plonk_create_proof: transforms on the helper context: %s", zk_last_error(lane.h));
+        for (uint32_t i = 0; i < pk->n_advice; i++) { adv[i] = coefA[i]; side_ext.push_back(extA[i]); }
+        for (uint32_t c = 0; c < pk->n_instance; c++) { inst_values[c] = coefA[pk->n_advice + c]; side_ext.push_back(extA[pk->n_advice + c]); }
+        for (uint32_t s_ = 0; s_ < n_sets; s_++) { zs[s_] = coefC[s_]; side_ext.push_back(extC[s_]); }
+        for (uint32_t l = 0; l < L; l++) { lzs[l] = coefC[n_sets + l]; side_ext.push_back(extC[n_sets + l]); }
+        for (uint32_t l = 0; l < L; l++) { pin[l] = coefB[2 * l]; ptab[l] = coefB[2 * l + 1]; side_ext.push_back(extB[2 * l]); side_ext.push_back(extB[2 * l + 1]); }
+    }
     std::vector<void*> lag(adv);
     lag.insert(lag.end(), inst_values.begin(), inst_values.end());
     lag.insert(lag.end(), zs.begin(), zs.end());
     lag.insert(lag.end(), lzs.begin(), lzs.end());
     for (uint32_t l = 0; l < L; l++) { lag.push_back(pin[l]); lag.push_back(ptab[l]); }
-    PK(zk_lagrange_to_coeff_batch_dev(ctx, lag.data(), lag.size(), k));
+    if (!side) PK(zk_lagrange_to_coeff_batch_dev(ctx, lag.data(), lag.size(), k));
     void* h_ext = by_cosets ? nullptr : mem.get(en * 32);
     if (!by_cosets && !h_ext) return ZK_ERR_HIP;
     std::vector<void*> numer(by_cosets ? n_pieces : 0);
@@ -716,8 +807,11 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
         for (auto e : cols) mem.give_back(e);
     } else if (!sharded) {
         std::vector<void*> ext(lag.size());
-        for (auto& e : ext) { e = mem.get(en * 32); if (!e) return ZK_ERR_HIP; }
-        PK(zk_coeff_to_extended_batch_dev(ctx, (const void* const*)lag.data(), ext.data(), ext.size(), k, ek));
+        if (side) ext = side_ext;
+        else {
+            for (auto& e : ext) { e = mem.get(en * 32); if (!e) return ZK_ERR_HIP; }
+            PK(zk_coeff_to_extended_batch_dev(ctx, (const void* const*)lag.data(), ext.data(), ext.size(), k, ek));
+        }
         std::vector<const void*> e_in, e_tab;
         zk_quotient_args a;
         quotient_args(a, ext.data(), e_in, e_tab);

@@ -873,7 +873,7 @@ def main(argv=None):
         best = min(lat, key=lambda x: x[0])
         extra["single_proof"] = {"ms": round(best[0] * 1e3, 2), "phase_ms": {k_: round(v, 2) for k_, v in best[1].items()},
                                  "side_lane": "on (prover_side_lane = 1: a proof that is alone runs each phase's transforms on the context's helper context beside its commitments, DESIGN 3.7)"}
-        if PROVER == "native" and inflight >= 2:
+        if PROVER == "native" and inflight >= 2 and world == 1:
             # ... and what ONE and TWO proving threads give (the headline takes `inflight` of them): back-to-back proofs, same contexts
             def few(nth, reps):
                 def loop_(w_):

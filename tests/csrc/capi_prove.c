@@ -6,46 +6,20 @@
  * With a second argument W > 1 the same proof is then made by W "ranks" — W threads of this process, one context each, every one holding 1/W of both SRS
  * tables and a sharded key (zk_plonk_pk_host.shard_world) — whose zk_allgather_fn is a barrier + device-to-device copies: the multi-GPU call sequence of a
  * Rust / C host (with RCCL's ncclAllGather in the callback's place), and every rank must emit the same expected bytes.
+ * With ZK_TAMPER_LAST_RANK=1 the ranks first run a proof in which the LAST rank's witness leaves its lookup table (advice column 0 := column 2 — the toy circuit):
+ * that rank must fail with its own error after telling the others through the library-owned exchange buffers, every other rank must return ZK_ERR_COMM from the
+ * same exchange, and the untampered proof that follows on the same contexts must still come out byte for byte.
+ * With ZK_RANK_DEVICES=1 rank r proves on GPU r % (number of GPUs) instead of GPU 0, and — when there is a GPU per rank and libzkmi355_rccl.so loads — the ranks'
+ * collective is zk_rccl_allgather on the communicators of zk_rccl_comm_init_all (ncclCommInitAll: one process, W devices; include/zkmi355_rccl.h): the deployment
+ * SURVEY 5 names, with no Python and no torch in the process.  On a one-GPU box that setting changes nothing (barrier + copies on GPU 0).
  * usage: capi_prove FILE.zkpk [W]  env ZK_TUNE="key=value,..." applies zk_tune_set pairs (the emulator build wants small launch shapes)
  * exit: 0 proof == expected on both contexts, 3 no usable GPU, 1 anything else */
+#include <dlfcn.h>
 #include <pthread.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include "zkmi355.h"
+#include "zkpk_reader.h"
+#include "zkmi355_rccl.h"
 
 #define CK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, zk_last_error(ctx)); return 1; } } while (0)
-
-typedef struct { const unsigned char* p; size_t left; } rd;
-static const void* take(rd* r, size_t bytes) {
-    bytes = (bytes + 7) & ~(size_t)7;
-    if (bytes > r->left) { fprintf(stderr, "ZKPK1 file truncated\n"); exit(1); }
-    const void* q = r->p; r->p += bytes; r->left -= bytes; return q;
-}
-static uint64_t take_u64(rd* r) { uint64_t v; memcpy(&v, take(r, 8), 8); return v; }
-
-/* the caller's rng: serves the recorded Fr::random stream in the order the library asks for it */
-typedef struct { const unsigned char* draws; uint64_t n, at; int overrun; } stream;
-static void serve(void* user, size_t count, void* out) {
-    stream* s = (stream*)user;
-    if (s->at + count > s->n) { s->overrun = 1; memset(out, 0, count * 32); return; }
-    memcpy(out, s->draws + 32 * s->at, count * 32);
-    s->at += count;
-}
-
-static void apply_tune(zk_ctx* ctx) {
-    const char* t = getenv("ZK_TUNE");
-    if (!t) return;
-    char* copy = strdup(t);
-    for (char* tok = strtok(copy, ","); tok; tok = strtok(NULL, ",")) {
-        char* eq = strchr(tok, '=');
-        if (!eq) continue;
-        *eq = 0;
-        if (zk_tune_set(ctx, tok, atoi(eq + 1))) fprintf(stderr, "zk_tune_set(%s) refused\n", tok);
-    }
-    free(copy);
-}
 
 /* ---- W ranks in one process: the collective is a barrier and W x W device copies --------------------------------------------------------------------- */
 typedef struct {
@@ -60,6 +34,9 @@ typedef struct {
     const zk_plonk_pk_host* host; const void* g; const void* g_lagrange; size_t n;
     const void** advice; const void** inst; const uint32_t* inst_len;
     stream st; const unsigned char* want; size_t want_len; int ok;
+    int tamper;                                                      /* 1: one failing proof first (see the header comment) */
+    zk_allgather_fn rccl_gather; zk_rccl_comm* comm;                 /* ZK_RANK_DEVICES=1 with a GPU per rank: RCCL is the collective — zk_rccl_allgather IS a zk_allgather_fn, user = the communicator */
+    uint64_t (*comm_calls)(const zk_rccl_comm*);
     int gathers;                                                     /* calls of the collective this rank made (the same on every rank: 7 commitment phases + the numerators) */
 } rank_job;
 static int gather(void* user, const void* send_dev, void* recv_dev, size_t bytes) {
@@ -81,6 +58,7 @@ static void* rank_main(void* arg) {
     const size_t n_loc = j->n / (size_t)W, lo = (size_t)j->rank * n_loc;
     zk_plonk_pk_host host = *j->host;
     host.shard_world = (uint32_t)W; host.shard_rank = (uint32_t)j->rank; host.allgather = gather; host.allgather_user = j;
+    if (j->rccl_gather) { host.allgather = j->rccl_gather; host.allgather_user = j->comm; }
     uint64_t h_g = 0, h_gl = 0, pk = 0;
     unsigned char* proof = (unsigned char*)malloc(j->want_len + 4096);
     size_t len = 0;
@@ -90,8 +68,25 @@ static void* rank_main(void* arg) {
     if (!rc) rc = zk_plonk_pk_build(ctx, &host, h_g, h_gl, &pk);
     if (rc) { fprintf(stderr, "rank %d setup -> %d: %s\n", j->rank, rc, zk_last_error(ctx)); j->fab->failed = 1; }
     pthread_barrier_wait(&j->fab->bar);                              /* all ranks ready (or all see `failed`): the collectives below stay matched */
+    if (!j->fab->failed && j->tamper) {
+        const int last = j->rank == W - 1;
+        const void** adv = j->advice;
+        if (last) {
+            adv = (const void**)calloc(host.n_advice + 1, sizeof(void*));
+            memcpy(adv, j->advice, host.n_advice * sizeof(void*));
+            if (host.n_advice > 2) adv[0] = j->advice[2];
+        }
+        rc = zk_plonk_prove(ctx, pk, adv, 0, j->inst, j->inst_len, serve, &j->st, proof, j->want_len + 4096, &len);
+        const int as_expected = last ? (rc != ZK_OK && rc != ZK_ERR_COMM && strstr(zk_last_error(ctx), "failure signalled to the other ranks") != NULL) : rc == ZK_ERR_COMM;
+        if (!as_expected) { fprintf(stderr, "rank %d, tampered round: rc %d (%s)\n", j->rank, rc, zk_last_error(ctx)); j->fab->failed = 1; }
+        if (last) free(adv);
+        j->st.at = 0; j->gathers = 0;
+        pthread_barrier_wait(&j->fab->bar);
+    }
     if (!j->fab->failed) {
+        const uint64_t calls0 = j->rccl_gather ? j->comm_calls(j->comm) : 0;
         rc = zk_plonk_prove(ctx, pk, j->advice, 0, j->inst, j->inst_len, serve, &j->st, proof, j->want_len + 4096, &len);
+        if (j->rccl_gather) j->gathers = (int)(j->comm_calls(j->comm) - calls0);
         if (rc) fprintf(stderr, "rank %d zk_plonk_prove -> %d: %s\n", j->rank, rc, zk_last_error(ctx));
         j->ok = !rc && len == j->want_len && !memcmp(proof, j->want, len) && j->st.at == j->st.n;
     }
@@ -103,54 +98,16 @@ static void* rank_main(void* arg) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s FILE.zkpk\n", argv[0]); return 1; }
-    FILE* f = fopen(argv[1], "rb");
-    if (!f) { perror(argv[1]); return 1; }
-    fseek(f, 0, SEEK_END);
-    const long size = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    unsigned char* file = (unsigned char*)malloc((size_t)size + 8);
-    if (!file || fread(file, 1, (size_t)size, f) != (size_t)size) { fprintf(stderr, "read failed\n"); return 1; }
-    fclose(f);
-    rd r = { file, (size_t)size };
-    const uint32_t* head = (const uint32_t*)take(&r, 8 + 12 * 4);
-    if (memcmp(head, "ZKPK", 4) || head[1] != 1) { fprintf(stderr, "not a ZKPK1 file\n"); return 1; }
-    const uint32_t k = head[2], cs_degree = head[3], bf = head[4], n_fixed = head[5], n_advice = head[6], n_instance = head[7], L = head[8], P = head[9],
-                   n_aq = head[10], n_fq = head[11], transcript = head[12], draw_schedule = head[13];
-    const size_t n = (size_t)1 << k;
-    const uint32_t* lists = (const uint32_t*)take(&r, 4 * (2 * (size_t)P + 2 * n_aq + 2 * n_fq + L));
-    const void* transcript_repr = take(&r, 32);
-
-    zk_plonk_pk_host host;
-    ZK_STRUCT_INIT(host);
-    host.k = k; host.cs_degree = cs_degree; host.blinding_factors = bf;
-    host.n_fixed = n_fixed; host.n_advice = n_advice; host.n_instance = n_instance; host.n_lookups = L; host.n_perm_columns = P;
-    host.perm_columns = lists; host.advice_queries = lists + 2 * P; host.n_advice_queries = n_aq;
-    host.fixed_queries = lists + 2 * P + 2 * n_aq; host.n_fixed_queries = n_fq;
-    host.lookup_table_key = lists + 2 * P + 2 * n_aq + 2 * n_fq;
-    host.transcript_repr = transcript_repr; host.transcript = transcript; host.draw_schedule = draw_schedule;
-    host.evaluator_zkq1_len = (size_t)take_u64(&r); host.evaluator_zkq1 = take(&r, host.evaluator_zkq1_len);
-    const void** in_blob = (const void**)calloc(L + 1, sizeof(void*)); const void** tab_blob = (const void**)calloc(L + 1, sizeof(void*));
-    size_t* in_len = (size_t*)calloc(L + 1, sizeof(size_t)); size_t* tab_len = (size_t*)calloc(L + 1, sizeof(size_t));
-    for (uint32_t l = 0; l < L; l++) {
-        in_len[l] = (size_t)take_u64(&r); in_blob[l] = take(&r, in_len[l]);
-        tab_len[l] = (size_t)take_u64(&r); tab_blob[l] = take(&r, tab_len[l]);
-    }
-    host.lookup_input_zkq1 = in_blob; host.lookup_input_zkq1_len = in_len; host.lookup_table_zkq1 = tab_blob; host.lookup_table_zkq1_len = tab_len;
-    const void* g = take(&r, n * 64);
-    const void* g_lagrange = take(&r, n * 64);
-    const void** fixed = (const void**)calloc(n_fixed + 1, sizeof(void*)); const void** sigma = (const void**)calloc(P + 1, sizeof(void*));
-    for (uint32_t i = 0; i < n_fixed; i++) fixed[i] = take(&r, n * 32);
-    for (uint32_t i = 0; i < P; i++) sigma[i] = take(&r, n * 32);
-    host.fixed_values = fixed; host.sigma_values = sigma;
-    const void** advice = (const void**)calloc(n_advice + 1, sizeof(void*));
-    for (uint32_t i = 0; i < n_advice; i++) advice[i] = take(&r, n * 32);
-    const void** inst = (const void**)calloc(n_instance + 1, sizeof(void*)); uint32_t* inst_len = (uint32_t*)calloc(n_instance + 1, sizeof(uint32_t));
-    for (uint32_t i = 0; i < n_instance; i++) { inst_len[i] = (uint32_t)take_u64(&r); inst[i] = take(&r, (size_t)inst_len[i] * 32); }
-    stream st = { NULL, 0, 0, 0 };
-    st.n = take_u64(&r); st.draws = (const unsigned char*)take(&r, (size_t)st.n * 32);
-    const size_t want_len = (size_t)take_u64(&r);
-    const unsigned char* want = (const unsigned char*)take(&r, want_len);
+    if (argc < 2) { fprintf(stderr, "usage: %s FILE.zkpk [W]\n", argv[0]); return 1; }
+    static zkpk z;
+    if (zkpk_read(argv[1], &z)) return 1;
+    zk_plonk_pk_host host = z.host;
+    const uint32_t k = z.k, n_advice = z.n_advice, n_fixed = z.n_fixed, n_instance = z.n_instance, L = z.L, P = z.P, draw_schedule = z.draw_schedule;
+    const size_t n = z.n, want_len = z.want_len;
+    const void* g = z.g; const void* g_lagrange = z.g_lagrange;
+    const void** advice = z.advice; const void** inst = z.inst; const uint32_t* inst_len = z.inst_len;
+    stream st = z.st;
+    const unsigned char* want = z.want;
 
     zk_ctx* ctx = NULL;
     int rc = zk_ctx_create(0, &ctx);
@@ -210,18 +167,44 @@ int main(int argc, char** argv) {
         pthread_t th[8];
         fab.world = W;
         pthread_barrier_init(&fab.bar, NULL, (unsigned)W);
+        /* ZK_RANK_DEVICES=1: a GPU per rank when the box has them (counted through the ABI: no HIP on this side), RCCL between them when its adapter loads */
+        int ndev = 1;
+        zk_allgather_fn rccl_gather = NULL;
+        zk_rccl_comm* comms[8] = { NULL };
+        uint64_t (*comm_calls)(const zk_rccl_comm*) = NULL;
+        void (*comm_destroy)(zk_rccl_comm*) = NULL;
+        if (getenv("ZK_RANK_DEVICES")) {
+            for (ndev = 0; ndev < 64; ndev++) { zk_ctx* probe = NULL; if (zk_ctx_create(ndev, &probe)) break; zk_ctx_destroy(probe); }
+            if (ndev < 1) ndev = 1;
+            void* so = ndev >= W ? dlopen(getenv("ZK_RCCL_LIB") ? getenv("ZK_RCCL_LIB") : "libzkmi355_rccl.so", RTLD_NOW) : NULL;
+            if (so) {
+                int (*init_all)(uint32_t, const int*, uint32_t, zk_rccl_comm**) = (int (*)(uint32_t, const int*, uint32_t, zk_rccl_comm**))dlsym(so, "zk_rccl_comm_init_all");
+                const char* (*last_error)(const zk_rccl_comm*) = (const char* (*)(const zk_rccl_comm*))dlsym(so, "zk_rccl_last_error");
+                rccl_gather = (zk_allgather_fn)dlsym(so, "zk_rccl_allgather");
+                comm_calls = (uint64_t (*)(const zk_rccl_comm*))dlsym(so, "zk_rccl_comm_calls");
+                comm_destroy = (void (*)(zk_rccl_comm*))dlsym(so, "zk_rccl_comm_destroy");
+                if (!init_all || !rccl_gather || !comm_calls || !comm_destroy) { fprintf(stderr, "libzkmi355_rccl.so lacks a symbol of zkmi355_rccl.h\n"); return 1; }
+                const int rc_all = init_all((uint32_t)W, NULL, 20000, comms);
+                if (rc_all) { fprintf(stderr, "zk_rccl_comm_init_all(%d) -> %d: %s\n", W, rc_all, last_error ? last_error(NULL) : ""); return 1; }
+            }
+            printf("%d GPUs for %d ranks: %s\n", ndev, W, rccl_gather ? "one GPU per rank, RCCL all-gather (ncclCommInitAll)" : "barrier + device copies");
+        }
         for (int r = 0; r < W; r++) {
-            if (zk_ctx_create(0, &fab.ctx[r])) { fprintf(stderr, "context of rank %d failed\n", r); return 1; }
+            if (zk_ctx_create(r % ndev, &fab.ctx[r])) { fprintf(stderr, "context of rank %d failed\n", r); return 1; }
             ctx = fab.ctx[r];
             apply_tune(ctx);
             rank_job* j = &jobs[r];
             j->fab = &fab; j->rank = r; j->host = &host; j->g = g; j->g_lagrange = g_lagrange; j->n = n;
             j->advice = advice; j->inst = inst; j->inst_len = inst_len; j->st = st; j->st.at = 0; j->want = want; j->want_len = want_len; j->ok = 0; j->gathers = 0;
+            j->tamper = getenv("ZK_TAMPER_LAST_RANK") != NULL;
+            j->rccl_gather = rccl_gather; j->comm = comms[r]; j->comm_calls = comm_calls;
         }
         for (int r = 0; r < W; r++) pthread_create(&th[r], NULL, rank_main, &jobs[r]);
         for (int r = 0; r < W; r++) pthread_join(th[r], NULL);
         for (int r = 0; r < W; r++) { if (!jobs[r].ok) { fprintf(stderr, "rank %d of %d: proof differs or failed\n", r, W); return 1; } zk_ctx_destroy(fab.ctx[r]); }
+        if (rccl_gather) for (int r = 0; r < W; r++) comm_destroy(comms[r]);
         for (int r = 1; r < W; r++) if (jobs[r].gathers != jobs[0].gathers) { fprintf(stderr, "rank %d made %d all-gathers, rank 0 made %d\n", r, jobs[r].gathers, jobs[0].gathers); return 1; }
+        if (jobs[0].tamper) printf("tampered round: the last rank failed on its own and signalled it through the library's exchange buffers, the others returned ZK_ERR_COMM\n");
         printf("%d ranks (sharded tables, sharded keys, all-gather callback): every rank emitted the expected bytes, %d all-gathers per proof\n", W, jobs[0].gathers);
     }
     printf("capi_prove OK\n");

@@ -22,13 +22,23 @@ struct uint2 { uint32_t x, y; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 
-#define __global__
-#define __device__
+// (the TSan build watches the library's HOST threads — prover.hip's lanes, pools and shared keys: the emulated kernels run one launch at a time under
+//  emu_launch_mutex, and instrumenting every load of the unrolled field arithmetic took the compile of msm.hip past half an hour)
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define EMU_DEVICE_ATTR __attribute__((no_sanitize("thread")))
+#endif
+#endif
+#ifndef EMU_DEVICE_ATTR
+#define EMU_DEVICE_ATTR
+#endif
+#define __global__ EMU_DEVICE_ATTR
+#define __device__ EMU_DEVICE_ATTR
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static
-#define ZK_KERNEL
+#define ZK_KERNEL EMU_DEVICE_ATTR
 #define ZK_WAVES_PER_EU(n)
 #define ZK_LAUNCH_BOUNDS(n)
 
@@ -37,8 +47,31 @@ inline thread_local unsigned char* emu_smem = nullptr;
 // Work-item contexts.  glibc's swapcontext saves and restores the signal mask — two system calls per switch, and a barrier-heavy kernel switches millions of
 // times: the test suite spent most of its time in the kernel.  On x86-64 the switch is done here instead (callee-saved registers + stack pointer, System V
 // ABI); elsewhere ucontext remains.
+// Under the sanitizer builds (`make emu-asan / emu-tsan`) every switch is announced: ASan keeps a shadow ("fake") stack per context and must know the bounds of
+// the stack it lands on, TSan keeps a clock per fiber (switches synchronise: work-items of one OS thread never race; what TSan watches is the library's real threads).
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#if __has_feature(thread_sanitizer)
+#define EMU_TSAN 1
+extern "C" void* __tsan_get_current_fiber(void);
+extern "C" void* __tsan_create_fiber(unsigned flags);
+extern "C" void __tsan_destroy_fiber(void* fiber);
+extern "C" void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+#endif
+#endif
+struct EmuSan {                                    // per context; empty in the plain build
+#ifdef EMU_ASAN
+    void* fake = nullptr; const void* bottom = nullptr; size_t size = 0;
+#endif
+#ifdef EMU_TSAN
+    void* fiber = nullptr;
+#endif
+};
 #if defined(__x86_64__)
-struct EmuCtx { void* sp; };
+struct EmuCtx { void* sp; EmuSan san; };
 extern "C" void emu_ctx_switch(void** save_sp, void* load_sp);
 asm(R"(
 .text
@@ -62,8 +95,8 @@ emu_ctx_switch:
     ret
 .size emu_ctx_switch,.-emu_ctx_switch
 )");
-static inline void emu_swap(EmuCtx* from, EmuCtx* to) { emu_ctx_switch(&from->sp, to->sp); }
-static inline void emu_make(EmuCtx* c, void* stack, size_t size, void (*entry)()) {
+static inline void emu_swap_raw(EmuCtx* from, EmuCtx* to) { emu_ctx_switch(&from->sp, to->sp); }
+static inline void emu_make_raw(EmuCtx* c, void* stack, size_t size, void (*entry)()) {
     void** sp = reinterpret_cast<void**>((reinterpret_cast<uintptr_t>(stack) + size) & ~(uintptr_t)15);
     *--sp = nullptr;                               // the entry function's (never used) return address: rsp = 8 mod 16 at its first instruction
     *--sp = reinterpret_cast<void*>(entry);        // where the first switch into this context returns to
@@ -71,9 +104,9 @@ static inline void emu_make(EmuCtx* c, void* stack, size_t size, void (*entry)()
     c->sp = sp;
 }
 #else
-struct EmuCtx { ucontext_t uc; };
-static inline void emu_swap(EmuCtx* from, EmuCtx* to) { swapcontext(&from->uc, &to->uc); }
-static inline void emu_make(EmuCtx* c, void* stack, size_t size, void (*entry)()) {
+struct EmuCtx { ucontext_t uc; EmuSan san; };
+static inline void emu_swap_raw(EmuCtx* from, EmuCtx* to) { swapcontext(&from->uc, &to->uc); }
+static inline void emu_make_raw(EmuCtx* c, void* stack, size_t size, void (*entry)()) {
     getcontext(&c->uc);
     c->uc.uc_stack.ss_sp = stack;
     c->uc.uc_stack.ss_size = size;
@@ -81,6 +114,29 @@ static inline void emu_make(EmuCtx* c, void* stack, size_t size, void (*entry)()
     makecontext(&c->uc, entry, 0);
 }
 #endif
+// `leaving_for_good`: the context that switches away never runs again (ASan drops its fake stack)
+static inline void emu_swap(EmuCtx* from, EmuCtx* to, bool leaving_for_good = false) {
+#ifdef EMU_ASAN
+    __sanitizer_start_switch_fiber(leaving_for_good ? nullptr : &from->san.fake, to->san.bottom, to->san.size);
+#endif
+#ifdef EMU_TSAN
+    __tsan_switch_to_fiber(to->san.fiber, 0);
+#endif
+    emu_swap_raw(from, to);
+#ifdef EMU_ASAN
+    __sanitizer_finish_switch_fiber(from->san.fake, nullptr, nullptr);      // back in `from`, resumed by somebody's switch
+#endif
+    (void)leaving_for_good;
+}
+static inline void emu_make(EmuCtx* c, void* stack, size_t size, void (*entry)()) {
+    emu_make_raw(c, stack, size, entry);
+#ifdef EMU_ASAN
+    c->san.fake = nullptr; c->san.bottom = stack; c->san.size = size;
+#endif
+#ifdef EMU_TSAN
+    c->san.fiber = __tsan_create_fiber(0);
+#endif
+}
 struct EmuSched {
     EmuCtx main;
     std::vector<EmuCtx> ctx;
@@ -115,8 +171,9 @@ enum { hipStreamNonBlocking = 1 };
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
-static inline hipError_t hipMalloc(void** p, size_t n) { return posix_memalign(p, 256, n ? n : 256) ? 2 : 0; }
-static inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline std::atomic<long> emu_live_device_allocs{0};      // blocks handed out by hipMalloc / hipHostMalloc and not yet freed: the leak check of tests/test_abi_no_throw.py
+static inline hipError_t hipMalloc(void** p, size_t n) { if (posix_memalign(p, 256, n ? n : 256)) return 2; emu_live_device_allocs++; return 0; }
+static inline hipError_t hipFree(void* p) { if (p) emu_live_device_allocs--; free(p); return 0; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return 0; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
@@ -133,13 +190,16 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return 0; }
 static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return 0; }
 static inline hipError_t hipHostUnregister(void*) { return 0; }
-static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return posix_memalign(p, 4096, n ? n : 4096) ? 2 : 0; }
-static inline hipError_t hipHostFree(void* p) { free(p); return 0; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { if (posix_memalign(p, 4096, n ? n : 4096)) return 2; emu_live_device_allocs++; return 0; }
+static inline hipError_t hipHostFree(void* p) { if (p) emu_live_device_allocs--; free(p); return 0; }
 
 // ---- launcher ------------------------------------------------------------------------------
 static void emu_fiber_main() {
     EmuSched* s = emu_sched;
     const unsigned me = s->cur;
+#ifdef EMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &s->main.san.bottom, &s->main.san.size);      // first time on this stack; the stack we came from is the launching thread's
+#endif
     for (unsigned by = 0; by < s->grid.y; by++)
         for (unsigned bx = 0; bx < s->grid.x; bx++) {
             blockIdx = dim3(bx, by, 0);
@@ -147,7 +207,7 @@ static void emu_fiber_main() {
             __syncthreads();                      // workgroups run one after another (static __shared__ reuse)
         }
     s->done[me] = 1;
-    emu_swap(&s->ctx[me], &s->main);              // never resumed
+    emu_swap(&s->ctx[me], &s->main, true);        // never resumed
 }
 inline std::mutex& emu_launch_mutex() { static std::mutex m; return m; }
 template <class F>
@@ -176,6 +236,9 @@ static inline void emu_launch(dim3 grid, dim3 block, size_t smem_bytes, F f) {
     emu_smem = static_cast<unsigned char*>(smem);
     blockDim = block; gridDim = grid;
     for (unsigned t = 0; t < nt; t++) emu_make(&s->ctx[t], s->stack_mem.data() + (size_t)t * STACK, STACK, emu_fiber_main);
+#ifdef EMU_TSAN
+    s->main.san.fiber = __tsan_get_current_fiber();
+#endif
     unsigned remaining = nt;
     while (remaining) {
         for (unsigned t = 0; t < nt; t++) {
@@ -186,6 +249,9 @@ static inline void emu_launch(dim3 grid, dim3 block, size_t smem_bytes, F f) {
             if (s->done[t]) remaining--;
         }
     }
+#ifdef EMU_TSAN
+    for (unsigned t = 0; t < nt; t++) __tsan_destroy_fiber(s->ctx[t].san.fiber);
+#endif
     emu_sched = nullptr;
 }
 #define ZK_LAUNCH(kern, grid, block, smem, stream, ...) \

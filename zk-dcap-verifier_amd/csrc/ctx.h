@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <stdio.h>
+#include <list>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -10,6 +11,7 @@
 #include <vector>
 #include "ec.cuh"
 #include "../../include/zkmi355.h"
+#include "abi_guard.h"
 
 namespace zk {
 
@@ -65,6 +67,16 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct DevTmp {               // a device allocation that lives until the end of its scope unless release() hands it on (error returns and exceptions free it)
+    void* p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    void* release() { void* q = p; p = nullptr; return q; }
+    void reset() { if (p) (void)hipFree(p); p = nullptr; }
+};
+
 struct TableMem {             // the window-expanded table in HBM; shared (refcounted) by every context of the process that registered or was lent it
     void* p = nullptr;
     int device = 0;
@@ -98,6 +110,7 @@ struct TwiddleSet {           // per (omega, log_n)
     // inter-pass twiddles of its LAST strided pass instead (that pass multiplies every element anyway): such a set's d_full[passes - 2] holds twiddle * scale
     bool scale_fused = false;
     u256 fused_scale;
+    uint64_t stamp = 0;       // zk_ctx::twiddle_clock at the last use (ntt.hip keeps the 16 most recently used sets)
 };
 
 struct QuotProgram;  // quotient.hip
@@ -107,12 +120,13 @@ struct QuotProgram;  // quotient.hip
 struct zk_ctx {
     int device = 0;
     std::mutex mu;            // calls are serialised per context (thread-safe, blocking)
-    std::string err;
+    char err[640] = {0};      // zk_last_error: a fixed buffer, so that reporting a failure (an exhausted heap included) allocates nothing
     hipStream_t stream = nullptr;
     zk::Tune tune;
     uint64_t next_handle = 1;
     std::map<uint64_t, zk::BaseTable> bases;
-    std::vector<zk::TwiddleSet> twiddles;
+    std::list<zk::TwiddleSet> twiddles;    // (a list: a set's address survives the eviction of another)
+    uint64_t twiddle_clock = 0;
     std::map<uint64_t, void*> coset_tables;                           // ntt.hip: (k, extended_k, coset) -> pre-scaling table of a coset transform
     std::map<uint64_t, std::shared_ptr<zk::QuotProgram>> programs;   // compiled micro-programs are immutable once loaded: contexts of one device may share them (zk_quotient_program_share)
     std::map<uint64_t, std::vector<uint32_t>> lookup_tie_hint;   // lookupperm.hip: columns whose rows tied on the sort window in the previous call of the same shape
@@ -128,12 +142,12 @@ struct zk_ctx {
     zk_ctx* helper = nullptr;
 
     int fail(int code, const char* fmt, ...) {
-        char buf[512];
+        char buf[sizeof err];                  // (callers pass zk_last_error's own text back in as an argument)
         va_list ap;
         va_start(ap, fmt);
         vsnprintf(buf, sizeof buf, fmt, ap);
         va_end(ap);
-        err = buf;
+        memcpy(err, buf, sizeof err);
         return code;
     }
 };
@@ -147,6 +161,7 @@ struct zk_ctx {
 #define ZK_CHECK_LAUNCH() ZK_HIP(hipGetLastError())
 
 namespace zk {
+inline void resolve_pending_timers(zk_ctx* ctx);
 struct EvTimer {
     zk_ctx* ctx; const char* label; hipEvent_t a = nullptr, b = nullptr; bool on;
     EvTimer(zk_ctx* c, const char* l) : ctx(c), label(l), on(c->timing) {
@@ -157,19 +172,34 @@ struct EvTimer {
         if (!on) return;
         (void)hipEventSynchronize(b);
         float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
-        ctx->last_ms[label] += ms; ctx->last_ms[std::string(label) + "#n"] += 1.0;
+        on = false;
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        ctx->last_ms[label] += ms; ctx->last_ms[std::string(label) + "#n"] += 1.0;
     }
-    // for entry points that return without waiting for their kernels (the NTT passes): the event pair is read at the next zk_timing_get
-    void defer() { if (on) { ctx->pending_timers.push_back({label, a, b}); on = false; } }
+    // for entry points that return without waiting for their kernels (the NTT passes): the event pair is read at the next zk_timing_get — or here, when a long timed run
+    // that never asks has let the list grow (one pair per pass otherwise, without bound)
+    void defer() {
+        if (!on) return;
+        if (ctx->pending_timers.size() >= 4096) resolve_pending_timers(ctx);
+        ctx->pending_timers.push_back({label, a, b});
+        on = false;
+    }
+    ~EvTimer() { if (on) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }       // an early return between the constructor and resolve() / defer()
+    EvTimer(const EvTimer&) = delete;
+    EvTimer& operator=(const EvTimer&) = delete;
 };
 inline void resolve_pending_timers(zk_ctx* ctx) {
-    for (auto& t : ctx->pending_timers) {
+    std::vector<zk_ctx::PendingTimer> list;
+    list.swap(ctx->pending_timers);                                   // (the events are destroyed whatever the bookkeeping below does)
+    struct Drop { std::vector<zk_ctx::PendingTimer>& l; ~Drop() { for (auto& t : l) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); } } } drop{list};
+    for (auto& t : list) {
         (void)hipEventSynchronize(t.b);
         float ms = 0; (void)hipEventElapsedTime(&ms, t.a, t.b);
         ctx->last_ms[t.label] += ms; ctx->last_ms[std::string(t.label) + "#n"] += 1.0;
-        (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
     }
+}
+inline void drop_pending_timers(zk_ctx* ctx) {                        // zk_ctx_destroy
+    for (auto& t : ctx->pending_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     ctx->pending_timers.clear();
 }
 

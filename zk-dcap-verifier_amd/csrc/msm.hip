@@ -806,10 +806,10 @@ static int pick_c(size_t n, const Tune& t) {
 static int build_table(zk_ctx* ctx, const void* d_pts, size_t n, BaseTable& bt) {
     const int c = bt.c, W = bt.W;
     const size_t tbytes = (size_t)W * n * 64;
-    ZK_HIP(hipMalloc(&bt.d_table, tbytes));
-    bt.mem = std::make_shared<TableMem>();
-    bt.mem->p = bt.d_table;
+    bt.mem = std::make_shared<TableMem>();                            // (the owner first: whatever fails below, the table goes with its last holder)
     bt.mem->device = ctx->device;
+    ZK_HIP(hipMalloc(&bt.mem->p, tbytes));
+    bt.d_table = bt.mem->p;
     ZK_HIP(hipMemcpyAsync(bt.d_table, d_pts, n * 64, hipMemcpyDeviceToDevice, ctx->stream));
     if (W > 1) {
         ZK_HIP(ctx->ws_pts.ensure(n * 128));
@@ -924,29 +924,27 @@ int msm_enable_runs(zk_ctx* ctx, uint64_t handle) {
     const uint32_t chunk = 64, m = (uint32_t)((n + chunk - 1) / chunk);
     const int blk = ctx->tune.msm_block;
     hipStream_t st = ctx->stream;
-    void *d_tot = nullptr, *d_pre = nullptr, *d_aff = nullptr;
-    auto cleanup = [&]() { if (d_tot) (void)hipFree(d_tot); if (d_pre) (void)hipFree(d_pre); if (d_aff) (void)hipFree(d_aff); };
-    hipError_t e = hipMalloc(&d_tot, (size_t)m * 128);
-    if (e == hipSuccess) e = hipMalloc(&d_pre, n * 128);
-    if (e == hipSuccess) e = hipMalloc(&d_aff, n * 64);
-    if (e != hipSuccess) { cleanup(); return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: device allocation failed"); }
+    DevTmp t_tot, t_pre, t_aff;                                       // freed on every way out
+    hipError_t e = hipMalloc(&t_tot.p, (size_t)m * 128);
+    if (e == hipSuccess) e = hipMalloc(&t_pre.p, n * 128);
+    if (e == hipSuccess) e = hipMalloc(&t_aff.p, n * 64);
+    if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: device allocation failed");
+    void* const d_tot = t_tot.p; void* const d_pre = t_pre.p; void* const d_aff = t_aff.p;
     ZK_LAUNCH(g1_chunk_total_kernel, (m + blk - 1) / blk, blk, 0, st, (const void*)bt.d_table, (uint32_t)n, chunk, d_tot);
     std::vector<XYZZ> tot(m), excl(m);
-    if (hipMemcpyAsync(tot.data(), d_tot, (size_t)m * 128, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-        cleanup(); return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: chunk totals");
-    }
+    if (hipMemcpyAsync(tot.data(), d_tot, (size_t)m * 128, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: chunk totals");
     XYZZ run = xyzz_identity();                                      // exclusive scan of the chunk totals on the host (one-time, n / 64 additions)
     for (uint32_t t = 0; t < m; t++) { excl[t] = run; xyzz_add(run, tot[t]); }
-    if (hipMemcpyAsync(d_tot, excl.data(), (size_t)m * 128, hipMemcpyHostToDevice, st) != hipSuccess) { cleanup(); return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: upload"); }
+    if (hipMemcpyAsync(d_tot, excl.data(), (size_t)m * 128, hipMemcpyHostToDevice, st) != hipSuccess) return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: upload");
     ZK_LAUNCH(g1_chunk_prefix_kernel, (m + blk - 1) / blk, blk, 0, st, (const void*)bt.d_table, (uint32_t)n, chunk, (const void*)d_tot, d_pre);
     const uint32_t bchunk = 32;
     ZK_LAUNCH(g1_batch_to_affine_kernel, (uint32_t)(((n + bchunk - 1) / bchunk + blk - 1) / blk), blk, 0, st, (const void*)d_pre, (uint32_t)n, bchunk, d_aff);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { cleanup(); return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: prefix kernels"); }
-    (void)hipFree(d_pre); d_pre = nullptr;
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ctx->fail(ZK_ERR_HIP, "zk_bases_enable_runs: prefix kernels");
+    t_pre.reset();
     BaseTable ps;
     ps.n = n; ps.c = bt.c; ps.W = bt.W;
     int rc = build_table(ctx, d_aff, n, ps);
-    cleanup();
     if (rc) return rc;
     bt.d_runs_table = ps.d_table;
     bt.runs_mem = ps.mem;
@@ -1232,9 +1230,10 @@ static int ensure_gtab(zk_ctx* ctx, void** out) {
     std::lock_guard<std::mutex> lk(g_gtab_mu);
     GTab& g = g_gtabs[ctx];
     if (!g.d) {
-        void* row = nullptr; void* tab = nullptr;
-        ZK_HIP(hipMalloc(&row, 255 * 128));
-        ZK_HIP(hipMalloc(&tab, (size_t)32 * 255 * 64));
+        DevTmp t_row, t_tab;
+        ZK_HIP(hipMalloc(&t_row.p, 255 * 128));
+        ZK_HIP(hipMalloc(&t_tab.p, (size_t)32 * 255 * 64));
+        void* const row = t_row.p; void* const tab = t_tab.p;
         ZK_LAUNCH(g1_gtab_row0_kernel, 1, 256, 0, ctx->stream, row);
         ZK_CHECK_LAUNCH();
         for (int w = 0; w < 32; w++) {
@@ -1243,8 +1242,7 @@ static int ensure_gtab(zk_ctx* ctx, void** out) {
             ZK_CHECK_LAUNCH();
         }
         ZK_HIP(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(row);
-        g.d = tab;
+        g.d = t_tab.release();
     }
     *out = g.d;
     return ZK_OK;

@@ -534,6 +534,15 @@ static void plan_passes(uint32_t log_n, const Tune& tn, uint32_t rl[3], int* pas
 
 // scale (optional): a constant every output of the transform is multiplied by; folded into the last strided pass's full twiddle table when the plan has one
 // (TwiddleSet::scale_fused tells the caller whether it was)
+static void free_twiddle_set(TwiddleSet& t) {
+    if (t.d_lo) (void)hipFree(t.d_lo);
+    if (t.d_hi) (void)hipFree(t.d_hi);
+    for (int i = 0; i < 3; i++) { if (t.d_stage[i]) (void)hipFree(t.d_stage[i]); if (t.d_stage_sh[i]) (void)hipFree(t.d_stage_sh[i]); if (t.d_stage29[i]) (void)hipFree(t.d_stage29[i]); if (t.d_full[i]) (void)hipFree(t.d_full[i]); }
+    t = TwiddleSet();
+}
+// A context keeps at most this many sets (one per (log n, omega, plan, fused scale): a prover touches 5-6 of them; a caller that walks sizes or tunables
+// would otherwise grow the list — up to 2 x 32 B x n each — without bound): the least recently used one goes.
+static const size_t MAX_TWIDDLE_SETS = 16;
 static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, const u256* scale, TwiddleSet** out) {
     uint32_t rl[3];
     int passes;
@@ -542,8 +551,9 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, const u2
     const bool fuse = scale && full && ctx->tune.ntt_fuse_scale;
     for (auto& t : ctx->twiddles)
         if (t.log_n == log_n && Fr::eq(t.omega, omega) && t.passes == passes && t.radix_log[0] == rl[0] && t.radix_log[1] == rl[1] &&
-            t.radix_log[2] == rl[2] && (t.d_full[0] != nullptr) == full && t.scale_fused == fuse && (!fuse || Fr::eq(t.fused_scale, *scale))) { *out = &t; return ZK_OK; }
-    TwiddleSet ts;
+            t.radix_log[2] == rl[2] && (t.d_full[0] != nullptr) == full && t.scale_fused == fuse && (!fuse || Fr::eq(t.fused_scale, *scale))) { t.stamp = ++ctx->twiddle_clock; *out = &t; return ZK_OK; }
+    struct Pending { TwiddleSet ts; ~Pending() { free_twiddle_set(ts); } } pending;      // a failing allocation or launch below frees the tables made so far
+    TwiddleSet& ts = pending.ts;
     ts.log_n = log_n; ts.omega = omega; ts.passes = passes;
     ts.scale_fused = fuse;
     if (fuse) ts.fused_scale = *scale;
@@ -597,17 +607,21 @@ static int get_twiddles(zk_ctx* ctx, uint32_t log_n, const u256& omega, const u2
         }
     }
     ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->twiddles.size() >= MAX_TWIDDLE_SETS) {                    // (the stream is idle: no kernel still reads the victim's tables; sets whose pointers this call already holds carry later stamps)
+        auto victim = ctx->twiddles.begin();
+        for (auto it = ctx->twiddles.begin(); it != ctx->twiddles.end(); ++it) if (it->stamp < victim->stamp) victim = it;
+        free_twiddle_set(*victim);
+        ctx->twiddles.erase(victim);
+    }
+    ts.stamp = ++ctx->twiddle_clock;
     ctx->twiddles.push_back(ts);
+    ts = TwiddleSet();                                                 // (the list owns the tables now)
     *out = &ctx->twiddles.back();
     return ZK_OK;
 }
 
 void release_twiddles(zk_ctx* ctx) {
-    for (auto& t : ctx->twiddles) {
-        if (t.d_lo) (void)hipFree(t.d_lo);
-        if (t.d_hi) (void)hipFree(t.d_hi);
-        for (int i = 0; i < 3; i++) { if (t.d_stage[i]) (void)hipFree(t.d_stage[i]); if (t.d_stage_sh[i]) (void)hipFree(t.d_stage_sh[i]); if (t.d_stage29[i]) (void)hipFree(t.d_stage29[i]); if (t.d_full[i]) (void)hipFree(t.d_full[i]); }
-    }
+    for (auto& t : ctx->twiddles) free_twiddle_set(t);
     ctx->twiddles.clear();
     for (auto& kv : ctx->coset_tables) (void)hipFree(kv.second);
     ctx->coset_tables.clear();
@@ -796,15 +810,17 @@ static int coset_table(zk_ctx* ctx, uint32_t k, uint32_t ek, uint32_t coset, con
     const uint64_t key = ((uint64_t)k << 48) | ((uint64_t)ek << 32) | coset;
     auto it = ctx->coset_tables.find(key);
     if (it == ctx->coset_tables.end()) {
-        void* d = nullptr;
-        ZK_HIP(hipMalloc(&d, (size_t)32 << k));
+        DevTmp t;
+        ZK_HIP(hipMalloc(&t.p, (size_t)32 << k));
+        void* const d = t.p;
         u256 c32 = Fr::zero();
         c32.v[0] = 32;
         c32 = Fr::to_mont(c32);
         ZK_LAUNCH(ntt_coset_table_kernel, (uint32_t)((((size_t)1 << k) + 255) / 256), 256, 0, ctx->stream, f.cs_lo, f.cs_hi, f.cs_lo_bits, coset, ek, c32, Fr::mul(zeta_pow(1), c32), Fr::mul(zeta_pow(2), c32),
                   (uint32_t)1 << k, d);
-        if (hipGetLastError() != hipSuccess) { (void)hipFree(d); return ctx->fail(ZK_ERR_HIP, "ntt_coset_table_kernel: launch failed"); }
+        if (hipGetLastError() != hipSuccess) return ctx->fail(ZK_ERR_HIP, "ntt_coset_table_kernel: launch failed");
         it = ctx->coset_tables.emplace(key, d).first;
+        (void)t.release();
     }
     *out = it->second;
     return ZK_OK;

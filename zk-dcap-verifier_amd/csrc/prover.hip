@@ -22,11 +22,13 @@
 #include <vector>
 #include "field.cuh"
 #include "../../include/zkmi355.h"
+#include "abi_guard.h"
 
 using namespace zk;
 
 int zk_internal_fail(zk_ctx* ctx, int code, const char* msg);   // capi.hip: sets zk_last_error(ctx)
 zk_ctx* zk_internal_helper_ctx(zk_ctx* ctx);                      // capi.hip: the helper context of ctx (ctx.h), or null
+void zk_internal_trim_helper(zk_ctx* ctx);                        // capi.hip: give the helper context's grow-only device memory back (zk_plonk_trim)
 
 namespace {
 int pk_fail(zk_ctx* ctx, int code, const char* fmt, ...) {
@@ -305,13 +307,13 @@ struct Arena {                                                        // everyth
             if (!v.empty()) { p = v.back(); v.pop_back(); }
         }
         if (!p && zk_dev_alloc(ctx, bytes, &p) != ZK_OK) return nullptr;
-        held.push_back({p, bytes});
+        try { held.push_back({p, bytes}); } catch (...) { put(p, bytes); throw; }
         return p;
     }
-    void put(void* p, size_t bytes) {
-        bool retired;
-        { std::lock_guard<std::mutex> lk(pool->mu); retired = pool->retired; if (!retired) pool->free_[bytes].push_back(p); }
-        if (retired) (void)zk_dev_free(ctx, p);
+    void put(void* p, size_t bytes) noexcept {                         // (runs in destructors: a buffer the free list cannot take is freed instead)
+        bool keep = false;
+        try { std::lock_guard<std::mutex> lk(pool->mu); if (!pool->retired) { pool->free_[bytes].push_back(p); keep = true; } } catch (...) {}
+        if (!keep) (void)zk_dev_free(ctx, p);
     }
     void give_back(void* p) {
         for (auto& h : held) if (h.first == p) { put(p, h.second); h.first = nullptr; return; }
@@ -332,6 +334,7 @@ struct SideLane {
     size_t open = 0; bool closing = false; int rc = ZK_OK;
     void start(zk_ctx* helper) {
         h = helper;
+        fault_thread_tick();
         th = std::thread([this]() {
             std::unique_lock<std::mutex> lk(mu);
             while (true) {
@@ -341,7 +344,8 @@ struct SideLane {
                 q.pop_front();
                 const int before = rc;
                 lk.unlock();
-                const int r = before ? before : f();                  // (after an error the remaining jobs are dropped)
+                int r = before;                                       // (after an error the remaining jobs are dropped)
+                if (!r) { try { r = f(); } catch (...) { r = abi_exception(h, "zk_plonk_create_proof (helper thread)"); } }      // nothing may leave a thread's entry function: it becomes the lane's rc
                 lk.lock();
                 if (r && !rc) rc = r;
                 open--;
@@ -367,6 +371,7 @@ struct Draws {
     std::mutex mu; std::condition_variable cv; size_t done = 0;
     std::thread th;
     std::atomic<bool> abandoned{false};                                // the proof ended early (an error): stop asking the caller for randomness nobody will use
+    int failed = 0;                                                    // the helper thread could not get its buffer (mu): every take() from then on throws the code to the proof's thread
     void start(zk_rng_fn rng, void* user, std::shared_ptr<Pool> p) {
         pool = std::move(p);
         size_t total = 4;
@@ -375,8 +380,15 @@ struct Draws {
             std::lock_guard<std::mutex> lk(pool->mu);
             if (!pool->draw_bufs.empty()) { buf.swap(pool->draw_bufs.back()); pool->draw_bufs.pop_back(); }
         }
+        fault_thread_tick();
         th = std::thread([this, rng, user, total]() {
-            if (buf.size() < total) buf.resize(total);                 // (first proof of a context only; on the helper thread, off the proof's critical path)
+            try {
+                if (buf.size() < total) buf.resize(total);             // (first proof of a context only; on the helper thread, off the proof's critical path)
+            } catch (...) {
+                { std::lock_guard<std::mutex> lk(mu); failed = abi_exception(nullptr, "zk_plonk_create_proof (rng thread)"); }
+                cv.notify_all();
+                return;
+            }
             for (size_t i = 0; i < counts.size() && !abandoned.load(); i++) {
                 if (counts[i]) rng(user, counts[i], buf.data() + offs[i]);
                 { std::lock_guard<std::mutex> lk(mu); done = i + 1; }
@@ -384,12 +396,19 @@ struct Draws {
             }
         });
     }
-    const uint64_t* take(size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done > i; }); return buf.data() + offs[i]; }
+    const uint64_t* take(size_t i) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done > i || failed; });
+        if (failed) throw AbiError{failed, "the rng helper thread could not allocate its draw buffer"};
+        return buf.data() + offs[i];
+    }
     void finish() { if (!counts.empty()) (void)take(counts.size() - 1); }     // a successful proof leaves the caller's stream where halo2 would: every planned draw made
     ~Draws() {
         abandoned.store(true);
         if (th.joinable()) th.join();
-        if (pool && !buf.empty()) { std::lock_guard<std::mutex> lk(pool->mu); if (!pool->retired && pool->draw_bufs.size() < 8) pool->draw_bufs.emplace_back(std::move(buf)); }
+        try {
+            if (pool && !buf.empty()) { std::lock_guard<std::mutex> lk(pool->mu); if (!pool->retired && pool->draw_bufs.size() < 8) pool->draw_bufs.emplace_back(std::move(buf)); }
+        } catch (...) {}                                              // (a destructor: the buffer is simply not kept)
     }
 };
 
@@ -451,6 +470,7 @@ struct ShardSignal {
     size_t next = 0;                                                   // the exchange every healthy rank enters next
     void* xsend = nullptr; void* xrecv = nullptr;
     bool armed = false;
+    Arena* xmem = nullptr;                                             // the wrapper's arena: library-owned exchange buffers must outlive the body, whose failure they announce
 };
 static const uint64_t POISON[4] = {~0ull, ~0ull, ~0ull, ~0ull};
 
@@ -463,10 +483,15 @@ static std::atomic<int> g_proofs_in_flight{0};
 struct InFlight { InFlight() { g_proofs_in_flight.fetch_add(1); } ~InFlight() { g_proofs_in_flight.fetch_sub(1); } };
 
 extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
-                                     const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len) {
+                                     const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len) ZK_ABI_TRY {
+    if (!ctx || !pk) return ZK_ERR_ARG;
     InFlight counted;
+    Arena xmem(ctx);                                                   // (before the body's own arena: a failing body has returned everything else when the poisoned block travels)
     ShardSignal sig;
-    const int rc = create_proof_body(ctx, pk, advice, advice_on_device, instances, instance_lens, rng, rng_user, proof_out, proof_cap, proof_len, sig);
+    sig.xmem = &xmem;
+    int rc;
+    try { rc = create_proof_body(ctx, pk, advice, advice_on_device, instances, instance_lens, rng, rng_user, proof_out, proof_cap, proof_len, sig); }
+    catch (...) { rc = abi_exception(ctx, "zk_plonk_create_proof"); }   // (here rather than at the barrier below: the other ranks of a sharded proof are told first)
     if (rc != ZK_OK && rc != ZK_ERR_COMM && sig.armed && sig.next < sig.sizes.size()) {
         std::string why = zk_last_error(ctx) ? zk_last_error(ctx) : "";
         if (zk_dev_upload(ctx, sig.xsend, POISON, 32) == ZK_OK && zk_dev_sync(ctx) == ZK_OK)
@@ -474,7 +499,7 @@ extern "C" int zk_plonk_create_proof(zk_ctx* ctx, const zk_plonk_pk_desc* pk, co
         pk_fail(ctx, rc, "%s [rank %u of a sharded proof: failure signalled to the other ranks in exchange %zu]", why.c_str(), pk->shard_rank, sig.next);
     }
     return rc;
-}
+} ZK_ABI_CATCH(ctx)
 
 static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void* const* advice, int advice_on_device, const void* const* instances,
                              const uint32_t* instance_lens, zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len, ShardSignal& sig) {
@@ -537,7 +562,7 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
         const size_t most_cols = std::max<size_t>({pk->n_advice, 2 * (size_t)L, (size_t)n_sets + L, n_pieces, 1});
         const size_t need = std::max(slots * unit_rows * 32, most_cols * 128);
         if (pk->xchg_send && pk->xchg_recv) { if (pk->xchg_cap < need) return ZK_ERR_LIMIT; xsend = pk->xchg_send; xrecv = pk->xchg_recv; }
-        else { xsend = mem.get(need); xrecv = mem.get(need * world); if (!xsend || !xrecv) return ZK_ERR_HIP; }
+        else { xsend = sig.xmem->get(need); xrecv = sig.xmem->get(need * world); if (!xsend || !xrecv) return ZK_ERR_HIP; }
         for (size_t cols : {(size_t)pk->n_advice, 2 * (size_t)L, (size_t)n_sets + L, (size_t)1}) if (cols) sig.sizes.push_back(cols * 128);   // advice, permuted pairs, grand products, random poly
         sig.sizes.push_back(slots * unit_rows * 32);                                                                                       // the quotient's numerators
         for (size_t cols : {(size_t)n_pieces, (size_t)1, (size_t)1}) sig.sizes.push_back(cols * 128);                                        // h pieces, SHPLONK h(X) and quotient
@@ -623,7 +648,7 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
         int want = 0;
         if (!sharded && !by_cosets && zk_tune_get(ctx, "prover_side_lane", &want) == ZK_OK && (want >= 2 || (want == 1 && g_proofs_in_flight.load() <= 2))) {
             zk_ctx* h = zk_internal_helper_ctx(ctx);
-            if (h) { lane.start(h); side = true; }
+            if (h) { try { lane.start(h); side = true; } catch (const std::system_error&) { side = false; } }      // no thread to be had: the proof runs in one lane, as with three proofs in flight
         }
     }
     std::vector<void*> coefA, extA, coefB, extB, coefC, extC;         // coefficient and extended forms of: advice + instance | permuted pairs | grand products
@@ -747,6 +772,14 @@ static int create_proof_body(zk_ctx* ctx, const zk_plonk_pk_desc* pk, const void
     if (side) {                                                       // the helper context has brought every column to both forms: from here on the vectors name the coefficient forms
         const int rc_side = lane.wait();
         if (rc_side) return pk_fail(ctx, rc_side, "zk_plonk_create_proof: transforms on the helper context: %s", zk_last_error(lane.h));
+        // the Lagrange forms have been committed (this context, synchronous calls) and copied (the lane, waited for above): nothing reads them again.  Back to the pool now
+        // rather than at the end of the proof — the lane's copies would otherwise double the columns a proof holds through its quotient phase.  Not the caller's own
+        // advice_on_device columns (give_back only knows what the arena handed out).
+        for (void* p : adv) mem.give_back(p);
+        for (void* p : inst_values) mem.give_back(p);
+        for (void* p : zs) mem.give_back(p);
+        for (void* p : lzs) mem.give_back(p);
+        for (uint32_t l = 0; l < L; l++) { mem.give_back(pin[l]); mem.give_back(ptab[l]); mem.give_back(cin[l]); mem.give_back(ctab[l]); }
         for (uint32_t i = 0; i < pk->n_advice; i++) { adv[i] = coefA[i]; side_ext.push_back(extA[i]); }
         for (uint32_t c = 0; c < pk->n_instance; c++) { inst_values[c] = coefA[pk->n_advice + c]; side_ext.push_back(extA[pk->n_advice + c]); }
         for (uint32_t s_ = 0; s_ < n_sets; s_++) { zs[s_] = coefC[s_]; side_ext.push_back(extC[s_]); }
@@ -1131,7 +1164,7 @@ void pk_drop(zk_ctx* ctx, PkHandle* h) {                              // g_pk_mu
 }
 }  // namespace
 
-extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk) {
+extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk) ZK_ABI_TRY {
     if (!ctx || !host || !pk) return ZK_ERR_ARG;
     if (host->struct_size != sizeof(zk_plonk_pk_host))
         return pk_fail(ctx, ZK_ERR_ARG, "zk_plonk_pk_build: zk_plonk_pk_host.struct_size %u, expected %zu (ABI version %u)", host->struct_size, sizeof(zk_plonk_pk_host), ZK_ABI_VERSION);
@@ -1148,11 +1181,18 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
     if (ek > 27) return ZK_ERR_LIMIT;
     const size_t ext_bytes = (size_t)32 << ek;
     PkHandle* h = new PkHandle();
+    struct Undo { zk_ctx* ctx; PkHandle* h; ~Undo() { if (h) { std::lock_guard<std::mutex> lk(g_pk_mu); pk_drop(ctx, h); } } } undo{ctx, h};      // every way out but the last line drops the half-built key
     h->mem = new PkMem();
     h->mem->holders = 1;
     PkMem* m = h->mem;
-    auto fail = [&](int rc) { std::lock_guard<std::mutex> lk(g_pk_mu); pk_drop(ctx, h); return rc; };
-    auto alloc = [&](size_t bytes) -> void* { void* p = nullptr; if (zk_dev_alloc(ctx, bytes, &p) != ZK_OK) return nullptr; m->owned.push_back(p); return p; };
+    auto fail = [&](int rc) { return rc; };
+    auto alloc = [&](size_t bytes) -> void* {
+        m->owned.reserve(m->owned.size() + 1);                         // (the slot first: a buffer is never allocated without an owner to free it)
+        void* p = nullptr;
+        if (zk_dev_alloc(ctx, bytes, &p) != ZK_OK) return nullptr;
+        m->owned.push_back(p);
+        return p;
+    };
     // values -> (values, polys, cosets); `src` are host columns, or device columns that are borrowed as they are
     // a sharded key keeps only the cosets this rank's quotient units live on (the unit rule of zk_plonk_pk_desc), n values per column
     const uint32_t world = host->shard_world > 1 ? host->shard_world : 1;
@@ -1220,17 +1260,17 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
         memcpy(&col[0], one.v, 32);
         memcpy(&col[(n + last) * 4], one.v, 32);
         for (size_t i = 0; i < last; i++) memcpy(&col[(2 * n + i) * 4], one.v, 32);
-        std::vector<void*> tmp(3, nullptr);
+        struct Tmp { zk_ctx* ctx; std::vector<void*> v; ~Tmp() { for (void* p : v) if (p) (void)zk_dev_free(ctx, p); } } t{ctx, std::vector<void*>(3, nullptr)};
+        std::vector<void*>& tmp = t.v;
         const void* hs[3];
         for (int i = 0; i < 3; i++) {
-            if (zk_dev_alloc(ctx, col_bytes, &tmp[i]) != ZK_OK) { for (int j = 0; j < i; j++) (void)zk_dev_free(ctx, tmp[j]); return fail(ZK_ERR_HIP); }
+            if (zk_dev_alloc(ctx, col_bytes, &tmp[i]) != ZK_OK) return fail(ZK_ERR_HIP);
             hs[i] = &col[(size_t)i * n * 4];
         }
         rc = zk_dev_upload_batch(ctx, tmp.data(), hs, 3, col_bytes);
         if (!rc) rc = zk_lagrange_to_coeff_batch_dev(ctx, tmp.data(), 3, k);
         std::vector<const void*> ext;
         if (!rc) rc = to_cosets(tmp, ext, m->coset_l);
-        for (int i = 0; i < 3; i++) (void)zk_dev_free(ctx, tmp[i]);
         if (rc) return fail(rc);
         for (int i = 0; i < 3 && whole_domain; i++) m->l[i] = (void*)ext[i];
     }
@@ -1257,19 +1297,23 @@ extern "C" int zk_plonk_pk_build(zk_ctx* ctx, const zk_plonk_pk_host* host, uint
     shape.transcript = host->transcript; shape.draw_schedule = host->draw_schedule;
     shape.shard_world = host->shard_world; shape.shard_rank = host->shard_rank; shape.allgather = host->allgather; shape.allgather_user = host->allgather_user;
     pk_fill_desc(h, shape, srs_g, srs_g_lagrange);
-    std::lock_guard<std::mutex> lk(g_pk_mu);
-    *pk = g_pk_next++;
-    g_pk_handles[{ctx, *pk}] = h;
+    {
+        std::lock_guard<std::mutex> lk(g_pk_mu);
+        g_pk_handles[{ctx, g_pk_next}] = h;
+        *pk = g_pk_next++;
+    }
+    undo.h = nullptr;
     return ZK_OK;
-}
+} ZK_ABI_CATCH(ctx)
 
-extern "C" int zk_plonk_pk_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_pk, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk) {
+extern "C" int zk_plonk_pk_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_pk, uint64_t srs_g, uint64_t srs_g_lagrange, uint64_t* pk) ZK_ABI_TRY {
     if (!ctx || !owner || !pk) return ZK_ERR_ARG;
     std::lock_guard<std::mutex> lk(g_pk_mu);
     auto it = g_pk_handles.find({owner, owner_pk});
     if (it == g_pk_handles.end()) return ZK_ERR_ARG;
     const PkHandle* src = it->second;
     PkHandle* h = new PkHandle();
+    struct Undo { zk_ctx* ctx; PkHandle* h; ~Undo() { if (h) pk_drop(ctx, h); } } undo{ctx, h};      // (g_pk_mu is held for the whole function)
     h->mem = src->mem;
     h->mem->holders++;
     const size_t L = src->desc.n_lookups;
@@ -1279,14 +1323,15 @@ extern "C" int zk_plonk_pk_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_pk, 
         rc = zk_quotient_program_share(ctx, owner, src->in_prog[l], &h->in_prog[l]);
         if (!rc) rc = zk_quotient_program_share(ctx, owner, src->tab_prog[l], &h->tab_prog[l]);
     }
-    if (rc) { pk_drop(ctx, h); return rc; }
+    if (rc) return rc;
     pk_fill_desc(h, src->desc, srs_g, srs_g_lagrange);
+    g_pk_handles[{ctx, g_pk_next}] = h;
     *pk = g_pk_next++;
-    g_pk_handles[{ctx, *pk}] = h;
+    undo.h = nullptr;
     return ZK_OK;
-}
+} ZK_ABI_CATCH(ctx)
 
-extern "C" int zk_plonk_pk_release(zk_ctx* ctx, uint64_t pk) {
+extern "C" int zk_plonk_pk_release(zk_ctx* ctx, uint64_t pk) ZK_ABI_TRY {
     if (!ctx) return ZK_ERR_ARG;
     std::lock_guard<std::mutex> lk(g_pk_mu);
     auto it = g_pk_handles.find({ctx, pk});
@@ -1295,19 +1340,19 @@ extern "C" int zk_plonk_pk_release(zk_ctx* ctx, uint64_t pk) {
     else pk_drop(ctx, it->second);
     g_pk_handles.erase(it);
     return ZK_OK;
-}
+} ZK_ABI_CATCH(ctx)
 
-extern "C" int zk_plonk_pk_descriptor(zk_ctx* ctx, uint64_t pk, const zk_plonk_pk_desc** desc) {
+extern "C" int zk_plonk_pk_descriptor(zk_ctx* ctx, uint64_t pk, const zk_plonk_pk_desc** desc) ZK_ABI_TRY {
     if (!ctx || !desc) return ZK_ERR_ARG;
     std::lock_guard<std::mutex> lk(g_pk_mu);
     auto it = g_pk_handles.find({ctx, pk});
     if (it == g_pk_handles.end()) return ZK_ERR_ARG;
     *desc = &it->second->desc;
     return ZK_OK;
-}
+} ZK_ABI_CATCH(ctx)
 
 extern "C" int zk_plonk_prove(zk_ctx* ctx, uint64_t pk, const void* const* advice, int advice_on_device, const void* const* instances, const uint32_t* instance_lens,
-                              zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len) {
+                              zk_rng_fn rng, void* rng_user, void* proof_out, size_t proof_cap, size_t* proof_len) ZK_ABI_TRY {
     if (!ctx) return ZK_ERR_ARG;
     PkHandle* h = nullptr;
     {   // the handle (descriptor, programs, its share of the columns) stays alive for the whole proof whatever other threads release meanwhile
@@ -1317,13 +1362,9 @@ extern "C" int zk_plonk_prove(zk_ctx* ctx, uint64_t pk, const void* const* advic
         h = it->second;
         h->in_use++;
     }
-    int rc = zk_plonk_create_proof(ctx, &h->desc, advice, advice_on_device, instances, instance_lens, rng, rng_user, proof_out, proof_cap, proof_len);
-    {
-        std::lock_guard<std::mutex> lk(g_pk_mu);
-        if (--h->in_use == 0 && h->released) pk_drop(ctx, h);
-    }
-    return rc;
-}
+    struct Done { zk_ctx* ctx; PkHandle* h; ~Done() { std::lock_guard<std::mutex> lk(g_pk_mu); if (--h->in_use == 0 && h->released) pk_drop(ctx, h); } } done{ctx, h};
+    return zk_plonk_create_proof(ctx, &h->desc, advice, advice_on_device, instances, instance_lens, rng, rng_user, proof_out, proof_cap, proof_len);
+} ZK_ABI_CATCH(ctx)
 
 // zk_ctx_destroy (capi.hip): the keys this context still holds go with it (before its programs are released)
 void zk_internal_plonk_ctx_destroyed(zk_ctx* ctx) {
@@ -1334,12 +1375,12 @@ void zk_internal_plonk_ctx_destroyed(zk_ctx* ctx) {
     }
 }
 
-extern "C" int zk_plonk_last_phase_ms(double out[9]) {
+extern "C" int zk_plonk_last_phase_ms(double out[9]) ZK_ABI_TRY {
     if (!out) return ZK_ERR_ARG;
     for (int i = 0; i < 9; i++) out[i] = g_phase_ms[i];
     return ZK_OK;
-}
-extern "C" int zk_plonk_trim(zk_ctx* ctx) {
+} ZK_ABI_CATCH(nullptr)
+extern "C" int zk_plonk_trim(zk_ctx* ctx) ZK_ABI_TRY {
     if (!ctx) return ZK_ERR_ARG;
     std::shared_ptr<Pool> p;
     {
@@ -1352,5 +1393,6 @@ extern "C" int zk_plonk_trim(zk_ctx* ctx) {
     std::map<size_t, std::vector<void*>> idle;
     { std::lock_guard<std::mutex> lk(p->mu); p->retired = true; idle.swap(p->free_); }      // a proof still running on this context keeps its Arena's reference: its buffers are freed as it returns them
     for (auto& kv : idle) for (void* d : kv.second) (void)zk_dev_free(ctx, d);
+    zk_internal_trim_helper(ctx);                                      // the side lane's context: its transform workspaces, twiddle and coset tables (rebuilt at the next lone proof)
     return ZK_OK;
-}
+} ZK_ABI_CATCH(ctx)

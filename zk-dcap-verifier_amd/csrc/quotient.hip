@@ -1064,19 +1064,21 @@ struct PkData {
     std::vector<void*> dyn_ext;
     void* stage = nullptr;
     void* h_ext = nullptr;
+    std::vector<void*> lv;                      // (pk_load: the three l columns on their way into `l`)
+    ~PkData() {
+        for (void* p : fixed) if (p) (void)hipFree(p);
+        for (void* p : sigma) if (p) (void)hipFree(p);
+        for (void* p : dyn_ext) if (p) (void)hipFree(p);
+        for (void* p : lv) if (p) (void)hipFree(p);
+        for (void* p : l) if (p) (void)hipFree(p);
+        if (stage) (void)hipFree(stage);
+        if (h_ext) (void)hipFree(h_ext);
+    }
 };
 static std::map<uint64_t, PkData*> g_pks;       // keyed by handle (handles are unique per process)
 static std::mutex g_pk_mu;
 
-static void pk_free(PkData* pk) {
-    for (void* p : pk->fixed) if (p) (void)hipFree(p);
-    for (void* p : pk->sigma) if (p) (void)hipFree(p);
-    for (void* p : pk->dyn_ext) if (p) (void)hipFree(p);
-    for (void* p : pk->l) if (p) (void)hipFree(p);
-    if (pk->stage) (void)hipFree(pk->stage);
-    if (pk->h_ext) (void)hipFree(pk->h_ext);
-    delete pk;
-}
+static void pk_free(PkData* pk) { delete pk; }
 
 // host columns -> extended cosets on the device.  form 0: n coefficients each; form 1: 2^ek coset values each
 static int pk_upload_cols(zk_ctx* ctx, const QuotProgram& P, const void* const* cols, size_t count, int form, std::vector<void*>& out) {
@@ -1111,25 +1113,26 @@ int pk_load(zk_ctx* ctx, uint64_t prog, const void* const* fixed, const void* co
     const QuotProgram& P = *it->second;
     if (!handle || !l0 || !l_last || !l_active || (P.n_fixed && !fixed) || (P.n_perm_cols && !sigma) || (form != 0 && form != 1))
         return ctx->fail(ZK_ERR_ARG, "zk_pk_load: null / bad argument");
-    PkData* pk = new PkData();
+    std::unique_ptr<PkData> pk(new PkData());                        // (every way out but the last frees what was uploaded)
     pk->prog = prog;
     int rc = pk_upload_cols(ctx, P, fixed, P.n_fixed, form, pk->fixed);
     if (!rc) rc = pk_upload_cols(ctx, P, sigma, P.n_perm_cols, form, pk->sigma);
-    std::vector<void*> lv;
     const void* ls[3] = {l0, l_last, l_active};
-    if (!rc) rc = pk_upload_cols(ctx, P, ls, 3, form, lv);
-    if (rc) { for (void* p : lv) if (p) (void)hipFree(p); pk_free(pk); return rc; }
-    for (int i = 0; i < 3; i++) pk->l[i] = lv[i];
+    if (!rc) rc = pk_upload_cols(ctx, P, ls, 3, form, pk->lv);
+    if (rc) return rc;
+    for (int i = 0; i < 3; i++) pk->l[i] = pk->lv[i];
+    pk->lv.clear();
     const size_t ndyn = (size_t)P.n_advice + P.n_instance + P.n_sets + 3 * (size_t)P.n_lookups;
     pk->dyn_ext.assign(ndyn, nullptr);
     hipError_t e = hipSuccess;
     for (size_t i = 0; i < ndyn && e == hipSuccess; i++) e = hipMalloc(&pk->dyn_ext[i], (size_t)32 << P.ek);
     if (e == hipSuccess) e = hipMalloc(&pk->stage, std::max<size_t>(ndyn, 1) * ((size_t)32 << P.k));
     if (e == hipSuccess) e = hipMalloc(&pk->h_ext, (size_t)32 << P.ek);
-    if (e != hipSuccess) { pk_free(pk); return ctx->fail(ZK_ERR_HIP, "zk_pk_load: device allocation failed"); }
-    *handle = ctx->next_handle++;
+    if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "zk_pk_load: device allocation failed");
     std::lock_guard<std::mutex> lk(g_pk_mu);
-    g_pks[((uint64_t)(uintptr_t)ctx << 20) ^ *handle] = pk;
+    g_pks[((uint64_t)(uintptr_t)ctx << 20) ^ ctx->next_handle] = pk.get();
+    (void)pk.release();
+    *handle = ctx->next_handle++;
     return ZK_OK;
 }
 static PkData* pk_find(zk_ctx* ctx, uint64_t h) {

@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
-EMU_SO = os.path.join(ROOT, "tests", "csrc", "libzkmi355_emu.so")
+# ZK_EMU_LIBDIR: a sanitizer build of the emulator library (tests/run_sanitizers.sh) instead of tests/csrc/libzkmi355_emu.so
+EMU_SO = os.path.join(os.environ.get("ZK_EMU_LIBDIR") or os.path.join(ROOT, "tests", "csrc"), "libzkmi355_emu.so")
 HOST_SO = os.path.join(ROOT, "tests", "csrc", "libhostharness.so")
 
 

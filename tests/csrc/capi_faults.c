@@ -11,6 +11,7 @@ void zk_test_fail_alloc_any_thread(long nth);
 long zk_test_alloc_count(void);
 void zk_test_fail_thread(int nth);
 long zk_test_live_device_allocs(void);
+int zk_test_alloc_hook_present(void);
 
 #define CK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, zk_last_error(ctx)); return 1; } } while (0)
 #define FAIL(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); return 1; } while (0)
@@ -33,7 +34,11 @@ int main(int argc, char** argv) {
     size_t len = 0;
     int rc, failures;
     long n;
-    const int sections = getenv("ZK_FAULTS_SECTIONS") ? atoi(getenv("ZK_FAULTS_SECTIONS")) : 31;      /* bit i: inject in section i (debugging aid: which section leaks) */
+    int sections = getenv("ZK_FAULTS_SECTIONS") ? atoi(getenv("ZK_FAULTS_SECTIONS")) : 31;      /* bit i: inject in section i (debugging aid: which section leaks) */
+    if (!zk_test_alloc_hook_present()) {                              /* an ASan / TSan build of the library: their runtimes own operator new */
+        sections &= 16;
+        printf("no allocation hook in this build of the library (sanitizer runtime): thread starts and the device-buffer census only\n");
+    }
 
     /* ---- zk_quotient_program_load: the ZKQ1 compiler parses caller bytes into vectors, maps and shared_ptrs ---- */
     failures = 0;

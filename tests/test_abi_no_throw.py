@@ -34,7 +34,7 @@ def test_every_extern_c_function_has_the_exception_barrier():
             continue
         src = open(os.path.join(CSRC, f)).read()
         in_block = [(m.end(), src.index('\n}  // extern "C"', m.end())) for m in re.finditer(r'^extern "C" \{', src, re.M)]
-        for m in re.finditer(r'^(extern "C" )?(?:int|double|void|long|uint32_t|const char\*) (zk_\w+)\(', src, re.M):
+        for m in re.finditer(r'^(extern "C" )?(?:int|double|void|long|uint32_t|uint64_t|const char\*) (zk_\w+)\(', src, re.M):
             if not (m.group(1) or any(a <= m.start() < b for a, b in in_block)):
                 continue
             depth, j = 1, m.end()
@@ -60,7 +60,7 @@ def test_every_extern_c_function_has_the_exception_barrier():
     assert not missing, "declared in include/ but not defined behind the barrier: " + ", ".join(missing)
     for f in sorted(os.listdir(CSRC)):                                 # and the barrier is the only try/catch idiom at the boundary: count them
         if f.endswith(".hip"):
-            src = open(os.path.join(CSRC, f)).read()
+            src = "\n".join(l for l in open(os.path.join(CSRC, f)).read().splitlines() if not l.startswith("#define"))
             assert src.count("ZK_ABI_TRY") == len(re.findall(r"ZK_ABI_CATCH(?:_VALUE|_VOID)?\(", src)), f
 
 
@@ -86,7 +86,8 @@ def test_injected_host_failures_become_error_codes_plain_c(emu, orc, tmp_path, w
         env["LD_LIBRARY_PATH"] = os.environ["ZK_EMU_LIBDIR"] + ":" + env.get("LD_LIBRARY_PATH", "")
     r = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0 and "capi_faults OK" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
-    assert "-> ZK_ERR_LIMIT each" in r.stdout and "no side-lane thread -> one lane" in r.stdout
+    assert "no side-lane thread -> one lane" in r.stdout
+    assert "-> ZK_ERR_LIMIT each" in r.stdout or os.environ.get("ZK_SANITIZER") in ("asan", "tsan")      # (their runtimes own operator new: no allocation ladder there)
 
 
 def test_injected_host_failures_through_the_python_binding(emu, orc):
@@ -97,6 +98,8 @@ def test_injected_host_failures_through_the_python_binding(emu, orc):
     import sgx_shaped_circuit as sc
     import test_create_proof as tcp
     lib = emu.lib
+    if not lib.zk_test_alloc_hook_present():
+        pytest.skip("a sanitizer build of the emulator library: the sanitizer's runtime owns operator new")
     lib.zk_test_fail_alloc.argtypes = [C.c_long]
     lib.zk_test_fail_alloc.restype = None
     k = 8

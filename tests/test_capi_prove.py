@@ -13,10 +13,12 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 EMU_TUNE = "msm_sort_threads=64,msm_sort_wgs=3,msm_block=32,ntt_threads=32,ntt_tile_log=6,ntt_max_radix_log=4,msm_target_threads=64,msm_min_chunk=2,vec_block=32,quot_threads=32"
 
 
-def _run(exe, path, tune=None, world=None):
-    env = dict(os.environ)
+def _run(exe, path, tune=None, world=None, extra_env=None):
+    env = dict(os.environ, **(extra_env or {}))
     if tune:
         env["ZK_TUNE"] = tune
+    if exe.endswith("_emu") and os.environ.get("ZK_EMU_LIBDIR"):        # tests/run_sanitizers.sh: the same program against a sanitizer build of the emulator library
+        env["LD_LIBRARY_PATH"] = os.environ["ZK_EMU_LIBDIR"] + ":" + env.get("LD_LIBRARY_PATH", "")
     return subprocess.run([os.path.join(ROOT, "tests", "csrc", exe), str(path)] + ([str(world)] if world else []), capture_output=True, text=True, timeout=900, env=env)
 
 
@@ -40,6 +42,17 @@ def test_plain_c_prover_sharded_over_ranks_emulated(emu, orc, tmp_path, world):
     path.write_bytes(dp.toy_blob(emu, 6, 7))
     r = _run("capi_prove_emu", path, EMU_TUNE, world)
     assert r.returncode == 0 and f"{world} ranks" in r.stdout and "8 all-gathers per proof" in r.stdout and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_plain_c_prover_a_failing_rank_tells_the_others_through_library_owned_buffers_emulated(emu, orc, tmp_path):
+    """the poisoned block of a failing rank travels in exchange buffers the LIBRARY owns (no xchg_send / xchg_recv from the caller) — they must outlive the
+    failed body.  Four ranks, the last one's witness leaves its lookup table after the first exchange: it returns its own error, the other three ZK_ERR_COMM from the
+    same exchange, and the untampered proof that follows on the same contexts is the golden."""
+    import dump_pk_blob as dp
+    path = tmp_path / "pk.zkpk"
+    path.write_bytes(dp.toy_blob(emu, 6, 7))
+    r = _run("capi_prove_emu", path, EMU_TUNE, 4, {"ZK_TAMPER_LAST_RANK": "1"})
+    assert r.returncode == 0 and "tampered round" in r.stdout and "4 ranks" in r.stdout and "capi_prove OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_plain_c_prover_has_no_cpu_fallback(emu, orc, tmp_path):

@@ -362,7 +362,4 @@ def test_full_chain_x4_census_gpu(gpu, orc):
     _full_chain_x4(gpu, 13, 12)
 
 
-@pytest.mark.gpu
-def test_full_chain_x4_census_at_k21_gpu(gpu, orc):
-    """BASELINE configs[4] at its own size: k = 21, the x4 census (100 advice columns, 44 lookups, 20 permutation sets: 269 commitments), one GPU; accepted by verify_proof"""
-    _full_chain_x4(gpu, 21, 16)
+# (configs[4] at its own size, k = 21 — single context and sharded over two ranks — is tests/test_sharded_cfg5.py)

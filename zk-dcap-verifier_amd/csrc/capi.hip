@@ -81,6 +81,14 @@ thread_local long g_alloc_count = 0;
 std::atomic<long> g_fail_alloc_any{0};      // > 0: allocations of ANY thread of the library left until one throws (reaches the prover's helper threads)
 thread_local int g_fail_thread = 0;         // > 0: thread starts of this thread left until one throws
 }
+// (not under ASan / TSan: their runtimes own operator new and delete — a second replacement would pair their new with this delete; the sanitizer runs keep the
+//  thread-start hook and the device-buffer census, the allocation ladder belongs to the plain emulator build)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer) || __has_feature(thread_sanitizer)
+#define ZK_NO_NEW_HOOK 1
+#endif
+#endif
+#ifndef ZK_NO_NEW_HOOK
 void* operator new(size_t n) {
     g_alloc_count++;
     if (g_fail_alloc_in > 0 && --g_fail_alloc_in == 0) throw std::bad_alloc();
@@ -94,9 +102,17 @@ void operator delete(void* p) noexcept { free(p); }
 void operator delete[](void* p) noexcept { free(p); }
 void operator delete(void* p, size_t) noexcept { free(p); }
 void operator delete[](void* p, size_t) noexcept { free(p); }
+#endif
 void zk::fault_thread_tick() { if (g_fail_thread > 0 && --g_fail_thread == 0) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "std::thread"); }
 extern "C" {
 // not in include/zkmi355.h: test hooks of the emulator build (tests/test_abi_no_throw.py)
+int zk_test_alloc_hook_present(void) {
+#ifdef ZK_NO_NEW_HOOK
+    return 0;
+#else
+    return 1;
+#endif
+}
 void zk_test_fail_alloc(long nth) { g_fail_alloc_in = nth; g_alloc_count = 0; }          // the nth host allocation of the calling thread from now on throws (0 = disarm)
 void zk_test_fail_alloc_any_thread(long nth) { g_fail_alloc_any.store(nth); }            // ... of any thread
 long zk_test_alloc_count(void) { return g_alloc_count; }

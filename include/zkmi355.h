@@ -270,6 +270,10 @@ int zk_quotient_run_coset_rows_dev(zk_ctx* ctx, uint64_t prog, const zk_quotient
  * joins through zk_cosets_to_pieces_dev(.., pieces = 2, ..): h = (pieces of the high part) + (the two pieces of the low part).  Same field elements as the unsplit evaluation
  * whenever the witness satisfies the circuit (every identity then vanishes on the domain, so both shares are polynomials); for a witness that violates it the (invalid) proofs
  * differ — tune "quot_degree_split" = 0 before zk_quotient_program_load / zk_plonk_pk_build keeps halo2's bytes there too.
+ * DEFAULT: on (1).  Where the setting is read: (1) when a program is loaded — that decides whether the two parts exist, and the PROGRAM records it (zk_quotient_program_split
+ * is the way to ask; the tunable says nothing about a key built earlier); (2) at every zk_plonk_create_proof / zk_plonk_prove, which takes the split route only when the tunable is on
+ * AND the key's program carries the parts.  So 0 at proof time switches the split off for a key that has it; 1 at proof time cannot switch it on for a key built with 0 — that proof
+ * silently runs unsplit (same bytes for a satisfied circuit, about 2 % slower).  Set it once, before the key is built, and leave it.
  * zk_quotient_program_split: *low_cosets = 2 when `prog` carries the two parts, 0 when it does not (then only zk_quotient_run*_dev above apply).
  * zk_quotient_run_high_dev: as zk_quotient_run_dev, high part only.  zk_quotient_run_low_dev: columns of the whole extended domain as for zk_quotient_run_dev, low part on the
  * rows of cosets 0 .. low_cosets-1; args->out receives low_cosets x n values, coset-major.  zk_quotient_run_coset_part_dev: as zk_quotient_run_coset_dev, part 1 = high, 2 = low. */

@@ -14,6 +14,11 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "zkmi355.h")
+RCCL_HEADER = os.path.join(ROOT, "include", "zkmi355_rccl.h")      # the optional RCCL adapter (libzkmi355_rccl.so): shim/halo2_proofs_mi355x/src/rccl.rs binds it
+
+
+def header_text():
+    return open(HEADER).read() + "\n" + open(RCCL_HEADER).read()
 
 C_BASE = {"uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8", "int": "c_int", "size_t": "usize", "double": "f64", "void": "c_void", "char": "c_char"}
 
@@ -158,12 +163,12 @@ def markdown_rust_blocks(path):
 
 def diff_against_header(rust_text, where, header_text=None):
     """every mismatch between the declarations in rust_text and the header, as strings (empty = in step)"""
-    structs, fnptrs, protos = parse_header(header_text if header_text is not None else open(HEADER).read())
+    structs, fnptrs, protos = parse_header(header_text if header_text is not None else globals()["header_text"]())
     r_structs, r_externs, r_fntypes, r_consts = parse_rust(rust_text)
     bad = []
     for name, fields in r_structs.items():
         cname = snake(name)
-        if cname == "zk_ctx":                            # opaque on both sides
+        if cname in ("zk_ctx", "zk_rccl_comm"):          # opaque on both sides
             continue
         if cname not in structs:
             bad.append(f"{where}: #[repr(C)] struct {name} has no C struct {cname} in the header")
@@ -226,6 +231,9 @@ def test_rust_bindings_match_the_header():
     # the parser did see the binding (an empty comparison proves nothing)
     assert {"ZkQuotientArgs", "ZkPlonkPkHost"} <= seen_structs
     assert {"zk_plonk_pk_build", "zk_plonk_prove", "zk_msm_batch", "zk_ntt", "zk_abi_version", "zk_abi_struct_size"} <= seen_fns
+    # the RCCL adapter: every function of its header is bound, with the header's types
+    _, _, rccl_protos = parse_header(open(RCCL_HEADER).read())
+    assert set(rccl_protos) == {f for f in seen_fns if f.startswith("zk_rccl_")} and len(rccl_protos) == 9, (sorted(rccl_protos), sorted(f for f in seen_fns if f.startswith("zk_rccl_")))
 
 
 def test_the_round3_drift_is_caught():

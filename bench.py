@@ -312,6 +312,72 @@ class ThinShimReplay:
         self.ev.release()
 
 
+class PhaseBatchedReplay:
+    """The integration level BETWEEN the thin shim and `value`: shim/halo2_proofs_mi355x/src/prover_phases.patch — an otherwise unchanged plonk/prover.rs whose
+    commitment loops, transforms and argument provers each became ONE batch of device calls per phase, while halo2's Polynomial values stay host Vec<Fr>s.  Every
+    phase therefore uploads the witness-dependent columns it reads and downloads the columns it produces (pageable host memory, as a Vec is); only the proving key
+    stays in HBM; the transcript runs on the host.  Measured by running the Python twin — the phase list of that patch, call for call — with the two hooks that move
+    those bytes for real (plonk/prover.py `phase_io`); the proof bytes are unchanged and compared.  `cache` = the variant with a pointer-keyed device cache in the
+    shim: a column that is still in HBM from the phase that uploaded or produced it is not uploaded again (downloads stay: halo2 owns host copies)."""
+
+    def __init__(self, z, be, wl, cache):
+        self.z, self.be, self.wl, self.cache = z, be, wl, cache
+        self.host, self.bytes_up, self.bytes_down, self.ms = {}, 0, 0, {}
+
+    def _key(self, col):
+        from zk_dcap_verifier_amd._lib import _dptr
+        return _dptr(col)
+
+    def reads(self, phase, cols):
+        import ctypes as C
+        be, nb = self.be, self.wl.n * 32
+        t0 = time.perf_counter()
+        for col in cols:
+            kptr = self._key(col)
+            if self.cache and kptr in self.host:
+                continue                                               # still resident: the shim's cache hands back the device copy
+            a = self.host.get(kptr)
+            if a is None:                                              # the witness itself: halo2's advice Vec (first touch)
+                a = np.empty((self.wl.n, 4), dtype=np.uint64)
+                be._ck(be.lib.zk_dev_download(be.ctx, a.ctypes.data_as(C.c_void_p), C.c_void_p(kptr), C.c_size_t(nb)))
+                self.host[kptr] = a
+                if self.cache:
+                    continue
+            be._ck(be.lib.zk_dev_upload(be.ctx, C.c_void_p(kptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(nb)))
+            self.bytes_up += nb
+        self.ms[phase + ":upload"] = self.ms.get(phase + ":upload", 0.0) + (time.perf_counter() - t0) * 1e3
+
+    def writes(self, phase, cols):
+        import ctypes as C
+        be, nb = self.be, self.wl.n * 32
+        t0 = time.perf_counter()
+        for col in cols:
+            kptr = self._key(col)
+            a = self.host.get(kptr)
+            if a is None:
+                a = self.host[kptr] = np.empty((self.wl.n, 4), dtype=np.uint64)
+            be._ck(be.lib.zk_dev_download(be.ctx, a.ctypes.data_as(C.c_void_p), C.c_void_p(kptr), C.c_size_t(nb)))
+            self.bytes_down += nb
+        self.ms[phase + ":download"] = self.ms.get(phase + ":download", 0.0) + (time.perf_counter() - t0) * 1e3
+
+    def step(self):
+        from zk_dcap_verifier_amd.transcript import Blake2bWrite
+        wl = self.wl
+        self.host, self.bytes_up, self.bytes_down, self.ms = {}, 0, 0, {}
+        for w, m in zip(wl.work, wl.master):
+            w.copy_from(m)
+        wl.be.sync()
+        tr = Blake2bWrite()
+        t0 = time.perf_counter()
+        # phase 2 of a host-resident prover: the advice columns cross PCIe inside commit_lagrange_batch (pageable memory)
+        wl.be.upload_columns(wl.work, wl.advice_host, wl.n * 32)
+        self.bytes_up += len(wl.work) * wl.n * 32
+        timings = {}
+        self.z.plonk.create_proof(wl.params, wl.pk, wl.work, [], np.random.default_rng(wl.seed), tr, timings=timings, phase_io=self)
+        ms = (time.perf_counter() - t0) * 1e3
+        return ms, tr.finalize(), dict(self.ms), timings, self.bytes_up, self.bytes_down
+
+
 def cpu_a13_a16(orc, shim, threads):
     """The CPU side of the thin shim: the loops of create_proof that the three redirected functions do not cover, on the
     port (oracle/bn254_oracle.c), over the captured columns of a real proof.  Independent items (the lookups, the queries) run on a thread pool as
@@ -955,6 +1021,27 @@ def main(argv=None):
                                               "call list (no phase batching, columns cross PCIe per call); a13-a16 stay CPU loops (timed by the CPU leg below)"}
             except Exception as e:
                 extra["thin_shim_error"] = repr(e)
+            try:
+                rungs = {}
+                for name, cache in (("host_columns", False), ("host_columns_with_device_cache", True)):
+                    pb = PhaseBatchedReplay(z, be, wl, cache)
+                    pb.step()
+                    ms_, proof_, io_, ph_, up_, down_ = min((pb.step() for _ in range(2)), key=lambda r: r[0])
+                    ref_tr = __import__("zk_dcap_verifier_amd.transcript", fromlist=["Blake2bWrite"]).Blake2bWrite()
+                    for w_, m_ in zip(wl.work, wl.master):
+                        w_.copy_from(m_)
+                    z.plonk.create_proof(wl.params, wl.pk, wl.work, [], np.random.default_rng(wl.seed), ref_tr)
+                    worst = max(io_, key=io_.get) if io_ else None
+                    rungs[name] = {"ms_per_proof": round(ms_, 1), "proofs_per_hour": round(3600e3 / ms_, 1), "same_bytes_as_the_resident_prover": proof_ == ref_tr.finalize(),
+                                   "pcie_GB_up": round(up_ / 1e9, 2), "pcie_GB_down": round(down_ / 1e9, 2), "pcie_bytes_up": up_, "pcie_bytes_down": down_, "transfer_ms": {k_: round(v, 1) for k_, v in sorted(io_.items())},
+                                   "transfer_ms_total": round(sum(io_.values()), 1), "largest_transfer": worst, "phase_ms_incl_transfers": {k_: round(v, 1) for k_, v in ph_.items()}}
+                extra["phase_batched_shim"] = dict(rungs, what="shim/halo2_proofs_mi355x/src/prover_phases.patch: every phase of create_proof is ONE batch of device calls, halo2's Polynomial "
+                                                   "values stay host Vec<Fr>s (pageable): each phase uploads the witness-dependent columns it reads and downloads the ones it produces; the "
+                                                   "proving key is resident, the transcript on the host, one proof at a time (a CPU prover's loop); measured on the Python twin with real "
+                                                   "transfers (plonk/prover.py phase_io).  The rungs: extra.thin_shim (one blocking call per best_multiexp / best_fft / evaluate_h) < this < "
+                                                   "`value` (zk_plonk_prove: columns never leave HBM)")
+            except Exception as e:
+                extra["phase_batched_shim_error"] = repr(e)
         # the CPU leg (the only part of this file that may touch oracle/): baseline timing, verify_proof on the GPU's proofs, and the
         # direct-sum check of the NTT outputs kept above
         if args.mode == "prove":

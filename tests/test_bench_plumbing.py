@@ -68,6 +68,11 @@ def test_bench_prove_mode_emits_verified_proof(built, capsys, monkeypatch):
     ts = line["extra"]["thin_shim"]
     assert ts["calls"] == {"zk_msm": line["extra"]["ops_per_proof"]["msm"], "zk_ntt": line["extra"]["ops_per_proof"]["intt_2^k"], "zk_evaluate_h": 1}
     assert ts["proofs_per_hour"] > 0 and line["cpu_baseline"]["a13_a16_cpu_port"]["total_ms"] > 0
+    # the rung between the thin shim and `value`: phase-batched device calls on host-resident columns (real transfers, same proof bytes), with and without the shim's device cache
+    pb = line["extra"]["phase_batched_shim"]
+    for rung in ("host_columns", "host_columns_with_device_cache"):
+        assert pb[rung]["same_bytes_as_the_resident_prover"] is True and pb[rung]["proofs_per_hour"] > 0 and pb[rung]["pcie_bytes_down"] > 0, pb[rung]
+    assert pb["host_columns"]["pcie_bytes_up"] > pb["host_columns_with_device_cache"]["pcie_bytes_up"]
 
 
 def _bench_rank(rank, world, port, out_dir):

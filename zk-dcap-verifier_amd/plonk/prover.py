@@ -67,7 +67,7 @@ class _Joiner:
 
 
 def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances: Sequence[Sequence[int]], rng: np.random.Generator, transcript,
-                 timings: Optional[dict] = None, capture: Optional[dict] = None) -> dict:
+                 timings: Optional[dict] = None, capture: Optional[dict] = None, phase_io=None) -> dict:
     """advice: cs.num_advice_columns columns of n rows — (n, 4) uint64 Montgomery host arrays or device buffers; rows past
     `usable_rows` are overwritten with blinding and device buffers are consumed (they hold coefficients afterwards).  instances:
     canonical ints per instance column.  Writes the proof into `transcript` and returns bookkeeping for tests / benches
@@ -76,13 +76,13 @@ def create_proof(params: ParamsKZG, pk: ProvingKey, advice: Sequence, instances:
     copies of the proof's committed Lagrange columns and challenges, so that a driver of the per-call host-buffer entry points can replay them."""
     owned: List = []
     try:
-        return _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture)
+        return _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture, phase_io)
     finally:
         for d in owned:
             d.free()
 
 
-def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture=None) -> dict:
+def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned, capture=None, phase_io=None) -> dict:
     be, cs, k, n = pk.backend, pk.vk.cs, params.k, params.n
     dom = pk.domain
     ek, en = dom.extended_k, dom.extended_n
@@ -102,6 +102,18 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
         d = be.alloc(nbytes)
         owned.append(d)
         return d
+
+    # `phase_io` (measurement tooling only, bench.py extra.phase_batched_shim): the integration level between the thin shim and the resident prover — halo2's
+    # Polynomial values stay HOST vectors and every phase is a batch of device calls.  phase_io.reads(phase, columns) runs before a phase touches witness-dependent
+    # columns it did not produce itself (a host-resident prover uploads them), phase_io.writes(phase, columns) after it produced columns halo2 keeps (it downloads
+    # them).  The hooks move the bytes for real and change no value: the proof is the same.
+    def reads(phase, cols):
+        if phase_io is not None:
+            phase_io.reads(phase, [c for c in cols if c is not None])
+
+    def writes(phase, cols):
+        if phase_io is not None:
+            phase_io.writes(phase, [c for c in cols if c is not None])
 
     def commit_all(which, cols):                                 # one device call per transcript phase (all-gathered when the tables are sharded)
         return [g1_affine_ints(r) for r in params.commit_columns(which, cols)]
@@ -181,6 +193,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     theta = transcript.squeeze_challenge()
     one = fr_mont(1)
     th = fr_mont(theta)
+    reads("3_lookup_permuted", adv_values + inst_values)
     compressed = []
     table_cache = {}                                            # lookups with the same table expressions share ONE compressed table column
     anycol = pk.fixed_values[0] if pk.fixed_values else adv_values[0]
@@ -202,6 +215,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     for a_, s_ in permuted:
         owned += [a_, s_]
     flat = [c for pr in permuted for c in pr]
+    writes("3_lookup_permuted", flat + [c[0] for c in compressed] + list(table_cache.values()))
     for pt in commit_all("g_lagrange", flat):           # per lookup: permuted input, permuted table
         transcript.write_point(pt)
 
@@ -214,10 +228,12 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     for t, i in cs.permutation_columns:
         perm_values.append({ADVICE: adv_values, FIXED: pk.fixed_values, INSTANCE: inst_values}[t][i])
     perm_blind, lookup_blind = take_draw("perm_blind"), take_draw("lookup_blind")
+    reads("4_grand_products", [c for c in perm_values if c in adv_values or c in inst_values] + flat + [c[0] for c in compressed] + list(table_cache.values()))
     zs = permutation_commit(perm_values, pk.sigma_values, k, cs.degree(), bt_m, gm_m, perm_blind, backend=be) if perm_values else []
     owned += zs
     lzs = lookup_commit_products([(c[0], c[1], p_[0], p_[1]) for c, p_ in zip(compressed, permuted)], k, bt_m, gm_m, lookup_blind, backend=be)
     owned += lzs
+    writes("4_grand_products", zs + lzs)
     for pt in commit_all("g_lagrange", zs + lzs):      # permutation products, then lookup products: one MSM batch, transcript order kept
         transcript.write_point(pt)
 
@@ -236,7 +252,9 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
                        lookup_products=[d.download((n, 4)) for d in lzs], permuted=[(a_.download((n, 4)), s_.download((n, 4))) for a_, s_ in permuted],
                        compressed=[(c[0].download((n, 4)), c[1].download((n, 4))) for c in compressed], random_poly=drawn["random_poly"][0],
                        theta=theta, beta=beta, gamma=gamma, y=y)
+    reads("6_ntt_evaluate_h", lag)
     be.lagrange_to_coeff_batch_dev(lag, k)                           # in place: from here on these buffers hold coefficients
+    writes("6_ntt_evaluate_h", lag)                                  # (halo2 keeps advice_polys / permuted polys / product polys for the evaluation phase)
     adv_polys, inst_polys = adv_values, inst_values
     nA, nI, nZ = len(adv_polys), len(inst_polys), len(zs)
 
@@ -305,6 +323,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
         be.divide_by_vanishing_poly_dev(h_ext, k, ek)
         be.extended_to_coeff_dev(h_ext, k, ek)
         pieces = [h_ext.ptr + i * n * 32 for i in range(n_pieces)]
+    writes("7_h_construct_commit", pieces)
     for pt in commit_all("g", pieces):
         transcript.write_point(pt)
 
@@ -314,6 +333,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
     xn = pow(x, n, R_MOD)
     rot = lambda r: rotate_omega(x, r, k)
     # h(X) as ONE polynomial of n coefficients: sum_i xn^i piece_i(X) (vanishing::Constructed::evaluate)
+    reads("8_evaluations", lag + [random_poly] + pieces)
     h_poly = dev(n * 32)
     be.fr_lincomb_dev(pieces, fr_mont_array([pow(xn, i, R_MOD) for i in range(n_pieces)]), n, h_poly)
     x_last = rot(-(bf + 1))
@@ -364,6 +384,7 @@ def _create_proof(params, pk, advice, instances, rng, transcript, timings, owned
         pz, pzn, pa, pai, ps = take(), take(), take(), take(), take()
         q_lk += [pz, pa, ps, pai, pzn]                              # lookup::Evaluated::open order
     q_h = take()
+    reads("9_shplonk", lag + [random_poly, h_poly])
     queries = q_adv + q_perm_a + list(reversed(q_perm_last)) + q_lk + q_fix + q_sigma + [q_h, q_rand]
     ProverSHPLONK(params).create_proof(transcript, queries)
     lap("9_shplonk")

@@ -322,7 +322,7 @@ class PhaseBatchedReplay:
 
     def __init__(self, z, be, wl, cache):
         self.z, self.be, self.wl, self.cache = z, be, wl, cache
-        self.host, self.bytes_up, self.bytes_down, self.ms = {}, 0, 0, {}
+        self.host, self.bytes_up, self.bytes_down, self.ms, self.skipped_s = {}, 0, 0, {}, 0.0
 
     def _key(self, col):
         from zk_dcap_verifier_amd._lib import _dptr
@@ -337,10 +337,15 @@ class PhaseBatchedReplay:
             if self.cache and kptr in self.host:
                 continue                                               # still resident: the shim's cache hands back the device copy
             a = self.host.get(kptr)
-            if a is None:                                              # the witness itself: halo2's advice Vec (first touch)
+            if a is None:
+                # the advice columns at their first re-read: halo2 holds them on the host WITH their blinding rows (this replay lets the library write those on the
+                # device, so the host copy is fetched here) — bookkeeping of the replay, outside its clock and its byte counts
+                t_skip = time.perf_counter()
                 a = np.empty((self.wl.n, 4), dtype=np.uint64)
                 be._ck(be.lib.zk_dev_download(be.ctx, a.ctypes.data_as(C.c_void_p), C.c_void_p(kptr), C.c_size_t(nb)))
                 self.host[kptr] = a
+                self.skipped_s += time.perf_counter() - t_skip
+                t0 += time.perf_counter() - t_skip
                 if self.cache:
                     continue
             be._ck(be.lib.zk_dev_upload(be.ctx, C.c_void_p(kptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(nb)))
@@ -363,7 +368,7 @@ class PhaseBatchedReplay:
     def step(self):
         from zk_dcap_verifier_amd.transcript import Blake2bWrite
         wl = self.wl
-        self.host, self.bytes_up, self.bytes_down, self.ms = {}, 0, 0, {}
+        self.host, self.bytes_up, self.bytes_down, self.ms, self.skipped_s = {}, 0, 0, {}, 0.0
         for w, m in zip(wl.work, wl.master):
             w.copy_from(m)
         wl.be.sync()
@@ -372,9 +377,10 @@ class PhaseBatchedReplay:
         # phase 2 of a host-resident prover: the advice columns cross PCIe inside commit_lagrange_batch (pageable memory)
         wl.be.upload_columns(wl.work, wl.advice_host, wl.n * 32)
         self.bytes_up += len(wl.work) * wl.n * 32
+
         timings = {}
         self.z.plonk.create_proof(wl.params, wl.pk, wl.work, [], np.random.default_rng(wl.seed), tr, timings=timings, phase_io=self)
-        ms = (time.perf_counter() - t0) * 1e3
+        ms = (time.perf_counter() - t0 - self.skipped_s) * 1e3
         return ms, tr.finalize(), dict(self.ms), timings, self.bytes_up, self.bytes_down
 
 

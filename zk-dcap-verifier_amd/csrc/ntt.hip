@@ -116,11 +116,16 @@ ZK_HD uint32_t tile_at(uint32_t row, uint32_t col, uint32_t r, uint32_t c_log) {
 // round trips and barriers as a radix-2 sweep; an odd last stage is a plain radix-2 step.
 // stage_tw: the R/2 stage twiddles of the pass, staged in LDS by the caller (32 bytes each: every radix-4 step reads three of them per quad,
 // and an LDS read returns in ~50 cycles where the L2 hit of a global load takes 200+)
+// Where twiddle i of the final pass sits in LDS (in units of its 64-byte Shoup pair).  A ds_read_b128 is served in groups of 16 lanes over 64 banks, and the lanes of a group
+// that belong to different tile rows read DIFFERENT twiddles of the same step — indices that are multiples of 2^(r - 1 - s), i.e. pairs a multiple of 256 bytes apart in the
+// linear layout: 2- to 4-way conflicts on every twiddle read of the early steps (round 4 moved the pairs into LDS without this: the kernel's conflict share doubled, 0.11 -> 0.20).
+// The low two bits of the position (which quarter of the 64 banks) take the XOR of all higher bit pairs of i, so neighbouring multiples of any power of two land on different quarters.
+ZK_HD uint32_t tw_slot(uint32_t i) { return i ^ (((i >> 2) ^ (i >> 4) ^ (i >> 6)) & 3u); }
 __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r, uint32_t c_log, const uint4* stage_tw, bool quarter_input) {
     const uint32_t C = 1u << c_log;
     // stage_tw holds Shoup pairs, 64 bytes per twiddle: the canonical integer w | wq = floor(w 2^256 / p) — Fr::mul_shoup_lazy: 115 partial products against 136, [0, 2p) out
     // like mul_lazy, no Montgomery factor (a tile value stays in the library's form)
-    auto half_at = [&](size_t i) { const uint4 l = stage_tw[2 * i], h = stage_tw[2 * i + 1]; u256 o; o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w; return o; };
+    auto half_at = [&](size_t j) { const size_t i = 4 * (size_t)tw_slot((uint32_t)(j >> 1)) + 2 * (j & 1); const uint4 l = stage_tw[i], h = stage_tw[i + 1]; u256 o; o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w; o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w; return o; };
     auto mul_tw = [&](const u256& x, size_t i) { return Fr::mul_shoup_lazy(x, half_at(2 * i), half_at(2 * i + 1)); };
     uint32_t s = 0;
     if (quarter_input && r >= 2) {
@@ -199,6 +204,10 @@ __device__ __forceinline__ void ntt_tile_stages(uint4* lo, uint4* hi, uint32_t r
 struct Tile29 {
     uint4* lo; uint4* hi; uint32_t* top;
 };
+// (The ninth limb's 4-byte plane is NOT swizzled on its own.  A ds_read_b32 / ds_write_b32 is served in groups of 32 lanes over 32 banks, so with 8 or 16 columns a group spans 4
+// or 2 tile rows, and in the load loop and the first radix-4 step those rows meet on the same banks: that plane is where the kernel's 0.17 conflict share comes from.  Folding the
+// higher row bits into the window bits removes it — 0.170 -> 0.115 — and costs more than it saves: the pass is VALU-bound with the LDS busy 6 % of its wave cycles, and 5 to 10
+// integer instructions per access made coeff_to_extended x 64 at k = 19 1.5-3 % (cheap two-field XOR) and 8 % (full fold) SLOWER, same box: profiles/r05/run302.)
 ZK_HD void lds_put29(const Tile29& t, uint32_t idx, const u261& v) {
     t.lo[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
     t.hi[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
@@ -422,7 +431,7 @@ ZK_KERNEL void ntt_final_pass_kernel(NttPassArgs a) {
     uint4* lo = smem;
     uint4* hi = smem + tile;
     uint4* twl = smem + 2 * tile;                                  // R/2 Shoup pairs of stage twiddles, 4 x uint4 each
-    for (uint32_t e = threadIdx.x; e < 2 * R; e += blockDim.x) twl[e] = reinterpret_cast<const uint4*>(a.stage_sh)[e];
+    for (uint32_t e = threadIdx.x; e < 2 * R; e += blockDim.x) twl[4 * tw_slot(e >> 2) + (e & 3u)] = reinterpret_cast<const uint4*>(a.stage_sh)[e];
     const uint32_t t = blockIdx.x;
     const uint32_t jm = t & ((1u << a.p_log) - 1);
     const uint32_t j10 = (t >> a.p_log) << a.c_log;

@@ -72,5 +72,7 @@ def gpu():
             break
     be = z.Backend(0)
     assert "gfx950" in be.version() and "EMULATED" not in be.version()
+    if os.environ.get("ZK_TUNE"):                # experiment knob: the whole GPU suite under other tunables, e.g. ZK_TUNE=quot_jit=1 (the generated quotient kernels)
+        be.tune(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ["ZK_TUNE"].split(",") if kv})
     yield be
     be.close()

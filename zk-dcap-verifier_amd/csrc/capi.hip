@@ -198,7 +198,7 @@ zk_ctx* zk_internal_helper_ctx(zk_ctx* ctx) {
 }
 static void release_workspaces(zk_ctx* ctx) {                          // ctx->mu held
     zk::DevBuf* bufs[] = {&ctx->ws_scalars, &ctx->ws_sorted, &ctx->ws_mid, &ctx->ws_small, &ctx->ws_sub0, &ctx->ws_sub1, &ctx->ws_cls0,
-                          &ctx->ws_cls1, &ctx->ws_tmp, &ctx->ws_ntt, &ctx->ws_ntt_in, &ctx->ws_pts, &ctx->ws_runs, &ctx->ws_quot};
+                          &ctx->ws_cls1, &ctx->ws_tmp, &ctx->ws_ntt, &ctx->ws_ntt_in, &ctx->ws_pts, &ctx->ws_runs, &ctx->ws_quot, &ctx->ws_quot_state};
     for (auto* b : bufs) b->release();
 }
 void zk_internal_trim_helper(zk_ctx* ctx) {
@@ -247,7 +247,7 @@ static int* tune_slot(zk_ctx* ctx, const char* key) {
         {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log}, {"ntt_coset_table", &t.ntt_coset_table}, {"ntt_col_major", &t.ntt_col_major},
         {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}, {"lookup_force_generic_sort", &t.lookup_force_generic_sort},
         {"ntt_quarter_input", &t.ntt_quarter_input}, {"ntt_fuse_scale", &t.ntt_fuse_scale}, {"quot_piece_cosets", &t.quot_piece_cosets}, {"quot_factor_horner", &t.quot_factor_horner}, {"quot_degree_split", &t.quot_degree_split}, {"quot_group_factors", &t.quot_group_factors}, {"ntt_ws_limit_mb", &t.ntt_ws_limit_mb}, 
-        {"quot_remat_ops", &t.quot_remat_ops}, {"quot_remat_distance", &t.quot_remat_distance}};
+        {"quot_jit", &t.quot_jit}, {"quot_jit_group", &t.quot_jit_group}, {"quot_jit_waves", &t.quot_jit_waves}, {"quot_remat_ops", &t.quot_remat_ops}, {"quot_remat_distance", &t.quot_remat_distance}};
     for (auto& e : tab) if (!strcmp(e.k, key)) return e.v;
     return nullptr;
 }

@@ -49,6 +49,9 @@ struct Tune {
     int quot_factor_horner = 1;  // quotient compiler: q * Horner([a_j], theta) for a theta-compression whose parts all carry the factor q (selector-switched lookups): m - 1 products fewer per row
     int quot_remat_ops = 4;      // quotient compiler: a shared sub-expression of at most this many operations ...
     int quot_remat_distance = 24;   // ... is recomputed when its previous copy lies further back than this many micro-ops
+    int quot_jit = 0;            // zk_quotient_program_load: also generate straight-line kernels for the program with hiprtc (quotient_jit.hip) and run those instead of the interpreter; 0 = interpreter only
+    int quot_jit_waves = 0;      // ... amdgpu_waves_per_eu of the generated kernels (0 = the compiler's choice; 4 = the interpreter's budget of 128 VGPRs, which costs some kernels a few spills)
+    int quot_jit_group = 24;     // ... micro-ops with a product per generated kernel (the kernel's code has to stay inside the instruction cache)
     int lookup_force_generic_sort = 0;   // tests: take the every-digit sort of permute_expression_pair even when the 64-bit window sort is exact
 };
 
@@ -131,7 +134,7 @@ struct zk_ctx {
     std::map<uint64_t, std::shared_ptr<zk::QuotProgram>> programs;   // compiled micro-programs are immutable once loaded: contexts of one device may share them (zk_quotient_program_share)
     std::map<uint64_t, std::vector<uint32_t>> lookup_tie_hint;   // lookupperm.hip: columns whose rows tied on the sort window in the previous call of the same shape
     // workspaces (grow-only)
-    zk::DevBuf ws_scalars, ws_sorted, ws_mid, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts, ws_runs, ws_quot;
+    zk::DevBuf ws_scalars, ws_sorted, ws_mid, ws_small, ws_sub0, ws_sub1, ws_cls0, ws_cls1, ws_tmp, ws_ntt, ws_ntt_in, ws_pts, ws_runs, ws_quot, ws_quot_state;
     // last-call kernel timing (ms), filled when timing is enabled
     bool timing = false;
     std::map<std::string, double> last_ms;

@@ -12,6 +12,7 @@
 // The micro-ISA (one uint4 per instruction) is internal; the input format is the "ZKQ1" blob
 // documented in INTEGRATION.md.
 #include "ctx.h"
+#include "quotient.h"
 #include <algorithm>
 #include <functional>
 #include <mutex>
@@ -26,37 +27,6 @@ u256 domain_omega(uint32_t k);
 
 enum { VS_CONST = 0, VS_INTER, VS_FIXED, VS_ADVICE, VS_INSTANCE, VS_CHALLENGE, VS_BETA, VS_GAMMA, VS_THETA, VS_Y, VS_PREV };
 enum { OP_ADD = 0, OP_SUB, OP_MUL, OP_SQUARE, OP_DOUBLE, OP_NEGATE, OP_HORNER, OP_STORE };
-// micro-ops
-enum { M_ADD = 0, M_SUB, M_MUL, M_SQR, M_DBL, M_NEG, M_MOV, M_MULADD, M_FOLD2 };   // M_FOLD2: acc = acc * c + a * b with ONE Montgomery reduction (value = value * y + product)
-enum { K_SLOT = 0, K_CONST, K_COL, K_ACC, K_XPOW, K_NONE = 7 };
-
-struct QuotProgram {
-    uint32_t k = 0, ek = 0, n_fixed = 0, n_advice = 0, n_instance = 0, n_challenges = 0, blinding = 0, degree = 0;
-    uint32_t n_perm_cols = 0, n_sets = 0, n_lookups = 0;
-    std::vector<uint32_t> perm_cols;      // pairs (type, index)
-    std::vector<uint4> code;
-    std::vector<u256> graph_consts;       // constants that come with the program
-    std::vector<int32_t> rotations;       // distinct rotations (rows)
-    uint32_t n_slots = 0, n_cols = 0;
-    // constant table layout (indices)
-    uint32_t c_zero = 0, c_one = 0, c_chal = 0, c_beta = 0, c_gamma = 0, c_theta = 0, c_y = 0, c_delta = 0, c_ypow = 0, n_consts = 0;
-    // Degree split (compile_program, `mode`): h's numerator is sum_i y^(N-1-i) id_i over the N identities halo2 folds with y; an identity of degree d (in the columns)
-    // contributes a share of h(X) of degree below (d - 1) n, which (d - 1) cosets of the size-n domain determine.  part_hi / part_lo are the SAME program restricted to the
-    // identities of degree above / up to SPLIT_LOW_DEGREE (a skipped identity leaves a power of y on the next fold: ypow_exps, constants of the run at c_ypow): the low part
-    // is evaluated on SPLIT_LOW_DEGREE - 1 cosets only and joins h(X) through zk_cosets_to_pieces_dev.  Exact for every witness that satisfies the circuit (each identity
-    // then vanishes on the domain on its own, so both shares are polynomials).
-    std::vector<uint32_t> ypow_exps;      // y^e constants this program reads, e >= 2
-    uint32_t folds_taken = 0, folds_skipped = 0;
-    std::shared_ptr<QuotProgram> part_hi, part_lo;
-    // column ids
-    uint32_t col_fixed = 0, col_advice = 0, col_instance = 0, col_l0 = 0, col_llast = 0, col_lactive = 0, col_sigma = 0, col_z = 0,
-             col_lk_z = 0, col_lk_a = 0, col_lk_s = 0;
-    bool uses_xpow = false;
-    void* d_code = nullptr;               // immutable after the load; the constants / column pointers / rotation offsets of a RUN live in the calling context's ws_quot,
-    int device = 0;                       // so contexts of one device can share a program (zk_quotient_program_share) and run it concurrently
-    ~QuotProgram() { if (d_code) { (void)hipSetDevice(device); (void)hipFree(d_code); } }
-};
-
 // ------------------------------------------------------------------------------------------------
 // interpreter kernel
 // ------------------------------------------------------------------------------------------------
@@ -68,23 +38,6 @@ struct QuotProgram {
 
 constexpr uint32_t QUOT_NREG = 1;   // first slot of the allocator is a register, the rest LDS (3 -> 1: 128 -> 116 VGPRs, 9.74 -> 9.18 ms at k = 19: profiles/r02)
 
-struct QuotArgs {
-    const uint4* code;
-    uint32_t n_instr;
-    const void* consts;
-    const void* const* cols;
-    const uint32_t* rot_off;   // row offsets (already scaled, non-negative, < size)
-    uint32_t size_log;
-    const void* tw_lo;
-    const void* tw_hi;
-    uint32_t lo_bits;
-    int uses_xpow;
-    uint32_t xpow_mul, xpow_add;   // X of row idx = extended_omega^(idx * xpow_mul + xpow_add): (1, 0) on the whole extended domain, (2^(ek-k), j) on coset j
-    uint32_t strided, sub_log, stride_log, k_log;   // strided: thread t works on row ((t >> sub_log) << stride_log) + (t & (2^sub_log - 1)) of extended-layout columns
-                                                    // and writes out[((t & (2^sub_log - 1)) << k_log) + (t >> sub_log)]: the first 2^sub_log cosets, coset-major
-    uint32_t row_base;             // first row of this launch (a launch may cover a slice of the rows: out[i] = numerator of row row_base + i)
-    void* out;
-};
 
 // One row per thread.  The loop is software-pipelined by one instruction: while instruction pc executes, the column /
 // constant operands of instruction pc + 1 are already in flight (the kernel is otherwise bound by the latency of ~850
@@ -861,6 +814,11 @@ int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* p
             P->part_hi = hi; P->part_lo = lo;
         }
     }
+    // tune quot_jit: the same micro-ops as generated straight-line kernels (quotient_jit.hip).  Asked for and not to be had is an error, not a silent change of executor.
+    if (ctx->tune.quot_jit && P->ek > P->k) {
+        rc = quot_jit_build(ctx, *P);
+        if (rc) return rc;
+    }
     *prog = ctx->next_handle++;
     ctx->programs[*prog] = P;
     return ZK_OK;
@@ -1041,8 +999,15 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
     const size_t lds = (size_t)lds_slots * T * 32;
     if (lds > 160 * 1024) return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %zu bytes of LDS", lds);
     EvTimer tq(ctx, "quotient");
-    ZK_LAUNCH(quotient_kernel, (uint32_t)(rows / T), T, lds, st, q);
-    ZK_CHECK_LAUNCH();
+    if (ctx->tune.quot_jit && quot_jit_ready(P)) {
+        uint32_t Tj = (uint32_t)std::min(ctx->tune.quot_threads, 256);
+        if (Tj > rows) Tj = (uint32_t)rows;
+        int rcj = quot_jit_launch(ctx, P, q, rows, Tj);
+        if (rcj) return rcj;
+    } else {
+        ZK_LAUNCH(quotient_kernel, (uint32_t)(rows / T), T, lds, st, q);
+        ZK_CHECK_LAUNCH();
+    }
     tq.stop();
     ZK_HIP(hipStreamSynchronize(st));
     tq.resolve();

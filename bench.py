@@ -635,6 +635,7 @@ def main(argv=None):
                     help="which synthetic circuit `value` is measured on (tools/sgx_shaped_circuit.py); the other one is measured as extra.census_* unless --no-extras")
     ap.add_argument("--prover", choices=("native", "python"), default="native",
                     help="which create_proof the timed steps run: the library's C++ one (zk_plonk_create_proof) or its Python twin (plonk.create_proof); same bytes")
+    ap.add_argument("--no-jit", action="store_true", help="the headline key's quotient on the micro-op interpreter instead of kernels generated for its program (tune quot_jit)")
     ap.add_argument("--inflight", type=int, default=4, help="proofs processed concurrently per step on one GPU (one context + HIP stream each)")
     ap.add_argument("--no-extras", action="store_true", help="skip the MSM 2^24 / NTT 2^22 microbenchmarks and the CPU baseline")
     args = ap.parse_args(argv)
@@ -679,8 +680,20 @@ def main(argv=None):
         import sgx_shaped_circuit as sgx
         circuit = sgx.build(z, be, args.k, census=args.census)  # one satisfying witness, shared by the contexts
         wls = []
+        # the headline key's quotient runs on kernels GENERATED for its program (csrc/quotient_jit.hip: hiprtc at key build, tune quot_jit; the contexts that borrow the key
+        # borrow the kernels).  Only this key: the other keys a default run builds (second census, configs[0], sharded extras) keep the interpreter — a key build costs
+        # ~45 s of compilation on a box that has not seen the program before (comgr's cache makes it 0.1 s afterwards).  --no-jit / ZK_TUNE=quot_jit=0: interpreter everywhere.
+        want_jit = not args.no_jit and bench_tune.get("quot_jit", 1) != 0 and not os.environ.get("ZK_BENCH_PLUMBING_TEST")
+        if want_jit:
+            be.tune(quot_jit=1)
         for b in bes:
             wls.append(ProverWorkload(z, b, args.k, circuit, srs=wls[0].params if wls else None, pk=wls[0].pk if wls else None))
+            if b is be:
+                jit_compile_s = be.stat_get("quot_jit_compile_s")
+                be.tune(quot_jit=bench_tune.get("quot_jit", 0) if "quot_jit" in bench_tune and not want_jit else 0)
+        quotient_executor = {"generated_kernels": bool(want_jit and jit_compile_s > 0), "hiprtc_compile_s": round(jit_compile_s, 2),
+                             "what": "the headline key's quotient program as straight-line kernels generated for it at key build (csrc/quotient_jit.hip, tune quot_jit = 1); "
+                                     "false = the micro-op interpreter (csrc/quotient.hip)"}
     else:
         circuit = None
         wls = [ProofWorkload(z, b, args.k, args.advice, args.fixed, args.lookups, args.perm_columns, args.degree) for b in bes]
@@ -759,6 +772,8 @@ def main(argv=None):
              "event_span_ms_per_proof_pipelined": {"msm_sort": round(sort_ms / proofs_total, 3), "msm_accumulate": round(acc_ms / proofs_total, 3),
                                                    "msm_reduce": round(red_ms / proofs_total, 3), "quotient": round(q_ms / proofs_total, 3) if q_ms else None} if inflight > 1 else None,
              "proofs_in_flight": inflight, "ms_per_proof": round(dt / proofs_total * 1e3, 3)}
+    if args.mode == "prove":
+        extra["quotient_executor"] = quotient_executor
     # roofline of the dominant kernel (msm_accumulate).  Algorithmic bytes = 96 B per (scalar, base) pair
     # (SURVEY 8d); one launch covers a whole batch, so bytes/launch = 96 * n * columns-per-launch.
     msm_columns = be_stats["msm_columns"]
@@ -1225,7 +1240,8 @@ def main(argv=None):
                 "data": "synthetic",
                 "config": {"workload": workload, "mode": args.mode,
                            "prover": "zk_plonk_create_proof (C++, csrc/prover.hip)" if args.prover == "native" else "plonk.create_proof (Python twin)",
-                           "parallelism": f"{world} x independent proofs (one process per GPU)"},
+                           "parallelism": f"{world} x independent proofs (one process per GPU)",
+                           "quotient": ("kernels generated for the key's program at key build (tune quot_jit = 1)" if args.mode == "prove" and quotient_executor["generated_kernels"] else "micro-op interpreter")},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line), flush=True)
     if multi_hung:

@@ -78,7 +78,7 @@ def rand_cols(pc_mod, orc, pyref, count, size, seed):
     return [pc_mod.rand_fr(orc, pyref, size, seed + 7 * i) for i in range(count)]
 
 
-def run_case(be, orc, pyref, pc_mod, prog, seed=5, check_cosets=True):
+def run_case(be, orc, pyref, pc_mod, prog, seed=5, check_cosets=True, expect_kernels=False):
     size = 1 << prog.extended_k
     chunk = prog.cs_degree - 2
     n_sets = (len(prog.perm_columns) + chunk - 1) // chunk if prog.perm_columns else 0
@@ -98,6 +98,8 @@ def run_case(be, orc, pyref, pc_mod, prog, seed=5, check_cosets=True):
     d_l0, d_ll, d_la = be.to_device(l0), be.to_device(l_last), be.to_device(l_active)
     out = be.alloc(size * 32)
     e = ev.Evaluator(prog, backend=be)
+    if expect_kernels:                                                 # tests/test_quotient_jit.py: the program must run on kernels generated for it, not on the interpreter
+        assert be.quotient_program_kernels(e.handle) >= 2, "the program was loaded without generated kernels (tune quot_jit)"
     e.evaluate_h(fixed=dev["fixed"], advice=dev["advice"], instance=dev["instance"], l0=d_l0, l_last=d_ll, l_active_row=d_la,
                  perm_cosets=dev["perm_cosets"], perm_products=dev["perm_products"], lookup_product=dev["lookup_product"],
                  lookup_input=dev["lookup_input"], lookup_table=dev["lookup_table"], challenges=chal, beta=beta, gamma=gamma, theta=theta, y=y, out=out)

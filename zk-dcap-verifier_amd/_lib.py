@@ -485,6 +485,12 @@ class Backend:
         self._ck(self.lib.zk_quotient_program_info(self.ctx, C.c_uint64(prog), C.byref(a), C.byref(b), C.byref(c)))
         return {"instructions": a.value, "slots": b.value, "columns": c.value}
 
+    def quotient_program_kernels(self, prog: int) -> int:
+        """generated kernels the program runs (tune quot_jit at load time); 0 = the micro-op interpreter"""
+        n = C.c_uint32()
+        self._ck(self.lib.zk_quotient_program_kernels(self.ctx, C.c_uint64(prog), C.byref(n)))
+        return n.value
+
     def quotient_program_opmix(self, prog: int, part: int = 0) -> dict:
         """opcode census of the compiled program; part 1 / 2 = its high / low part when it has a degree split (quotient_program_split)"""
         c = (C.c_uint32 * 9)()

@@ -45,6 +45,7 @@ int g1_ntt(zk_ctx* ctx, const void* d_affine_in, uint32_t log_n, const void* ome
 int quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog);
 int quotient_program_release(zk_ctx* ctx, uint64_t prog);
 int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
+int quotient_program_kernels(zk_ctx* ctx, uint64_t prog, uint32_t* n_kernels);
 int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t part, uint32_t counts[9]);
 int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* args, int coset, uint64_t row_lo, uint64_t row_count, int part, uint32_t low_cosets);
 int quotient_program_split(zk_ctx* ctx, uint64_t prog, uint32_t* low_cosets, uint32_t* n_instr_high, uint32_t* n_instr_low);
@@ -492,6 +493,7 @@ int zk_fr_lincomb_dev(zk_ctx* ctx, const void* const* polys_dev, const void* sca
 // ---- quotient -----------------------------------------------------------------------------------
 int zk_quotient_program_load(zk_ctx* ctx, const void* blob, size_t len, uint64_t* prog) ZK_ABI_TRY { ENTER; return quotient_program_load(ctx, blob, len, prog); } ZK_ABI_CATCH(ctx)
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* ni, uint32_t* ns, uint32_t* nc) ZK_ABI_TRY { ENTER; return quotient_program_info(ctx, prog, ni, ns, nc); } ZK_ABI_CATCH(ctx)
+int zk_quotient_program_kernels(zk_ctx* ctx, uint64_t prog, uint32_t* n_kernels) ZK_ABI_TRY { ENTER; return quotient_program_kernels(ctx, prog, n_kernels); } ZK_ABI_CATCH(ctx)
 int zk_quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t counts[9]) ZK_ABI_TRY { ENTER; return quotient_program_opmix(ctx, prog, 0, counts); } ZK_ABI_CATCH(ctx)
 int zk_quotient_program_part_opmix(zk_ctx* ctx, uint64_t prog, uint32_t part, uint32_t counts[9]) ZK_ABI_TRY { ENTER; return quotient_program_opmix(ctx, prog, part, counts); } ZK_ABI_CATCH(ctx)
 int zk_quotient_program_release(zk_ctx* ctx, uint64_t prog) ZK_ABI_TRY { ENTER; return quotient_program_release(ctx, prog); } ZK_ABI_CATCH(ctx)

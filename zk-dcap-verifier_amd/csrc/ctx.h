@@ -51,7 +51,7 @@ struct Tune {
     int quot_remat_distance = 24;   // ... is recomputed when its previous copy lies further back than this many micro-ops
     int quot_jit = 0;            // zk_quotient_program_load: also generate straight-line kernels for the program with hiprtc (quotient_jit.hip) and run those instead of the interpreter; 0 = interpreter only
     int quot_jit_waves = 0;      // ... amdgpu_waves_per_eu of the generated kernels (0 = the compiler's choice; 4 = the interpreter's budget of 128 VGPRs, which costs some kernels a few spills)
-    int quot_jit_group = 24;     // ... micro-ops with a product per generated kernel (the kernel's code has to stay inside the instruction cache)
+    int quot_jit_group = 200;    // ... products per generated kernel (swept 24 .. 400 on the sgx-shaped program, profiles/r05/run303: straight-line code streams well past the instruction cache; 200 = three to four kernels per program)
     int lookup_force_generic_sort = 0;   // tests: take the every-digit sort of permute_expression_pair even when the 64-bit window sort is exact
 };
 

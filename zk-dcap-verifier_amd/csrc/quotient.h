@@ -47,5 +47,6 @@ struct QuotJitKernel {                        // one generated kernel = a run of
 std::string quot_jit_source(const QuotProgram& P, uint32_t group_ops, std::vector<QuotJitKernel>* kernels, uint32_t waves_per_eu = 0);
 int quot_jit_build(zk_ctx* ctx, QuotProgram& P);                                   // tune quot_jit: compile P (and its parts) into kernels; failure leaves the interpreter in charge
 bool quot_jit_ready(const QuotProgram& P);
+uint32_t quot_jit_kernel_count(const QuotProgram& P);
 int quot_jit_launch(zk_ctx* ctx, const QuotProgram& P, const QuotArgs& q, uint64_t rows, uint32_t threads);
 }  // namespace zk

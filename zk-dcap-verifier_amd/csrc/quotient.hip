@@ -849,6 +849,13 @@ int quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_
     return ZK_OK;
 }
 // counts[op] = instructions with opcode op (add, sub, mul, sqr, dbl, neg, mov, muladd), counts[8] = memory (column / constant) operands
+int quotient_program_kernels(zk_ctx* ctx, uint64_t prog, uint32_t* n_kernels) {
+    auto it = ctx->programs.find(prog);
+    if (it == ctx->programs.end() || !n_kernels) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_kernels: unknown program %llu", (unsigned long long)prog);
+    const QuotProgram& P = *it->second;
+    *n_kernels = quot_jit_kernel_count(P) + (P.part_hi ? quot_jit_kernel_count(*P.part_hi) : 0u) + (P.part_lo ? quot_jit_kernel_count(*P.part_lo) : 0u);
+    return ZK_OK;
+}
 int quotient_program_opmix(zk_ctx* ctx, uint64_t prog, uint32_t part, uint32_t counts[9]) {
     auto it = ctx->programs.find(prog);
     if (it == ctx->programs.end() || !counts || part > 2) return ctx->fail(ZK_ERR_ARG, "zk_quotient_program_opmix: unknown program / null pointer / part");
@@ -999,7 +1006,7 @@ int quotient_run(zk_ctx* ctx, uint64_t prog, const zk_quotient_args* a, int cose
     const size_t lds = (size_t)lds_slots * T * 32;
     if (lds > 160 * 1024) return ctx->fail(ZK_ERR_LIMIT, "quotient program needs %zu bytes of LDS", lds);
     EvTimer tq(ctx, "quotient");
-    if (ctx->tune.quot_jit && quot_jit_ready(P)) {
+    if (quot_jit_ready(P)) {                                          // (the PROGRAM records whether it was generated: contexts that borrow it need no tunable of their own)
         uint32_t Tj = (uint32_t)std::min(ctx->tune.quot_threads, 256);
         if (Tj > rows) Tj = (uint32_t)rows;
         int rcj = quot_jit_launch(ctx, P, q, rows, Tj);

@@ -163,6 +163,7 @@ class Backend:
         for ptrs in pool.values():
             for p in ptrs:
                 self.lib.zk_dev_free(self.ctx, C.c_void_p(p))
+        self.lib.zk_plonk_trim(self.ctx)              # ... and the buffers zk_plonk_create_proof keeps per context between proofs (a k = 21 proof leaves ~80 GB of them)
 
     def close(self):
         if self.ctx:

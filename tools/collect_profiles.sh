@@ -22,7 +22,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cal_stream -o c -- ./tools/
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/valu -o v -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/mix -o m -- python3 bench.py --steps 1 --warmup 0 --inflight 1 --no-extras > /dev/null 2>> $O/bench.err
 unset ZK_TUNE
-python tools/prover_probe.py 19 3 > $O/${TAG}_prover_probe_k19.json 2>> $O/bench.err
+ZK_PROVER=native python tools/prover_probe.py 19 3 > $O/${TAG}_prover_probe_k19.json 2>> $O/bench.err
 ZK_CENSUS=reference_exact python tools/prover_probe.py 19 3 > $O/${TAG}_prover_probe_k19_census_reference_exact.json 2>> $O/bench.err
 python tools/prover_probe.py 21 1 > $O/${TAG}_prover_probe_k21.json 2>> $O/bench.err
 grep -h '^{' $O/${TAG}_bench_default.json | cut -c1-330

@@ -365,7 +365,26 @@ ZK_KERNEL void lpb_hist_kernel(const uint2* keys, uint32_t u, uint32_t pass, uin
     __syncthreads();
     for (uint32_t e = 0; e < FS_E; e++) {
         const uint32_t i = base + e * FS_T + tid;
-        if (i < u) atomicAdd(&lh[fs_digit(keys[i], pass)], 1u);
+        bool live = i < u;
+        const uint32_t d = live ? fs_digit(keys[i], pass) : 0u;
+#ifndef ZK_EMU
+        // Most passes of a lookup's sort see ONE hot digit (the upper digits of small values, the zero padding of a column): 64 lanes adding to one LDS word serialise —
+        // 96 % of this kernel's LDS cycles were conflicts.  Two rounds of wave aggregation take the lanes that share the first live lane's digit out with one add
+        // of their count; what is left goes lane by lane as before (uniform digits pay two ballots).
+#pragma unroll
+        for (int round = 0; round < 2; round++) {
+            if (live) {
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                const bool same = d == lead;
+                const unsigned long long m = __ballot(same);
+                if (same) {
+                    if ((__lane_id() & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(&lh[lead], (uint32_t)__builtin_popcountll(m));
+                    live = false;
+                }
+            }
+        }
+#endif
+        if (live) atomicAdd(&lh[d], 1u);
     }
     __syncthreads();
     ghist[((size_t)s * nwg + blockIdx.x) * 256 + tid] = lh[tid];

@@ -835,7 +835,7 @@ def main(argv=None):
                             "pmc_source": json.load(open(tj)).get("valu_source") if acc_valu else None},
                 # the other throughput-bound kernels, same counters (profiles/traffic.json): NTT passes and the quotient interpreter
                 "other_kernels_pmc": {k_: {c_: valu[k_].get(c_) for c_ in ("ms_per_launch", "valu_busy", "active_valu_per_wave_cycle", "wait_inst_per_wave_cycle", "eff_clock_ghz", "int64_share", "issue_model")}
-                                      for k_ in ("ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "quotient_kernel") if k_ in valu} or None}
+                                      for k_ in ("ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "quotient_kernel", "zkq_generated") if k_ in valu} or None}
     if isinstance(traffic, dict):
         alg = roofline["algorithmic_bytes_per_launch"]
         pairs_per_launch = msm_pairs / max(acc_n, 1)
@@ -857,7 +857,8 @@ def main(argv=None):
         kline("ntt_strided_pass29_kernel + ntt_final_pass_kernel", 64.0 * be_stats["ntt_points"], ntt_ms, ntt_s_n + ntt_f_n, per_unit="64 B per point per transform",
               passes=round(passes, 2) if passes else None, hbm_bytes_moved_estimate=round(64.0 * be_stats["ntt_pass_points"]),
               strided_ms=round(ntt_s_ms or 0.0, 3), final_ms=round(ntt_f_ms or 0.0, 3)),
-        kline("quotient_kernel", be_stats["quotient_alg_bytes"], q_ms or 0.0, q_n, per_unit="(columns + 1) x 32 B per evaluated row")]
+        kline("quotient (kernels generated for the key's program)" if args.mode == "prove" and quotient_executor["generated_kernels"] else "quotient_kernel",
+              be_stats["quotient_alg_bytes"], q_ms or 0.0, q_n, per_unit="(columns + 1) x 32 B per evaluated row")]
 
     if args.mode == "prove":
         # The same K steps once more with the witness starting in HOST memory (what the Rust boundary hands over: create_proof receives host-owned

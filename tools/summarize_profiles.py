@@ -12,7 +12,8 @@ import sys
 
 
 def short(n):
-    return re.sub(r"<.*", "", re.sub(r"\(.*", "", n).replace("zk::", "").replace("void ", ""))      # templates: quotient_kernel<1> -> quotient_kernel
+    n = re.sub(r"<.*", "", re.sub(r"\(.*", "", n).replace("zk::", "").replace("void ", ""))      # templates: quotient_kernel<1> -> quotient_kernel
+    return "zkq_generated" if re.match(r"zkq[0-9a-f]*_\d+$", n) else n                            # the kernels generated per quotient program (csrc/quotient_jit.hip): one class
 
 
 def last_json_line(path):
@@ -47,7 +48,7 @@ def valu_section(O, P, tag, rnd):
                 d[k]["ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         return d
     v, m = per_kernel(vp), per_kernel(mp)
-    keep = ["msm_accumulate_kernel", "ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "ntt_final_pass29_kernel", "quotient_kernel", "msm_scatter_kernel", "msm_hist_kernel", "msm_merge_kernel",
+    keep = ["msm_accumulate_kernel", "ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "ntt_final_pass29_kernel", "quotient_kernel", "zkq_generated", "msm_scatter_kernel", "msm_hist_kernel", "msm_merge_kernel",
             "msm_rowcol_kernel", "lpb_scatter_kernel", "pe_lincomb_kernel", "pe_eval_partial_kernel", "gp_batch_divide_kernel"]
     out = {}
     with open(f"{P}/{tag}_rocprofv3_pmc_valu.csv", "w") as f:
@@ -137,7 +138,7 @@ def main():
                 d[k][1] += float(r["Counter_Value"])
         return d
     fe, wr = agg(f"{O}/fetch/f_counter_collection.csv", "FETCH_SIZE"), agg(f"{O}/write/w_counter_collection.csv", "WRITE_SIZE")
-    keep = ["msm_accumulate_kernel", "quotient_kernel", "ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "ntt_final_pass29_kernel", "msm_hist_kernel", "msm_scatter_kernel", "lpb_scatter_kernel",
+    keep = ["msm_accumulate_kernel", "quotient_kernel", "zkq_generated", "ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel", "ntt_final_pass29_kernel", "msm_hist_kernel", "msm_scatter_kernel", "lpb_scatter_kernel",
             "lpb_hist_kernel", "msm_merge_kernel", "msm_rowcol_kernel", "pe_eval_partial_kernel", "pe_lincomb_kernel", "gp_batch_divide_kernel"]
     traffic, raw = {}, {}
     with open(f"{P}/{tag}_rocprofv3_pmc_hbm_traffic.csv", "w") as f:
@@ -156,6 +157,7 @@ def main():
     tj = {"source": f"profiles/{rnd}/{tag}_rocprofv3_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 --inflight 1 --no-extras; "
                     "bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 per the gfx950 correction of MI355X_MICROARCH.md HBM section)",
           "msm_accumulate_bytes_per_launch": round(traffic["msm_accumulate_kernel"]), "quotient_bytes_per_launch": round(traffic["quotient_kernel"]),
+          "quotient_generated_bytes_per_launch": round(traffic["zkq_generated"]) if "zkq_generated" in traffic else None,      # the kernels generated for the key's program (tune quot_jit): one launch = one kernel of a part
           "ntt_strided_pass_bytes_per_launch": round(traffic.get("ntt_strided_pass29_kernel") or traffic["ntt_strided_pass_kernel"]),      # (the 29-bit-limb kernel when the plan uses it)
           "ntt_final_pass_bytes_per_launch": round(traffic.get("ntt_final_pass_kernel") or traffic["ntt_final_pass29_kernel"]),
           "kernels": raw}                                              # FETCH_SIZE / WRITE_SIZE as counted, per launch: bench.py reports raw and doubled readings side by side
@@ -173,7 +175,7 @@ def main():
         f.write("# lookup radix sort is the share of LDS cycles lost to bank conflicts: conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (both in LDS-array cycles), and LDS busy share of wave cycles\n")
         f.write("kernel,launches,SQ_INSTS_LDS,SQ_LDS_IDX_ACTIVE,SQ_LDS_BANK_CONFLICT,conflict_frac,lds_active_over_wave_cycles\n")
         for k in ["msm_hist_kernel", "msm_scatter_kernel", "msm_rowcol_kernel", "lpb_hist_kernel", "lpb_scatter_kernel", "ntt_strided_pass_kernel", "ntt_strided_pass29_kernel", "ntt_final_pass_kernel",
-                  "ntt_final_pass29_kernel", "quotient_kernel"]:
+                  "ntt_final_pass29_kernel", "quotient_kernel", "zkq_generated"]:
             if k in d:
                 v = d[k]
                 act = v["SQ_LDS_IDX_ACTIVE"] or 1

@@ -43,6 +43,7 @@ struct QuotJitKernel {                        // one generated kernel = a run of
     uint32_t first = 0, count = 0;            // micro-ops [first, first + count)
     std::vector<uint32_t> live_in, live_out;  // slots whose values cross the kernel's boundaries (carried in QuotArgs::state, one row-major plane per slot)
     bool reads_acc = false;                   // the accumulator arrives from the previous kernel (in `out`, redundant form)
+    std::string name;                         // zkq<program tag>_<index>
 };
 std::string quot_jit_source(const QuotProgram& P, uint32_t group_ops, std::vector<QuotJitKernel>* kernels, uint32_t waves_per_eu = 0);
 int quot_jit_build(zk_ctx* ctx, QuotProgram& P);                                   // tune quot_jit: compile P (and its parts) into kernels; failure leaves the interpreter in charge

@@ -257,6 +257,9 @@ int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint
  * zk_quotient_run*_dev and zk_plonk_prove on that program, from any context that holds or borrows it, then runs those kernels instead of the micro-op interpreter: the same field
  * elements (the same proof bytes), about a fifth less kernel time on the quotient, +2.7-3.0 % proofs per hour at k = 19 (profiles/r05/run303).  A load that asks for them and cannot
  * have them (no libhiprtc.so, a compile error) FAILS with ZK_ERR_PROGRAM: the executor is never swapped silently.  Default 0: the interpreter.
+ * "quot_jit" = 1 generates what a proof on ONE GPU launches: the high and low degree parts of a split program ("quot_degree_split", the default) and nothing for the whole
+ * program — zk_quotient_run_dev / _coset_dev / _coset_rows_dev on it (a sharded proof's units, a proof that turns the split off) stay on the interpreter — or the whole program
+ * when there is no split; that halves the compile (compile time is linear in the products generated).  "quot_jit" = 2 generates all three.
  * zk_quotient_program_kernels: how many generated kernels `prog` runs (its high and low degree parts included); 0 = the interpreter. */
 int zk_quotient_program_kernels(zk_ctx* ctx, uint64_t prog, uint32_t* n_kernels);
 /* opcode census of the compiled micro-program (the arithmetic a row costs — what the kernel's roofline is priced from):

@@ -99,7 +99,7 @@ def run_case(be, orc, pyref, pc_mod, prog, seed=5, check_cosets=True, expect_ker
     out = be.alloc(size * 32)
     e = ev.Evaluator(prog, backend=be)
     if expect_kernels:                                                 # tests/test_quotient_jit.py: the program must run on kernels generated for it, not on the interpreter
-        assert be.quotient_program_kernels(e.handle) >= 2, "the program was loaded without generated kernels (tune quot_jit)"
+        assert be.quotient_program_kernels(e.handle) >= (2 if expect_kernels is True else int(expect_kernels)), "the program was loaded without generated kernels (tune quot_jit)"
     e.evaluate_h(fixed=dev["fixed"], advice=dev["advice"], instance=dev["instance"], l0=d_l0, l_last=d_ll, l_active_row=d_la,
                  perm_cosets=dev["perm_cosets"], perm_products=dev["perm_products"], lookup_product=dev["lookup_product"],
                  lookup_input=dev["lookup_input"], lookup_table=dev["lookup_table"], challenges=chal, beta=beta, gamma=gamma, theta=theta, y=y, out=out)

@@ -60,7 +60,7 @@ def test_generated_source_is_valid_hip_for_gfx950(emu, orc, pyref, tmp_path, gro
 def test_generated_kernels_against_the_oracle_gpu(gpu, orc, pyref):
     """one of tests/test_quotient.py's random-program shapes (gates with rotations, a two-set permutation, two lookups, an instance column, a challenge): whole domain, every
     coset, row slices and both degree parts, each against the oracle — through kernels cut after every 6 products, so that accumulator and slots cross many boundaries"""
-    gpu.tune(quot_jit=1, quot_jit_group=6)
+    gpu.tune(quot_jit=2, quot_jit_group=6)          # 2: the whole program AND its degree parts (1 leaves the whole program of a split key on the interpreter)
     try:
         prog = qc.build_program(orc, pyref, seed=5, gate_ops=24, k=8, cs_degree=5, n_fixed=4, n_advice=6, n_instance=1, n_challenges=1, n_perm=7, n_lookups=3)
         qc.run_case(gpu, orc, pyref, pc, prog, seed=5, expect_kernels=True)
@@ -84,3 +84,24 @@ def test_golden_proofs_through_generated_kernels_gpu(gpu, orc):
         params.release()
     finally:
         gpu.tune(quot_jit=0)
+
+
+@pytest.mark.gpu
+def test_level_one_generates_the_degree_parts_only_gpu(gpu, orc, pyref):
+    """quot_jit = 1 on a split program: kernels for the high and low parts (what a single-GPU proof launches), the whole program stays on the interpreter — and still
+    gives the oracle's values; quot_jit = 2 adds the whole program's kernels"""
+    from zk_dcap_verifier_amd import evaluation as ev
+    prog = qc.build_program(orc, pyref, seed=11, gate_ops=24, k=6, cs_degree=5, n_fixed=3, n_advice=4, n_instance=1, n_challenges=1, n_perm=5, n_lookups=2)
+    counts = {}
+    try:
+        for level in (1, 2):
+            gpu.tune(quot_jit=level, quot_jit_group=8)
+            e = ev.Evaluator(prog, backend=gpu)
+            assert gpu.quotient_program_split(e.handle)["low_cosets"] == 2
+            counts[level] = gpu.quotient_program_kernels(e.handle)
+            e.release()
+        assert 2 <= counts[1] < counts[2], counts
+        gpu.tune(quot_jit=1, quot_jit_group=8)
+        qc.run_case(gpu, orc, pyref, pc, prog, seed=11, expect_kernels=True)        # whole domain and cosets on the interpreter, the parts on their kernels
+    finally:
+        gpu.tune(quot_jit=0, quot_jit_group=200)

@@ -49,7 +49,7 @@ struct Tune {
     int quot_factor_horner = 1;  // quotient compiler: q * Horner([a_j], theta) for a theta-compression whose parts all carry the factor q (selector-switched lookups): m - 1 products fewer per row
     int quot_remat_ops = 4;      // quotient compiler: a shared sub-expression of at most this many operations ...
     int quot_remat_distance = 24;   // ... is recomputed when its previous copy lies further back than this many micro-ops
-    int quot_jit = 0;            // zk_quotient_program_load: also generate straight-line kernels for the program with hiprtc (quotient_jit.hip) and run those instead of the interpreter; 0 = interpreter only
+    int quot_jit = 0;            // zk_quotient_program_load: also generate straight-line kernels for the program with hiprtc (quotient_jit.hip) and run those instead of the interpreter; 0 = interpreter only; 1 = the kernels a single-GPU proof launches (the degree parts of a split program, else the whole program); 2 = whole program and parts
     int quot_jit_waves = 0;      // ... amdgpu_waves_per_eu of the generated kernels (0 = the compiler's choice; 4 = the interpreter's budget of 128 VGPRs, which costs some kernels a few spills)
     int quot_jit_group = 200;    // ... products per generated kernel (swept 24 .. 400 on the sgx-shaped program, profiles/r05/run303: straight-line code streams well past the instruction cache; 200 = three to four kernels per program)
     int lookup_force_generic_sort = 0;   // tests: take the every-digit sort of permute_expression_pair even when the 64-bit window sort is exact

@@ -682,7 +682,7 @@ def main(argv=None):
         wls = []
         # the headline key's quotient runs on kernels GENERATED for its program (csrc/quotient_jit.hip: hiprtc at key build, tune quot_jit; the contexts that borrow the key
         # borrow the kernels).  Only this key: the other keys a default run builds (second census, configs[0], sharded extras) keep the interpreter — a key build costs
-        # ~45 s of compilation on a box that has not seen the program before (comgr's cache makes it 0.1 s afterwards).  --no-jit / ZK_TUNE=quot_jit=0: interpreter everywhere.
+        # ~13 s of compilation (level 1: the degree parts) on a box that has not seen the program before (comgr's cache makes it 0.1 s afterwards).  --no-jit / ZK_TUNE=quot_jit=0: interpreter everywhere.
         want_jit = not args.no_jit and bench_tune.get("quot_jit", 1) != 0 and not os.environ.get("ZK_BENCH_PLUMBING_TEST")
         if want_jit:
             be.tune(quot_jit=1)

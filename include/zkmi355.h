@@ -253,7 +253,7 @@ int zk_quotient_program_share(zk_ctx* ctx, zk_ctx* owner, uint64_t owner_prog, u
 int zk_quotient_program_info(zk_ctx* ctx, uint64_t prog, uint32_t* n_instr, uint32_t* n_slots, uint32_t* n_columns);
 /* Generated kernels (csrc/quotient_jit.hip).  With tune "quot_jit" = 1 at zk_quotient_program_load / zk_plonk_pk_build a program whose extended domain is larger than its
  * domain is ALSO turned into straight-line kernels written for it — one statement per micro-op on the same field functions, "quot_jit_group" products per kernel — and compiled
- * for gfx950 by hiprtc inside the load (about 45 s for the sgx-shaped program on a box that has not seen it; comgr caches the code objects, the next load takes 0.1 s).  Every
+ * for gfx950 by hiprtc inside the load (13 s at level 1 and about 45 s at level 2 for the sgx-shaped program on a box that has not seen it; comgr caches the code objects, the next load takes 0.1 s).  Every
  * zk_quotient_run*_dev and zk_plonk_prove on that program, from any context that holds or borrows it, then runs those kernels instead of the micro-op interpreter: the same field
  * elements (the same proof bytes), about a fifth less kernel time on the quotient, +2.7-3.0 % proofs per hour at k = 19 (profiles/r05/run303).  A load that asks for them and cannot
  * have them (no libhiprtc.so, a compile error) FAILS with ZK_ERR_PROGRAM: the executor is never swapped silently.  Default 0: the interpreter.

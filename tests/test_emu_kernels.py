@@ -67,13 +67,27 @@ def test_msm_uniform(emu, orc, pyref, n, c):
 def test_msm_both_sorts(emu, orc, pyref, n, c, kind, two_level):
     """The pairs are grouped by bucket either by the one-level counting sort (small / batched inputs) or the two-level one (large inputs):
     force each and compare with the oracle; a batch too."""
-    emu.tune(msm_c=c, msm_two_level_sort=two_level)
+    emu.tune(msm_c=c, msm_two_level_sort=two_level, msm_bsort_chunk=64 if n in (257, 513) else 8192)   # (two-level: some cases with bins of several chunks)
     try:
         pc.check_msm(emu, orc, pyref, n, seed=n + 1, kind=kind)
         if n == 300:
             pc.check_msm_batch(emu, orc, pyref, 120, 6)
     finally:
-        emu.tune(msm_c=0, msm_two_level_sort=0)
+        emu.tune(msm_c=0, msm_two_level_sort=0, msm_bsort_chunk=8192)
+
+
+@pytest.mark.parametrize("n,c,kind", [(300, 17, "uniform"), (700, 18, "uniform"), (257, 17, "minus_one"), (257, 18, "witness"), (64, 17, "zeros")])
+def test_msm_wide_windows(emu, orc, pyref, n, c, kind):
+    """windows wider than 16 bits (c = 17 .. 22, the large-n plan: fewer windows per scalar for more buckets) take the two-level sort with bins of 2^8 .. 2^10 buckets"""
+    emu.tune(msm_c=c)
+    try:
+        pc.check_msm(emu, orc, pyref, n, seed=n + c, kind=kind)
+        if n == 300:
+            pc.check_msm_batch(emu, orc, pyref, 120, 3)
+        emu.tune(msm_bsort_chunk=64)                       # bins cut into several chunks (the short top window fills the lowest bin)
+        pc.check_msm(emu, orc, pyref, n, seed=n + c + 1, kind=kind)
+    finally:
+        emu.tune(msm_c=0, msm_bsort_chunk=8192)
 
 
 @pytest.mark.parametrize("kind", ["ones", "zeros", "witness", "minus_one"])

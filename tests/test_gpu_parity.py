@@ -62,13 +62,13 @@ def test_msm_uniform_vs_oracle(gpu, orc, pyref, n):
                                       (5000, 0, "ones"), (5000, 0, "witness"), (5000, 16, "minus_one"), (5000, 0, "zeros")])
 def test_msm_both_sorts(gpu, orc, pyref, n, c, kind, two_level):
     """one-level (small / batched) and two-level (large) bucket sort, each forced, against the oracle"""
-    gpu.tune(msm_c=c, msm_two_level_sort=two_level)
+    gpu.tune(msm_c=c, msm_two_level_sort=two_level, msm_bsort_chunk=512 if n == 5000 else 8192)   # (two-level: the degenerate columns with bins of several chunks)
     try:
         pc.check_msm(gpu, orc, pyref, n, seed=n + 1, kind=kind)
         if n == 3000:
             pc.check_msm_batch(gpu, orc, pyref, 2000, 7, device=True)
     finally:
-        gpu.tune(msm_c=0, msm_two_level_sort=0)
+        gpu.tune(msm_c=0, msm_two_level_sort=0, msm_bsort_chunk=8192)
 
 
 @pytest.mark.parametrize("c", [3, 8, 11, 13, 16])
@@ -78,6 +78,21 @@ def test_msm_window_sizes(gpu, orc, pyref, c):
         pc.check_msm(gpu, orc, pyref, 3000, seed=c)
     finally:
         gpu.tune(msm_c=0)
+
+
+@pytest.mark.parametrize("n,c,kind", [(3000, 17, "uniform"), (40000, 19, "uniform"), (20000, 22, "uniform"), (5000, 20, "minus_one"), (5000, 22, "witness"), (5000, 21, "ones"),
+                                      (1, 22, "uniform"), (5000, 18, "zeros")])
+def test_msm_wide_windows(gpu, orc, pyref, n, c, kind):
+    """windows wider than 16 bits (c = 17 .. 22: what a 2^24 MSM runs with) take the two-level sort with up to 2048 bins of up to 1024 buckets"""
+    gpu.tune(msm_c=c)
+    try:
+        pc.check_msm(gpu, orc, pyref, n, seed=n + c, kind=kind)
+        if n == 3000:
+            pc.check_msm_batch(gpu, orc, pyref, 2000, 5, device=True)
+        gpu.tune(msm_bsort_chunk=256)                      # bins cut into several chunks (the short top window fills the lowest bins)
+        pc.check_msm(gpu, orc, pyref, n, seed=n + c + 1, kind=kind)
+    finally:
+        gpu.tune(msm_c=0, msm_bsort_chunk=8192)
 
 
 @pytest.mark.parametrize("kind", ["ones", "zeros", "witness", "minus_one"])

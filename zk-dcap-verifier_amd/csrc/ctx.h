@@ -20,7 +20,12 @@ struct Tune {
     int msm_c = 0;               // 0 = pick from n
     int msm_sort_wgs = 256;      // workgroups of the counting-sort kernels (one per CU)
     int msm_sort_threads = 1024;
-    int msm_bsort_threads = 256;     // workgroup size of the per-bin bucket sort (small LDS footprint: several workgroups per CU hide its load latency)
+    int msm_bsort_threads = 1024;    // workgroup size of the two-level sort's second level ...
+    int msm_bsort_chunk = 8192;      // ... and the entries of a bin one of its workgroups sorts: one round of eight entries per lane — the kernel is a chain of load -> LDS atomic -> scattered store,
+                                     // and its time follows the rounds a lane runs one after the other (2^24 scalars, c = 20: 256 threads x 65536 entries 5.8 ms of sort, this 3.6: profiles/r05/run35x)
+    int msm_part_threads = 1024, msm_part_pairs = 16384; // two-level sort, first level: workgroup size and the pairs a workgroup stages in LDS (8 bytes each): a workgroup pays a scan and one global
+                                                         // atomic per bin whatever it stages (2^24, c = 20: 256 x 8192 3.64 ms of sort, 1024 x 16384 3.09, 256 x 4096 5.72: profiles/r05/run357)
+    int msm_wide_bins_log = 9;       // windows wider than 16 bits: log2 of the bins of the two-level sort (8 .. 11; 9 measured best at 2^24)
     int msm_two_level_sort = 0;      // 1: take the two-level bucket sort even where the one-level sort applies (tests, measurements)
     int msm_sort_batch_wgs = 2048;   // total sort workgroups aimed for by a batched call
     int msm_target_threads = 1 << 19;  // sub-bucket count the accumulate launch aims for

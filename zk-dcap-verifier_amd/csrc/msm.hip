@@ -128,9 +128,9 @@ struct MsmPlan {
     uint32_t small_stride, o_off, o_cursor, o_suboff, o_info, o_tiles, o_fulloff, o_remorder, o_remhist, o_remstart, o_remcursor;
     uint32_t* sorted;                      // per column: pairs_max references
     uint64_t sorted_stride;
-    uint32_t low_bits, nbin, pch, o_bintot, o_bincur;   // two-level sort: bin = bucket >> low_bits; pch = scalars per partition workgroup
+    uint32_t low_bits, nbin, pch, bch, o_bintot, o_bincur, o_binbase, o_chunkbase;   // two-level sort: bin = bucket >> low_bits; pch = scalars per partition workgroup; bch = entries per second-level workgroup
     uint32_t* mid_ref;                     // per column (stride sorted_stride): references grouped by bin ...
-    uint8_t* mid_low;                      // ... and the low bits of their bucket
+    uint16_t* mid_low;                     // ... and the low bits of their bucket
     void* sub[2];                          // level r lives in sub[r & 1]
     uint64_t sub_stride[2];                // entries per column
     void* cls[2];
@@ -148,14 +148,18 @@ ZK_HD uint32_t plan_eff_levels(const MsmPlan& p, uint32_t max_s) {  // merge rou
 // grouping the (scalar, window) pairs by bucket: a two-level counting sort.
 // (Written to replace the one-level sort below, whose workgroups put ~1 pair into each of their 32768 buckets at n = 2^19 — millions of
 // global atomics and isolated 4-byte stores per column.  Measured, it does not: see the note at the one-level kernels.)
-//        bin_hist    bucket >> low_bits (<= 256 bins): per-column bin totals                                (LDS counters, 256 global atomics / workgroup)
+//        bin_hist    bucket >> low_bits (<= MSM_MAX_BINS bins): per-column bin totals                       (LDS counters, one global atomic per bin and workgroup)
+//        bin_base    one workgroup per column: exclusive scan of the bin totals (every later workgroup reads its bases instead of scanning)
 //        partition   a workgroup takes pch scalars, groups their pairs by bin in LDS and writes each bin's run with coalesced stores
 //                    (reference + low bucket bits) at a range reserved with ONE global atomic per bin
-//        bucket_sort one workgroup per bin: <= 128 bucket counters in LDS, the bin's slice of `sorted` is a window of a few hundred KB
-//                    (L2-resident); it also writes the bucket sizes the scans below start from.
+//        bsort_count / bsort_place   a bin's run is cut into chunks of <= bch entries, one workgroup each, <= MSM_MAX_LOW bucket counters in LDS: count adds the
+//                    chunk's bucket sizes to the histogram the scans below start from; place (after the scans) reserves and fills the chunk's slots of `sorted`.
 // reference = (negative << 31) | (window * n_table + scalar index)
+// It is also the ONLY sort for windows wider than 16 bits (c = 17 .. 22: 2^(c-1) counters do not fit one CU's LDS): 256 bins of 2^8 .. 2^13 buckets.
+// Wide windows pay where n is large against the bucket count — 2^24 scalars at c = 22 are 12 windows instead of 16 (-25 % additions) for 2^21 buckets.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t MSM_MAX_BINS = 256, MSM_PART_PAIRS = 8192;
+constexpr uint32_t MSM_MAX_BINS = 2048, MSM_MAX_LOW = 8192;
+constexpr int MSM_MAX_C = 22;
 
 // inclusive scan of v[0..N) in LDS (N <= MSM_MAX_BINS), any block size; tmp: N words
 __device__ __forceinline__ void block_incscan(uint32_t* v, uint32_t* tmp, uint32_t N) {
@@ -188,17 +192,33 @@ ZK_KERNEL void msm_bin_hist_kernel(MsmPlan p) {
     }
 }
 
-// Every thread keeps its (<= PART_SPT) canonical scalars in registers between the counting and the placing sweep; the staging area is
-// small enough for three workgroups per CU (the sweeps are latency chains: load -> Montgomery reduction -> digits -> LDS atomics).
+// exclusive scans of a column's bin totals (one workgroup per column): binbase[b] = pairs in bins below b, chunkbase[b] = chunks of <= bch pairs in bins below b
+// (a bin is sorted by ceil(size / bch) workgroups — the short top window of a scalar puts 1/W of all pairs into the few lowest bins, so bins are NOT of one size)
+ZK_KERNEL void msm_bin_base_kernel(MsmPlan p) {
+    __shared__ uint32_t v[MSM_MAX_BINS], w[MSM_MAX_BINS], tmp[MSM_MAX_BINS];
+    uint32_t* sm = plan_small(p, blockIdx.x);
+    for (uint32_t b = threadIdx.x; b < p.nbin; b += blockDim.x) { const uint32_t t = sm[p.o_bintot + b]; v[b] = t; w[b] = ceil_div(t, p.bch); }
+    __syncthreads();
+    block_incscan(v, tmp, p.nbin);
+    block_incscan(w, tmp, p.nbin);
+    for (uint32_t b = threadIdx.x; b < p.nbin; b += blockDim.x) { sm[p.o_binbase + b + 1] = v[b]; sm[p.o_chunkbase + b + 1] = w[b]; }
+    if (threadIdx.x == 0) { sm[p.o_binbase] = 0; sm[p.o_chunkbase] = 0; }
+}
+
+// Every thread keeps its (<= PART_SPT) canonical scalars in registers between the counting and the placing sweep (the sweeps are latency chains:
+// load -> Montgomery reduction -> digits -> LDS atomics).  LDS: the staging area (a reference and a bucket index per pair) and four words per bin.
 constexpr uint32_t PART_SPT = 2;
 ZK_KERNEL void msm_partition_kernel(MsmPlan p) {
-    ZK_DYN_SHARED(uint32_t, st_ref);                       // [pch * W] references, then [pch * W] u16 bucket indices
-    __shared__ uint32_t cnt[MSM_MAX_BINS], start[MSM_MAX_BINS], dst[MSM_MAX_BINS], base[MSM_MAX_BINS], tmp[MSM_MAX_BINS];
+    ZK_DYN_SHARED(uint32_t, st_ref);                       // [pch * W] references | [pch * W] bucket indices | cnt, start, dst, tmp [nbin]
     const uint32_t col = blockIdx.y, nbin = p.nbin, cap = p.pch * (uint32_t)p.W;
-    uint16_t* st_key = reinterpret_cast<uint16_t*>(st_ref + cap);
+    uint32_t* st_key = st_ref + cap;
+    uint32_t* cnt = st_key + cap;
+    uint32_t* start = cnt + nbin;
+    uint32_t* dst = start + nbin;
+    uint32_t* tmp = dst + nbin;
     const void* scalars = p.scalars[col];
     uint32_t* sm = plan_small(p, col);
-    for (uint32_t b = threadIdx.x; b < nbin; b += blockDim.x) { cnt[b] = 0; base[b] = sm[p.o_bintot + b]; }
+    for (uint32_t b = threadIdx.x; b < nbin; b += blockDim.x) cnt[b] = 0;
     const uint32_t lo = blockIdx.x * p.pch;
     const uint32_t hi = lo + p.pch < p.n ? lo + p.pch : p.n;
     u256 sc[PART_SPT];
@@ -220,10 +240,9 @@ ZK_KERNEL void msm_partition_kernel(MsmPlan p) {
     for (uint32_t b = threadIdx.x; b < nbin; b += blockDim.x) start[b] = cnt[b];
     __syncthreads();
     block_incscan(start, tmp, nbin);                       // start[b] = end of bin b inside this workgroup's staging area
-    block_incscan(base, tmp, nbin);                        // base[b]  = end of bin b in the column
     for (uint32_t b = threadIdx.x; b < nbin; b += blockDim.x) {
         const uint32_t c0 = cnt[b];
-        dst[b] = (base[b] - sm[p.o_bintot + b]) + (c0 ? atomicAdd(&sm[p.o_bincur + b], c0) : 0u);
+        dst[b] = sm[p.o_binbase + b] + (c0 ? atomicAdd(&sm[p.o_bincur + b], c0) : 0u);
         tmp[b] = start[b] - c0;                            // cursor
     }
     __syncthreads();
@@ -236,62 +255,99 @@ ZK_KERNEL void msm_partition_kernel(MsmPlan p) {
             for_each_digit(sc[u], p.c, p.W, [&](int j, uint32_t mag, bool neg) {
                 const uint32_t pos = atomicAdd(&tmp[(mag - 1) >> p.low_bits], 1u);
                 st_ref[pos] = (neg ? 0x80000000u : 0u) | ((uint32_t)j * p.n_table + i);
-                st_key[pos] = (uint16_t)(mag - 1);
+                st_key[pos] = mag - 1;
             });
     }
     __syncthreads();
     const uint32_t total = tmp[nbin - 1];                  // the last cursor ended at the number of staged pairs
     uint32_t* mref = p.mid_ref + (size_t)col * p.sorted_stride;
-    uint8_t* mlow = p.mid_low + (size_t)col * p.sorted_stride;
+    uint16_t* mlow = p.mid_low + (size_t)col * p.sorted_stride;
     const uint32_t lmask = (1u << p.low_bits) - 1u;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {   // neighbouring lanes -> neighbouring addresses of the same bin's run
         const uint32_t key = st_key[e], b = key >> p.low_bits;
         const uint32_t d = dst[b] + (e - start[b]);
         mref[d] = st_ref[e];
-        mlow[d] = (uint8_t)(key & lmask);
+        mlow[d] = (uint16_t)(key & lmask);
     }
 }
 
-// One workgroup per (bin, column).  The bin's entries are read four at a time (one 4-byte load of low bits, one 16-byte load of references
-// per lane; the column arrays are 16-byte aligned and the range is widened to multiples of four entries, the overhang masked).
-ZK_KERNEL void msm_bucket_sort_kernel(MsmPlan p) {
-    __shared__ uint32_t cnt[128], cur[128], tmp[MSM_MAX_BINS], red[MSM_MAX_BINS];
-    const uint32_t col = blockIdx.y, bin = blockIdx.x, nlow = 1u << p.low_bits;
+// The second level: workgroup t of a column takes chunk t - chunkbase[bin] of the bin it falls into (<= bch entries of the bin's run, all of them buckets of that bin),
+// counts them per bucket in LDS (2^low_bits counters) and
+//   count:  adds its counts to the column's histogram (the scans below turn it into bucket offsets and cursors, as for the one-level sort);
+//   place:  reserves its entries' slots of every bucket with one global atomic per non-empty bucket, then walks the chunk again and stores each reference at
+//           its bucket's running LDS cursor.
+// Consecutive lanes read consecutive entries (4-byte references, 2-byte low bits).
+constexpr uint32_t BS_U = 8;
+__device__ __forceinline__ bool bsort_chunk(const MsmPlan& p, const uint32_t* sm, uint32_t& bin, uint32_t& lo, uint32_t& hi) {
+    const uint32_t t = blockIdx.x;
+    if (t >= sm[p.o_chunkbase + p.nbin]) return false;
+    bin = find_segment(sm + p.o_chunkbase, p.nbin, t);
+    lo = sm[p.o_binbase + bin] + (t - sm[p.o_chunkbase + bin]) * p.bch;
+    const uint32_t end = sm[p.o_binbase + bin + 1];
+    hi = lo + p.bch < end ? lo + p.bch : end;
+    return true;
+}
+ZK_KERNEL void msm_bsort_count_kernel(MsmPlan p) {
+    ZK_DYN_SHARED(uint32_t, cnt);                          // [2^low_bits]
+    const uint32_t col = blockIdx.y, nlow = 1u << p.low_bits;
     uint32_t* sm = plan_small(p, col);
-    for (uint32_t b = threadIdx.x; b < p.nbin; b += blockDim.x) red[b] = b < bin ? sm[p.o_bintot + b] : 0u;
+    uint32_t bin, lo, hi;
+    if (!bsort_chunk(p, sm, bin, lo, hi)) return;          // (uniform: before any barrier)
     for (uint32_t b = threadIdx.x; b < nlow; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    block_incscan(red, tmp, p.nbin);
-    const uint32_t base = red[p.nbin - 1], end = base + sm[p.o_bintot + bin];
-    const uint32_t* __restrict__ mref = p.mid_ref + (size_t)col * p.sorted_stride;
-    const uint8_t* __restrict__ mlow = p.mid_low + (size_t)col * p.sorted_stride;
-    const uint32_t a0 = base & ~3u, step = 4 * blockDim.x;
-    for (uint32_t e = a0 + 4 * threadIdx.x; e < end; e += 2 * step) {
-        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(mlow + e);
-        const uint32_t w1 = e + step < end ? *reinterpret_cast<const uint32_t*>(mlow + e + step) : 0u;
+    const uint16_t* __restrict__ mlow = p.mid_low + (size_t)col * p.sorted_stride;
+    for (uint32_t e0 = lo + threadIdx.x; e0 < hi; e0 += BS_U * blockDim.x) {            // BS_U loads in flight per lane
+        uint32_t k[BS_U];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) if (e + u >= base && e + u < end) atomicAdd(&cnt[(w0 >> (8 * u)) & 0xffu], 1u);
+        for (uint32_t u = 0; u < BS_U; u++) { const uint32_t e = e0 + u * blockDim.x; k[u] = e < hi ? mlow[e] : 0xffffffffu; }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) if (e + step + u < end) atomicAdd(&cnt[(w1 >> (8 * u)) & 0xffu], 1u);
+        for (uint32_t u = 0; u < BS_U; u++) if (k[u] != 0xffffffffu) atomicAdd(&cnt[k[u]], 1u);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nlow; b += blockDim.x) { sm[bin * nlow + b] = cnt[b]; cur[b] = cnt[b]; }   // hist[bucket]
+    uint32_t* hist = sm + (size_t)bin * nlow;
+    for (uint32_t b = threadIdx.x; b < nlow; b += blockDim.x) {
+        const uint32_t v = cnt[b];
+        if (v) atomicAdd(&hist[b], v);
+    }
+}
+ZK_KERNEL void msm_bsort_place_kernel(MsmPlan p) {
+    ZK_DYN_SHARED(uint32_t, cnt);                          // [2^low_bits]: counts, then the chunk's cursor per bucket
+    const uint32_t col = blockIdx.y, nlow = 1u << p.low_bits;
+    uint32_t* sm = plan_small(p, col);
+    uint32_t bin, lo, hi;
+    if (!bsort_chunk(p, sm, bin, lo, hi)) return;
+    for (uint32_t b = threadIdx.x; b < nlow; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    block_incscan(cur, tmp, nlow);
-    for (uint32_t b = threadIdx.x; b < nlow; b += blockDim.x) tmp[b] = base + cur[b] - cnt[b];
+    const uint32_t* __restrict__ mref = p.mid_ref + (size_t)col * p.sorted_stride;
+    const uint16_t* __restrict__ mlow = p.mid_low + (size_t)col * p.sorted_stride;
+    for (uint32_t e0 = lo + threadIdx.x; e0 < hi; e0 += BS_U * blockDim.x) {            // BS_U loads in flight per lane
+        uint32_t k[BS_U];
+#pragma unroll
+        for (uint32_t u = 0; u < BS_U; u++) { const uint32_t e = e0 + u * blockDim.x; k[u] = e < hi ? mlow[e] : 0xffffffffu; }
+#pragma unroll
+        for (uint32_t u = 0; u < BS_U; u++) if (k[u] != 0xffffffffu) atomicAdd(&cnt[k[u]], 1u);
+    }
+    __syncthreads();
+    uint32_t* cursor = sm + p.o_cursor + (size_t)bin * nlow;
+    for (uint32_t b0 = threadIdx.x; b0 < nlow; b0 += 4 * blockDim.x) {    // 4 reservations in flight per thread
+        uint32_t v[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t b = b0 + u * blockDim.x; v[u] = b < nlow ? cnt[b] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = v[u] ? atomicAdd(&cursor[b0 + u * blockDim.x], v[u]) : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t b = b0 + u * blockDim.x; if (b < nlow) cnt[b] = r[u]; }
+    }
     __syncthreads();
     uint32_t* __restrict__ sorted = p.sorted + (size_t)col * p.sorted_stride;
-    for (uint32_t e = a0 + 4 * threadIdx.x; e < end; e += 2 * step) {
-        const bool two = e + step < end;
-        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(mlow + e);
-        const uint4 r0 = *reinterpret_cast<const uint4*>(mref + e);
-        const uint32_t w1 = two ? *reinterpret_cast<const uint32_t*>(mlow + e + step) : 0u;
-        const uint4 r1 = two ? *reinterpret_cast<const uint4*>(mref + e + step) : make_uint4(0, 0, 0, 0);
-        const uint32_t v0[4] = {r0.x, r0.y, r0.z, r0.w}, v1[4] = {r1.x, r1.y, r1.z, r1.w};
+    for (uint32_t e0 = lo + threadIdx.x; e0 < hi; e0 += BS_U * blockDim.x) {            // (issuing the next round's loads before this round's stores measured slower)
+        uint32_t k[BS_U], r[BS_U], d[BS_U];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) if (e + u >= base && e + u < end) sorted[atomicAdd(&tmp[(w0 >> (8 * u)) & 0xffu], 1u)] = v0[u];
+        for (uint32_t u = 0; u < BS_U; u++) { const uint32_t e = e0 + u * blockDim.x; const bool in = e < hi; k[u] = in ? mlow[e] : 0xffffffffu; r[u] = in ? mref[e] : 0u; }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) if (e + step + u < end) sorted[atomicAdd(&tmp[(w1 >> (8 * u)) & 0xffu], 1u)] = v1[u];
+        for (uint32_t u = 0; u < BS_U; u++) d[u] = k[u] != 0xffffffffu ? atomicAdd(&cnt[k[u]], 1u) : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < BS_U; u++) if (k[u] != 0xffffffffu) sorted[d[u]] = r[u];
     }
 }
 
@@ -792,7 +848,13 @@ ZK_KERNEL void g1_gtab_row0_kernel(void* row_xyzz) {  // 255 threads: d*G by dou
 static int windows_for(int c) { return 254 / c + 1; }
 
 static int pick_c(size_t n, const Tune& t) {
-    if (t.msm_c >= 3 && t.msm_c <= 16) return t.msm_c;
+    if (t.msm_c >= 3 && t.msm_c <= MSM_MAX_C) return t.msm_c;
+    // From 2^22 points a 20-bit window: 13 windows per scalar instead of 16 (-19 % additions) for 2^19 buckets and the two-level sort — measured on single MSMs
+    // (profiles/r05/run353, run354): 2^22 627 -> 699, 2^23 683 -> 775, 2^24 704 -> 827 Mscalar/s; 2^21 +5 %, 2^20 -3 %.  Not below: the prover's BATCHES at
+    // k = 20 / 21 lose what the shorter chains save to the per-column bucket reduction (x 4 buckets) and the two-level sort (k = 21: 226 -> 229 ms per proof).
+    // Of the wider windows only c = 20 has a well-filled top window (254 = 12 x 20 + 14 bits): at c = 18, 19, 21, 22 the top digit of every scalar falls into the
+    // lowest 2^2 .. 2^12 buckets (1/W of all pairs: deep merge levels there, and c = 22 measured behind c = 20 at 2^24).
+    if (n >= ((size_t)1 << 22)) return 20;
     int best = 3;
     double best_cost = 1e300;
     for (int c = 3; c <= 16; c++) {
@@ -1019,13 +1081,16 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     p.o_remstart = p.o_remhist + REM_CLASSES;
     p.o_remcursor = p.o_remstart + REM_CLASSES;
     p.o_bintot = p.o_remcursor + REM_CLASSES;
-    p.o_bincur = p.o_bintot + MSM_MAX_BINS;
-    p.small_stride = p.o_bincur + MSM_MAX_BINS;
-    p.low_bits = (uint32_t)std::min(7, c - 1);
+    p.low_bits = c <= 16 ? (uint32_t)std::min(7, c - 1) : (uint32_t)std::max(c - 1 - std::min(std::max(tn.msm_wide_bins_log, 8), 11), 5);      // c <= 16: at most 256 bins of 128 buckets; wider: 2^msm_wide_bins_log bins
     p.nbin = B >> p.low_bits;
-    const int part_threads = std::min(256, tn.msm_sort_threads);
-    p.pch = std::min<uint32_t>(std::max<uint32_t>(1, MSM_PART_PAIRS / (uint32_t)W), PART_SPT * (uint32_t)part_threads);
-    if (p.nbin > MSM_MAX_BINS) return ctx->fail(ZK_ERR_LIMIT, "zk_msm: window width c = %d exceeds 16", c);
+    p.bch = (uint32_t)std::max(64, tn.msm_bsort_chunk);
+    p.o_bincur = p.o_bintot + p.nbin;
+    p.o_binbase = p.o_bincur + p.nbin;
+    p.o_chunkbase = p.o_binbase + p.nbin + 1;
+    p.small_stride = p.o_chunkbase + p.nbin + 1;
+    const int part_threads = std::min(std::max(tn.msm_part_threads, 64), std::min(1024, tn.msm_sort_threads));
+    p.pch = std::min<uint32_t>(std::max<uint32_t>(1, (uint32_t)std::min(std::max(tn.msm_part_pairs, 64), 16384) / (uint32_t)W), PART_SPT * (uint32_t)part_threads);
+    if (p.nbin > MSM_MAX_BINS || (1u << p.low_bits) > MSM_MAX_LOW) return ctx->fail(ZK_ERR_LIMIT, "zk_msm: window width c = %d exceeds %d", c, MSM_MAX_C);
     ZK_HIP(ctx->ws_small.ensure((size_t)nb * p.small_stride * 4 + 2 * (size_t)nb * sizeof(void*) + 64));
     p.small = (uint32_t*)ctx->ws_small.p;
     const void** d_ptrs = (const void**)((char*)ctx->ws_small.p + (((size_t)nb * p.small_stride * 4 + 15) & ~(size_t)15));
@@ -1035,9 +1100,9 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     p.sorted_stride = (pairs_max + 4 + 15) & ~(uint64_t)15;      // columns of the 1-, 4-byte arrays start 16-byte aligned
     ZK_HIP(ctx->ws_sorted.ensure((size_t)nb * p.sorted_stride * 4));
     p.sorted = (uint32_t*)ctx->ws_sorted.p;
-    ZK_HIP(ctx->ws_mid.ensure((size_t)nb * p.sorted_stride * 5 + 64));          // (vector loads may touch the 3 entries after a column's last)
+    ZK_HIP(ctx->ws_mid.ensure((size_t)nb * p.sorted_stride * 6 + 64));          // (vector loads may touch the 3 entries after a column's last)
     p.mid_ref = (uint32_t*)ctx->ws_mid.p;
-    p.mid_low = (uint8_t*)ctx->ws_mid.p + (size_t)nb * p.sorted_stride * 4;
+    p.mid_low = (uint16_t*)((char*)ctx->ws_mid.p + (size_t)nb * p.sorted_stride * 4);
     p.sub_stride[0] = cap[0];
     p.sub_stride[1] = R >= 1 ? cap[1] : 1;
     ZK_HIP(ctx->ws_sub0.ensure((size_t)nb * p.sub_stride[0] * 128));
@@ -1063,14 +1128,17 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     // one-level sort: the rank registers of msm_scatter_kernel hold SC_SPT scalars per thread and 16-bit ranks
     const uint64_t chunk_max = std::min<uint64_t>((uint64_t)SC_SPT * tn.msm_sort_threads, 65536 / (uint64_t)W);
     const uint64_t need = (n + chunk_max - 1) / chunk_max;
-    const bool two_level = W > (int)SC_WMAX || tn.msm_two_level_sort != 0;   // (tiny inputs pick narrow windows: more of them than the rank registers cover)
+    const bool two_level = W > (int)SC_WMAX || c > 16 || tn.msm_two_level_sort != 0;   // (tiny inputs pick narrow windows: more of them than the rank registers cover; wide windows: more counters than LDS)
+    const uint32_t bsort_grid = (uint32_t)(pairs_max / p.bch) + p.nbin;       // >= sum over bins of ceil(size / bch): workgroups past the last chunk exit
     EvTimer t_sort(ctx, "msm_sort");
     if (two_level) {
         ZK_LAUNCH(msm_bin_hist_kernel, dim3(wgs, nb), tn.msm_sort_threads, 0, st, p);
         ZK_CHECK_LAUNCH();
-        ZK_LAUNCH(msm_partition_kernel, dim3(ceil_div(p.n, p.pch), nb), part_threads, (size_t)p.pch * W * 6, st, p);
+        ZK_LAUNCH(msm_bin_base_kernel, nb, 256, 0, st, p);
         ZK_CHECK_LAUNCH();
-        ZK_LAUNCH(msm_bucket_sort_kernel, dim3(p.nbin, nb), std::min(tn.msm_bsort_threads, tn.msm_sort_threads), 0, st, p);
+        ZK_LAUNCH(msm_partition_kernel, dim3(ceil_div(p.n, p.pch), nb), part_threads, ((size_t)p.pch * W * 2 + 4 * (size_t)p.nbin) * 4, st, p);
+        ZK_CHECK_LAUNCH();
+        ZK_LAUNCH(msm_bsort_count_kernel, dim3(bsort_grid, nb), tn.msm_bsort_threads, (size_t)4 << p.low_bits, st, p);
         ZK_CHECK_LAUNCH();
     } else {
         ZK_LAUNCH(msm_hist_kernel, dim3(wgs, nb), tn.msm_sort_threads, (size_t)B * 4, st, p);
@@ -1082,7 +1150,10 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     ZK_CHECK_LAUNCH();
     ZK_LAUNCH(msm_scan_apply_kernel, dim3(scan_tiles, nb), SC_T, 0, st, p);
     ZK_CHECK_LAUNCH();
-    if (!two_level) {
+    if (two_level) {
+        ZK_LAUNCH(msm_bsort_place_kernel, dim3(bsort_grid, nb), tn.msm_bsort_threads, (size_t)4 << p.low_bits, st, p);
+        ZK_CHECK_LAUNCH();
+    } else {
         ZK_LAUNCH(msm_scatter_kernel, dim3((uint32_t)std::max<uint64_t>(need, (uint64_t)wgs), nb), tn.msm_sort_threads, (size_t)B * 4, st, p);
         ZK_CHECK_LAUNCH();
     }
@@ -1274,7 +1345,7 @@ int g1_fixed_base_mul(zk_ctx* ctx, const void* d_scalars, size_t n, void* d_out_
 
 int msm_set_lds_attr() {
 #ifndef ZK_EMU
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msm_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msm_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msm_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msm_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif

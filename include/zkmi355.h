@@ -92,7 +92,11 @@ int zk_dev_upload_batch(zk_ctx* ctx, void* const* dptrs_dev, const void* const* 
  * halo2_proofs src/arithmetic.rs best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1 and
  * src/poly/kzg/commitment.rs commit{,_lagrange} (bases = params.g / params.g_lagrange, fixed per
  * SRS).  A base table is registered once (copied to HBM and expanded to its window multiples
- * 2^(c*j) * P_i so that every window shares one bucket set); each MSM then only ships scalars.  */
+ * 2^(c*j) * P_i so that every window shares one bucket set); each MSM then only ships scalars.
+ * The window width c is chosen at registration from the TABLE's size (16 bits for 2^17 .. 2^21 points — the
+ * prover's sizes, whose batches pay a bucket reduction per column — and 20 bits from 2^22 points: 13 windows per
+ * scalar instead of 16 for single large MSMs; tune "msm_c" = 3 .. 22 before registering overrides it), so register
+ * the table of the size you commit with — halo2's ParamsKZG::downsize(k) — rather than a prefix of a much larger SRS. */
 int zk_bases_register(zk_ctx* ctx, const void* g1_affine_host, size_t n, uint64_t* handle);
 int zk_bases_register_dev(zk_ctx* ctx, const void* g1_affine_dev, size_t n, uint64_t* handle);
 int zk_bases_release(zk_ctx* ctx, uint64_t handle);

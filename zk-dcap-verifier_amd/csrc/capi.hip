@@ -179,6 +179,21 @@ zk_ctx* zk_internal_helper_ctx(zk_ctx* ctx) {
     if (!h) {                                                          // made outside the lock (a context is a stream and three attribute calls); of two proofs that start together one wins, the other's goes
         zk_ctx* made = nullptr;
         if (zk_ctx_create(ctx->device, &made) != ZK_OK) return nullptr;
+#ifndef ZK_EMU
+        {   // The lane only helps if its stream runs on ANOTHER hardware queue than the proof's: the runtime spreads a process's streams of one priority over four queues
+            // (GPU_MAX_HW_QUEUES), so beside four proving contexts the fifth stream shares one — with its own proof's stream one time in four, and the two then run in
+            // turn (profiles/r05/run360: 63.8 ms for the proof alone, 57.5 when the queues differ).  Streams of another priority get queues of their own.
+            int lane_prio;
+            { LOCK; lane_prio = ctx->tune.prover_lane_priority; }
+            int least = 0, greatest = 0;
+            hipStream_t s = nullptr;
+            if (lane_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
+                hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lane_prio > 0 ? least : greatest) == hipSuccess) {
+                (void)hipStreamDestroy(made->stream);
+                made->stream = s;
+            }
+        }
+#endif
         {
             LOCK;
             if (!ctx->helper) { ctx->helper = made; made = nullptr; }
@@ -244,7 +259,7 @@ static int* tune_slot(zk_ctx* ctx, const char* key) {
     struct { const char* k; int* v; } tab[] = {
         {"msm_c", &t.msm_c}, {"msm_sort_wgs", &t.msm_sort_wgs}, {"msm_sort_threads", &t.msm_sort_threads}, {"msm_sort_batch_wgs", &t.msm_sort_batch_wgs}, {"msm_bsort_threads", &t.msm_bsort_threads}, {"msm_bsort_chunk", &t.msm_bsort_chunk}, {"msm_wide_bins_log", &t.msm_wide_bins_log}, {"msm_part_threads", &t.msm_part_threads}, {"msm_part_pairs", &t.msm_part_pairs}, {"msm_two_level_sort", &t.msm_two_level_sort},
         {"msm_target_threads", &t.msm_target_threads}, {"msm_min_chunk", &t.msm_min_chunk}, {"msm_max_chunk", &t.msm_max_chunk},
-        {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block}, {"msm_runs", &t.msm_runs}, {"prover_side_lane", &t.prover_side_lane},
+        {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block}, {"msm_runs", &t.msm_runs}, {"prover_side_lane", &t.prover_side_lane}, {"prover_lane_priority", &t.prover_lane_priority},
         {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log}, {"ntt_coset_table", &t.ntt_coset_table}, {"ntt_col_major", &t.ntt_col_major},
         {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}, {"lookup_force_generic_sort", &t.lookup_force_generic_sort},
         {"ntt_quarter_input", &t.ntt_quarter_input}, {"ntt_fuse_scale", &t.ntt_fuse_scale}, {"quot_piece_cosets", &t.quot_piece_cosets}, {"quot_factor_horner", &t.quot_factor_horner}, {"quot_degree_split", &t.quot_degree_split}, {"quot_group_factors", &t.quot_group_factors}, {"ntt_ws_limit_mb", &t.ntt_ws_limit_mb}, 

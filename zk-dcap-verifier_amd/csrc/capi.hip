@@ -188,7 +188,7 @@ zk_ctx* zk_internal_helper_ctx(zk_ctx* ctx) {
             int least = 0, greatest = 0;
             hipStream_t s = nullptr;
             if (lane_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
-                hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lane_prio > 0 ? least : greatest) == hipSuccess) {
+                hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lane_prio == 1 ? least : greatest) == hipSuccess) {
                 (void)hipStreamDestroy(made->stream);
                 made->stream = s;
             }

@@ -34,7 +34,7 @@ struct Tune {
     int msm_merge_fanin = 8;
     int msm_tree_fanin = 2;
     int msm_block = 128;         // threads per workgroup of the curve-arithmetic kernels
-    int prover_lane_priority = 1;  // the helper context's stream: 1 = the device's lowest stream priority, -1 = its highest, 0 = the default priority (capi.hip, zk_internal_helper_ctx: a queue of its own)
+    int prover_lane_priority = 1;  // the helper context's stream: 1 = the device's lowest stream priority, 2 = its highest, 0 = the default priority (capi.hip, zk_internal_helper_ctx: a queue of its own)
     int prover_side_lane = 1;    // zk_plonk_create_proof (single-GPU keys on the extended domain): lagrange_to_coeff + coeff_to_extended of a phase's columns on the helper context while the phase's commitments run; 1 = when at most two proofs are in flight in the process, 2 = always, 0 = never
     int msm_runs = 1;            // commit run-heavy columns through adjacent differences against the prefix-sum table (when the table has one)
     int ntt_tile_log = 10;       // log2(elements) of the LDS tile of one NTT workgroup (sweep: profiles/r01/run6_ntt_plan_sweep.txt)

@@ -31,6 +31,7 @@ struct Tune {
     int msm_target_threads = 1 << 19;  // sub-bucket count the accumulate launch aims for
     int msm_min_chunk = 16;      // min pairs per accumulate thread
     int msm_max_chunk = 48;        // fixed-size sub-buckets keep all 64 lanes of a wave equally loaded (profiles/r01); 32 -> 48 with the 29-bit chain, whose per-chain entry and exit cost 6 products (profiles/r03: -0.6 %)
+    int msm_max_chunk_wide = 128;  // ... of tables with windows wider than 16 bits
     int msm_merge_fanin = 8;
     int msm_tree_fanin = 2;
     int msm_block = 128;         // threads per workgroup of the curve-arithmetic kernels

@@ -1057,8 +1057,10 @@ static int msm_core(zk_ctx* ctx, const BaseTable& bt, const void* const* h_scal_
     uint32_t Mlog = 1;
     while ((2u << Mlog) <= (uint32_t)std::max(2, tn.msm_merge_fanin) && Mlog < 8) Mlog++;
     const uint32_t M = 1u << Mlog;   // merge fan-in rounded down to a power of two
+    // (wide windows = single large MSMs: hundreds of pairs per bucket, so longer sub-buckets halve the merge level's work — 2^24: reduction 1.33 -> 0.82 ms at 128, profiles/r05/run368;
+    //  the prover's batches measure flat from 48 to 96: run369)
     uint32_t L = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)nb * pairs_max / (uint64_t)tn.msm_target_threads, (uint64_t)tn.msm_min_chunk),
-                                              (uint64_t)tn.msm_max_chunk);
+                                              (uint64_t)(c > 16 ? tn.msm_max_chunk_wide : tn.msm_max_chunk));
     MsmPlan p;
     memset(&p, 0, sizeof p);
     p.n = (uint32_t)n; p.n_table = (uint32_t)bt.n; p.B = B; p.L = L; p.M = M; p.Mlog = Mlog; p.nb = nb; p.c = c; p.W = W;

@@ -233,6 +233,35 @@ def test_sgx_shaped_circuit_proof_verifies_gpu(gpu, orc, k):
     _sgx_shaped(gpu, k)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", [17, 20])
+def test_proof_bytes_do_not_depend_on_the_msm_window_gpu(gpu, orc, c):
+    """SRS tables of 2^22 points and more are registered with 20-bit windows (csrc/msm.hip pick_c): the prover's batched commitments, the run-length twin
+    tables and the two-level sort then run on wide windows.  A commitment is a group element, so the proof bytes must not move: the k = 8 golden of the
+    independent CPU prover reproduced with the window forced wide, and a k = 13 proof equal to the default window's."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sgx_shaped_circuit as sc
+    gpu.tune(msm_c=c)
+    try:
+        _sgx_shaped(gpu, 8)                                            # asserts the golden bytes at k = 8
+        proofs = []
+        for cc in (c, 0):
+            gpu.tune(msm_c=cc)
+            cs, fixed, asm, advice = sc.build(z, gpu, 13)
+            params = z.kzg.ParamsKZG.setup(13, TAU, backend=gpu)
+            pk = plonk.keygen(params, cs, fixed, asm)
+            tr = Blake2bWrite()
+            plonk.create_proof(params, pk, advice, [], np.random.default_rng(5), tr)
+            proofs.append(tr.finalize())
+            pk.release()
+            params.release()
+        assert proofs[0] == proofs[1]
+    finally:
+        gpu.tune(msm_c=0)
+
+
 def test_cpu_prover_reproduces_the_committed_goldens(orc):
     """tests/golden/{toy_proof_k6_seed7, sgx_shaped_k8_seed3}.bin are what oracle/prover.py (independent CPU prover: Python integers, quotient from
     its definition) emits — regenerate them here and compare, so the goldens cannot drift from their generator; verify_proof accepts both."""

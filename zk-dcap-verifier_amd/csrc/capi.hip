@@ -260,7 +260,7 @@ static int* tune_slot(zk_ctx* ctx, const char* key) {
         {"msm_c", &t.msm_c}, {"msm_sort_wgs", &t.msm_sort_wgs}, {"msm_sort_threads", &t.msm_sort_threads}, {"msm_sort_batch_wgs", &t.msm_sort_batch_wgs}, {"msm_bsort_threads", &t.msm_bsort_threads}, {"msm_bsort_chunk", &t.msm_bsort_chunk}, {"msm_wide_bins_log", &t.msm_wide_bins_log}, {"msm_part_threads", &t.msm_part_threads}, {"msm_part_pairs", &t.msm_part_pairs}, {"msm_two_level_sort", &t.msm_two_level_sort},
         {"msm_target_threads", &t.msm_target_threads}, {"msm_min_chunk", &t.msm_min_chunk}, {"msm_max_chunk", &t.msm_max_chunk},
         {"msm_max_chunk_wide", &t.msm_max_chunk_wide}, {"msm_merge_fanin", &t.msm_merge_fanin}, {"msm_tree_fanin", &t.msm_tree_fanin}, {"msm_block", &t.msm_block}, {"msm_runs", &t.msm_runs}, {"prover_side_lane", &t.prover_side_lane}, {"prover_lane_priority", &t.prover_lane_priority},
-        {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log}, {"ntt_coset_table", &t.ntt_coset_table}, {"ntt_col_major", &t.ntt_col_major},
+        {"ntt_tile_log", &t.ntt_tile_log}, {"ntt_threads", &t.ntt_threads}, {"ntt_max_radix_log", &t.ntt_max_radix_log}, {"ntt_plan", &t.ntt_plan}, {"ntt_full_twiddle_max_log", &t.ntt_full_twiddle_max_log}, {"ntt_coset_table", &t.ntt_coset_table}, {"ntt_col_major", &t.ntt_col_major},
         {"vec_block", &t.vec_block}, {"quot_threads", &t.quot_threads}, {"lookup_force_generic_sort", &t.lookup_force_generic_sort},
         {"ntt_quarter_input", &t.ntt_quarter_input}, {"ntt_fuse_scale", &t.ntt_fuse_scale}, {"quot_piece_cosets", &t.quot_piece_cosets}, {"quot_factor_horner", &t.quot_factor_horner}, {"quot_degree_split", &t.quot_degree_split}, {"quot_group_factors", &t.quot_group_factors}, {"ntt_ws_limit_mb", &t.ntt_ws_limit_mb}, 
         {"quot_jit", &t.quot_jit}, {"quot_jit_group", &t.quot_jit_group}, {"quot_jit_waves", &t.quot_jit_waves}, {"quot_remat_ops", &t.quot_remat_ops}, {"quot_remat_distance", &t.quot_remat_distance}};

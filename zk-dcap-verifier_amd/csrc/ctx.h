@@ -41,6 +41,7 @@ struct Tune {
     int ntt_tile_log = 10;       // log2(elements) of the LDS tile of one NTT workgroup (sweep: profiles/r01/run6_ntt_plan_sweep.txt)
     int ntt_threads = 256;
     int ntt_max_radix_log = 8;
+    int ntt_plan = 0;            // measurement knob: three radices as decimal digits for the transforms they fit (0 = balanced)
     int ntt_col_major = 1;               // strided passes of a batch walk the columns of one tile before the next tile (NttPassArgs::col_major)
     int ntt_coset_table = 1;             // coset transforms of two passes and more: the pre-scaling ZETA^(m mod 3) * ext_omega^(coset * m) from ONE table per coset (32 B/element, one product) instead of two-level powers (up to 2.67 products)
     int ntt_full_twiddle_max_log = 24;   // up to this size inter-pass twiddles come from full HBM tables (32 B/element/pass)

@@ -532,6 +532,14 @@ static void plan_passes(uint32_t log_n, const Tune& tn, uint32_t rl[3], int* pas
     if (p < 1) p = 1;
     if (p > 3) p = 3;
     rl[0] = rl[1] = rl[2] = 0;
+    if (tn.ntt_plan > 0) {                                              // measurement knob: the radices as decimal digits ("885" = 2^8, 2^8, 2^5), taken when they fit this transform
+        const uint32_t d[3] = {(uint32_t)tn.ntt_plan / 100 % 10, (uint32_t)tn.ntt_plan / 10 % 10, (uint32_t)tn.ntt_plan % 10};
+        if (d[0] && d[1] && d[2] && d[0] + d[1] + d[2] == log_n && d[0] <= rmax && d[1] <= rmax && d[2] <= rmax) {
+            rl[0] = d[0]; rl[1] = d[1]; rl[2] = d[2];
+            *passes = 3;
+            return;
+        }
+    }
     uint32_t rem = log_n;
     for (int i = 0; i < p; i++) {
         uint32_t r = (rem + (p - i) - 1) / (p - i);

@@ -852,8 +852,8 @@ static int pick_c(size_t n, const Tune& t) {
     // From 2^22 points a 20-bit window: 13 windows per scalar instead of 16 (-19 % additions) for 2^19 buckets and the two-level sort — measured on single MSMs
     // (profiles/r05/run353, run354): 2^22 627 -> 699, 2^23 683 -> 775, 2^24 704 -> 827 Mscalar/s; 2^21 +5 %, 2^20 -3 %.  Not below: the prover's BATCHES at
     // k = 20 / 21 lose what the shorter chains save to the per-column bucket reduction (x 4 buckets) and the two-level sort (k = 21: 226 -> 229 ms per proof).
-    // Of the wider windows only c = 20 has a well-filled top window (254 = 12 x 20 + 14 bits): at c = 18, 19, 21, 22 the top digit of every scalar falls into the
-    // lowest 2^2 .. 2^12 buckets (1/W of all pairs: deep merge levels there, and c = 22 measured behind c = 20 at 2^24).
+    // Of the wider windows only c = 17 and c = 20 have a well-filled top window (254 = 14 x 17 + 16 = 12 x 20 + 14 bits): at c = 18, 19, 21, 22 the top digit of every scalar
+    // falls into the lowest 2^2 .. 2^12 buckets (1/W of all pairs: deep merge levels there, and c = 22 measured behind c = 20 at 2^24).
     if (n >= ((size_t)1 << 22)) return 20;
     int best = 3;
     double best_cost = 1e300;

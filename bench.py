@@ -562,6 +562,15 @@ def msm_microbench(be, log_n, seed, reps=3, verify=False):
     dt = (time.time() - t) / reps
     out = {"log_n": log_n, "ms": round(dt * 1e3, 3), "Mscalar_per_s": round(n / dt / 1e6, 2), "hbm_frac_algorithmic": round(96 * n / dt / 1e9 / HBM_PEAK_GBS, 5),
            "table_expand_s": round(t_reg, 3)}
+    # one more call with the library's HIP-event timers on: where the time goes (the window width is the library's choice for the table size: 16 bits below 2^22 points, 20 from there)
+    be.timing(True)
+    be.msm(h, ks, n)
+    ph = {lab: be.timing_get(lab)[0] for lab in ("msm_sort", "msm_accumulate", "msm_reduce")}
+    pairs = be.stat_get("msm_pairs")
+    be.timing(False)
+    out["phase_ms"] = {lab: round(v, 3) for lab, v in ph.items() if v is not None}
+    if pairs:
+        out["windows_per_scalar"] = round(pairs / n, 2)
     if verify:
         # the limb arrays are Montgomery forms: value = limbs * R^-1; sum_i s_i k_i = (sum_i S_i K_i) * R^-2, and the
         # fixed-base kernel takes a Montgomery scalar, so feed it (sum S_i K_i) * R^-1

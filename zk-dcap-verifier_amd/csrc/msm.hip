@@ -155,8 +155,8 @@ ZK_HD uint32_t plan_eff_levels(const MsmPlan& p, uint32_t max_s) {  // merge rou
 //        bsort_count / bsort_place   a bin's run is cut into chunks of <= bch entries, one workgroup each, <= MSM_MAX_LOW bucket counters in LDS: count adds the
 //                    chunk's bucket sizes to the histogram the scans below start from; place (after the scans) reserves and fills the chunk's slots of `sorted`.
 // reference = (negative << 31) | (window * n_table + scalar index)
-// It is also the ONLY sort for windows wider than 16 bits (c = 17 .. 22: 2^(c-1) counters do not fit one CU's LDS): 256 bins of 2^8 .. 2^13 buckets.
-// Wide windows pay where n is large against the bucket count — 2^24 scalars at c = 22 are 12 windows instead of 16 (-25 % additions) for 2^21 buckets.
+// It is also the ONLY sort for windows wider than 16 bits (c = 17 .. 22: 2^(c-1) counters do not fit one CU's LDS): 2^msm_wide_bins_log bins (512) of 2^7 .. 2^12 buckets.
+// Wide windows pay where n is large against the bucket count — 2^24 scalars at c = 20 are 13 windows instead of 16 (-19 % additions) for 2^19 buckets (pick_c).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t MSM_MAX_BINS = 2048, MSM_MAX_LOW = 8192;
 constexpr int MSM_MAX_C = 22;
